@@ -1,0 +1,72 @@
+"""torchvision-free ResNet-18 trunk with torchvision's module/attribute names.
+
+The reference builds ``torchvision.models.resnet18(pretrained=True)`` and drives
+``conv1, bn1, relu, maxpool, layer1, layer2`` by hand (reference src/model.py:31,127-132);
+``layer3``/``layer4`` exist only so that checkpoints load and ``train.py`` can freeze them
+(reference train.py:60-64).  torchvision is not installed in this image, so the trunk is
+restated here with identical ``state_dict`` keys.  Runs on
+PyTorch-ROCm (MIOpen) -- the CNN front-end is a "next" row, not a
+hand-kernel target this round.
+"""
+import torch.nn as nn
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        y = self.relu(self.bn1(self.conv1(x)))
+        y = self.bn2(self.conv2(y))
+        return self.relu(y + idt)
+
+
+class ResNet18(nn.Module):
+    """Same parameter/buffer names as torchvision.models.resnet18()."""
+
+    def __init__(self, num_classes=1000):
+        super().__init__()
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        self.layer1 = self._stage(64, 2, 1)
+        self.layer2 = self._stage(128, 2, 2)
+        self.layer3 = self._stage(256, 2, 2)
+        self.layer4 = self._stage(512, 2, 2)
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Linear(512, num_classes)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
+
+    def _stage(self, planes, blocks, stride):
+        down = None
+        if stride != 1 or self.inplanes != planes:
+            down = nn.Sequential(nn.Conv2d(self.inplanes, planes, 1, stride, bias=False),
+                                 nn.BatchNorm2d(planes))
+        layers = [BasicBlock(self.inplanes, planes, stride, down)]
+        self.inplanes = planes
+        for _ in range(1, blocks):
+            layers.append(BasicBlock(planes, planes))
+        return nn.Sequential(*layers)
+
+
+def resnet18(pretrained=False, **kw):
+    # ImageNet weights are not obtainable offline; every rel_pose checkpoint overrides them anyway
+    # (reference src/model.py:31 comment).
+    return ResNet18(**kw)

@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by importing the REAL reference (build container only).
+
+    python -B tests/golden/make_fixtures.py            # writes tests/golden/*.npz, *.json
+
+The reference (/root/reference, read-only, Python) cannot travel to the GPU box, so its outputs on
+closed-form (RNG-free) inputs and weights are committed here as data.  Harness-side shims, reference
+files untouched:
+  * torch.Tensor.cuda -> identity  (vision_transformer.py:209,211 and model.py:164 hard-code .cuda())
+  * sys.modules['torchvision.models'].resnet18 -> this repo's torchvision-free trunk (same keys)
+  * sys.modules['lietorch'].SE3 -> thin wrapper exposing .data / __getitem__ (all the model path uses)
+Inputs/weights come from oracle.relpose_oracle.closed_form (integer hash), so tests regenerate them
+bit-identically and only OUTPUTS are stored.
+"""
+import json
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = os.environ.get("RELPOSE_REFERENCE", "/root/reference")
+
+import numpy as np
+import torch
+
+torch.Tensor.cuda = lambda self, *a, **k: self          # shim 1
+
+from oracle import relpose_oracle as O                   # noqa: E402  (closed-form generators only)
+from rel_pose_amd.modules import resnet as _rn           # noqa: E402
+
+tv = types.ModuleType("torchvision")
+tvm = types.ModuleType("torchvision.models")
+tvm.resnet18 = _rn.resnet18                              # shim 2
+tv.models = tvm
+sys.modules["torchvision"] = tv
+sys.modules["torchvision.models"] = tvm
+
+
+class SE3:                                               # shim 3
+    def __init__(self, data):
+        self.data = data
+
+    def __getitem__(self, idx):
+        return SE3(self.data[idx])
+
+
+lt = types.ModuleType("lietorch")
+lt.SE3 = SE3
+sys.modules["lietorch"] = lt
+
+sys.path.insert(0, REF)
+from src.model import ViTEss                              # noqa: E402  (reference)
+from src.modules import vision_transformer as RVT         # noqa: E402  (reference)
+
+torch.set_num_threads(8)
+torch.manual_seed(0)
+
+
+def ref_args(**kw):
+    a = types.SimpleNamespace(noess="", pool_size=60, fc_hidden_size=512, fusion_transformer=True,
+                              transformer_depth=6, cross_features=False, use_single_softmax=False,
+                              no_pos_encoding=False, l1_pos_encoding=False)
+    a.__dict__.update(kw)
+    # reference does `'noess' in args` (argparse.Namespace supports `in`)
+    return _NS(a.__dict__)
+
+
+class _NS(types.SimpleNamespace):
+    def __init__(self, d):
+        super().__init__(**d)
+
+    def __contains__(self, k):
+        return k in self.__dict__
+
+
+def subsample(t, step=37):
+    return t.detach().reshape(-1)[::step].contiguous().numpy()
+
+
+def summarize(g, n=16):
+    g = g.detach().double().reshape(-1)
+    return np.concatenate([[float(g.sum()), float(g.abs().sum()), float((g * g).sum())], g[:n].numpy(),
+                           np.zeros(max(0, n - g.numel()))])
+
+
+def intrinsics_24(dtype=torch.float32):
+    # already on the 24x24 grid; equal across the two images of a pair (vision_transformer.py:117)
+    a = torch.tensor([[32.373, 25.898, 12.0, 12.0], [18.0, 21.0, 12.0, 9.0]], dtype=dtype)
+    return a[:, None, :].repeat(1, 2, 1).contiguous()
+
+
+def main():
+    out = {}
+    model = ViTEss(ref_args()).eval()
+    ref_keys = {k: list(v.shape) for k, v in model.state_dict().items()}
+    with open(os.path.join(HERE, "state_dict_keys.json"), "w") as f:
+        json.dump(ref_keys, f, indent=0, sort_keys=True)
+
+    shapes = dict(O.vit_param_shapes())
+    shapes.update(O.cnn_param_shapes())
+    sd32 = O.make_state(shapes, torch.float32)
+    # reference also carries resnet.layer3/4 (unused): leave at their constructed values
+    missing, unexpected = model.load_state_dict(sd32, strict=False)
+    assert not unexpected, unexpected
+    assert all(k.startswith("resnet.layer3") or k.startswith("resnet.layer4") for k in missing), missing
+    ft = model.fusion_transformer
+
+    # ---- A: ViT stack on tokens, fp32 and fp64 -------------------------------------------------
+    B = 2
+    tok32 = O.synthetic_tokens(2 * B)
+    intr = intrinsics_24()
+
+    def run_stack(m, tok, intr_):
+        x = tok + m.pos_embed
+        inter = []
+        for l in range(6):
+            x = m.blocks[l](x, intrinsics=intr_)
+            inter.append(x)
+        return m.norm(x), inter
+
+    with torch.no_grad():
+        f32, inter32 = run_stack(ft, tok32, intr.clone())
+    out["vit_feat_f32"] = f32.numpy()
+    out["vit_block0_sub_f32"] = subsample(inter32[0])
+    out["vit_block4_sub_f32"] = subsample(inter32[4])
+    out["vit_block5_f32"] = inter32[5].numpy()
+
+    model64 = ViTEss(ref_args()).eval()
+    sd64 = O.make_state(shapes, torch.float64)
+    model64.load_state_dict(sd32, strict=False)
+    model64 = model64.double()
+    model64.load_state_dict({k: v for k, v in sd64.items()}, strict=False)
+    ft64 = model64.fusion_transformer
+    tok64 = O.synthetic_tokens(2 * B, dtype=torch.float64).requires_grad_(True)
+    f64, inter64 = run_stack(ft64, tok64, intr.clone().double())
+    out["vit_feat_f64"] = f64.detach().numpy()
+    out["vit_block0_sub_f64"] = subsample(inter64[0])
+    out["vit_block4_sub_f64"] = subsample(inter64[4])
+
+    # ---- B: gradients of <feat, cot> through the reference (fp64) -----------------------------
+    cot = O.closed_form(tuple(f64.shape), 991, 1.0, dtype=torch.float64)
+    for p_ in ft64.parameters():
+        p_.grad = None
+    (f64 * cot).sum().backward()
+    out["grad_tokens_sub_f64"] = subsample(tok64.grad)
+    out["grad_tokens_sum_f64"] = summarize(tok64.grad)
+    gnames = []
+    gsum = []
+    for n_, p_ in ft64.named_parameters():
+        if p_.grad is None:
+            continue
+        gnames.append("fusion_transformer." + n_)
+        gsum.append(summarize(p_.grad))
+    out["grad_param_summaries_f64"] = np.stack(gsum)
+    with open(os.path.join(HERE, "grad_param_names.json"), "w") as f:
+        json.dump(gnames, f)
+
+    # ---- regressor + normalise on the stack output (fp32, fp64) --------------------------------
+    Gs = torch.tensor([0, 0, 0, 0, 0, 0, 1.0]).repeat(B, 2, 1)
+    with torch.no_grad():
+        pp32 = model.pose_regressor(f32.reshape(B, -1))
+        out["pose_from_tokens_f32"] = model.normalize_preds(SE3(Gs), pp32, False)[0].data.numpy()
+        pp64 = model64.pose_regressor(f64.detach().reshape(B, -1))
+        out["pose_from_tokens_f64"] = model64.normalize_preds(SE3(Gs.double()), pp64, False)[0].data.numpy()
+
+    # ---- C: positional encodings ---------------------------------------------------------------
+    out["posenc_intr_f32"] = RVT.get_positional_encodings(B, 576, intrinsics=intr.clone()).numpy()
+    out["posenc_none_f32"] = RVT.get_positional_encodings(B, 576, intrinsics=None).numpy()
+    mp = torch.tensor([[517.97, 517.97, 320, 240]] * 2)[None].repeat(1, 1, 1)
+    mp[:, :, [0, 2]] *= 24 / 512
+    mp[:, :, [1, 3]] *= 24 / 384
+    out["posenc_matterport_f32"] = RVT.get_positional_encodings(1, 576, intrinsics=mp).numpy()
+
+    # ---- D: full ViTEss forward (stand-in trunk), eval + train mode ---------------------------
+    for tag, (Bf, H, W) in {"sq": (2, 384, 384), "rect": (1, 256, 320)}.items():
+        imgs = O.synthetic_images(Bf, H, W, key=7 if tag == "sq" else 8)
+        intr_px = torch.tensor([[0.9 * W, 0.8 * W, W / 2.0, H / 2.0]]).repeat(Bf, 2, 1).contiguous()
+        Gsf = torch.tensor([0, 0, 0, 0, 0, 0, 1.0]).repeat(Bf, 2, 1)
+        with torch.no_grad():
+            i_in = intr_px.clone()
+            feats, i_out = model.extract_features(imgs.clone(), i_in.clone())
+            out["full_%s_tokens_sub_f32" % tag] = subsample(feats, 101)
+            pose = model(imgs.clone(), SE3(Gsf), intrinsics=i_in)[0].data
+        out["full_%s_pose_f32" % tag] = pose.numpy()
+        out["full_%s_intr_after" % tag] = i_in.numpy()          # mutated in place by forward
+        with torch.no_grad():
+            pose64 = model64(imgs.double(), SE3(Gsf.double()), intrinsics=intr_px.clone().double())[0].data
+        out["full_%s_pose_f64" % tag] = pose64.numpy()
+    model.train()
+    with torch.no_grad():
+        imgs = O.synthetic_images(2, 384, 384, key=7)
+        intr_px = torch.tensor([[0.9 * 384, 0.8 * 384, 192.0, 192.0]]).repeat(2, 2, 1).contiguous()
+        pose_tr = model(imgs, SE3(torch.tensor([0, 0, 0, 0, 0, 0, 1.0]).repeat(2, 2, 1)), intrinsics=intr_px)[0].data
+    out["full_sq_pose_trainmode_f32"] = pose_tr.numpy()
+    model.eval()
+
+    # ---- F: index ops (bit-exact rows) ---------------------------------------------------------
+    for n_in in (256, 320, 384, 480, 512, 640):
+        ramp = torch.arange(n_in, dtype=torch.float32)[None, None, None, :].repeat(1, 1, 2, 1)
+        res = torch.nn.functional.interpolate(ramp, size=(2, 224))
+        out["nearest224_from_%d" % n_in] = res[0, 0, 0].numpy().astype(np.int32)
+    x = torch.arange(2 * 192 * 576, dtype=torch.float32).reshape(2, 192, 24, 24)
+    tk = x.reshape(2, -1, 576)[:, :192].permute(0, 2, 1)
+    out["token_layout_probe"] = tk[1, ::97, ::31].contiguous().numpy().astype(np.int64)
+
+    np.savez_compressed(os.path.join(HERE, "reference_outputs.npz"), **out)
+    sz = os.path.getsize(os.path.join(HERE, "reference_outputs.npz"))
+    print("wrote reference_outputs.npz: %d arrays, %.1f KB" % (len(out), sz / 1024))
+
+
+if __name__ == "__main__":
+    main()

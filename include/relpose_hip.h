@@ -1,0 +1,142 @@
+/*
+ * relpose_hip.h -- C ABI of librelpose_hip.so (gfx950 / MI355X).
+ *
+ * The reference (crockwell/rel_pose) has NO FFI / plugin interface: its hot path is a chain of stock
+ * ATen calls inside Python modules.  This header is therefore the build-defined
+ * boundary that SURVEY.md 8b specifies: one shared object, extern "C", plain pointers and sizes, no
+ * torch types.  Each entry point names the reference op chain (file:line under /root/reference) it
+ * replaces.  INTEGRATION.md shows the ctypes binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - every pointer is DEVICE memory owned by the caller (PyTorch tensors); the library never
+ *     allocates, frees or keeps global state; workspaces are passed in.
+ *   - `stream` is a hipStream_t (void*); launches are enqueued there and never synchronise.
+ *   - return value: 0 = ok, <0 = RP_E* argument error, >0 = hipError_t from the launch.
+ *   - all tensors are fp32, row-major; "ld*" = row stride in floats.
+ *   - token count per image is 576 (24x24), head dim 64 (reference src/model.py:19-23).
+ */
+#ifndef RELPOSE_HIP_H
+#define RELPOSE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RP_OK 0
+#define RP_EBADSHAPE (-1)
+#define RP_EALIGN (-2)
+#define RP_EWORKSPACE (-3)
+#define RP_EUNSUPPORTED (-4)
+
+/* library / ABI version and target arch string ("gfx950") */
+int rp_abi_version(void);
+const char* rp_target_arch(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense contraction C = epilogue(op(A) * op(B))   (fp32 MFMA v_mfma_f32_32x32x2_f32)
+ * replaces nn.Linear forward and its autograd (dX, dW):
+ *   vision_transformer.py:323,331 (qkv, proj), :191-195,233-234 (cross qkv, proj_fundamental),
+ *   vit_layers/mlp.py:20-26 (fc1, GELU, fc2), src/model.py:91-98 (pose_regressor).
+ * a_layout: 0 = A stored [M,K] (K contiguous), 1 = A stored [K,M] (M contiguous)
+ * b_layout: 0 = B stored [N,K] (K contiguous; nn.Linear weight), 1 = B stored [K,N]
+ * contiguous extents and all ld* must be multiples of 4 (K only when an operand is K-contiguous).
+ * batch > 1: independent problems at A + i*stride_a etc. (split_k must be 1).
+ * split_k > 1: partial products go to `workspace` ([split_k][M][N] floats) and are reduced in a
+ *   fixed order by a second kernel that also applies the epilogue (deterministic).
+ * epilogue, in this order:  v += bias[n];  pre_out[m][n] = v;  act (0 none, 1 exact-erf GELU,
+ *   2 ReLU);  dact (0 none, 1: v *= gelu'(aux[m][n]), 2: v = aux[m][n] > 0 ? v : 0);
+ *   v += residual[m][n];  C[m][n] = v.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct RpGemm {
+  const float* A;
+  const float* B;
+  float* C;
+  int M, N, K;
+  int lda, ldb, ldc;
+  int a_layout, b_layout;
+  int batch;
+  long long stride_a, stride_b, stride_c;
+  int split_k;
+  float* workspace;
+  size_t workspace_bytes;
+  const float* bias;
+  float* pre_out; /* ld = ldc */
+  int act;
+  int dact;
+  const float* aux; /* ld = ldc */
+  const float* residual; /* ld = ldc */
+} RpGemm;
+int rp_gemm(const RpGemm* g, void* stream);
+size_t rp_gemm_workspace_bytes(int M, int N, int split_k);
+
+/* LayerNorm over the last dim C (multiple of 64, <= 512), eps as given (reference uses 1e-6,
+ * vision_transformer.py:396).  Saves mean / rstd per row for the backward. */
+int rp_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                     int rows, int C, float eps, void* stream);
+/* dx = LN'(dy) (+ add if non-null); dgamma_part/dbeta_part: [nblk][C] partial sums, nblk = rp_layernorm_bwd_blocks(rows) */
+int rp_layernorm_bwd_blocks(int rows);
+int rp_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                     const float* add, float* dx, float* dgamma_part, float* dbeta_part, int rows, int C, void* stream);
+
+/* out[c] = sum_r in[r][c]  (two-stage, fixed order).  workspace: rp_colsum_workspace_bytes(rows, cols). */
+size_t rp_colsum_workspace_bytes(int rows, int cols);
+int rp_colsum(const float* in, int rows, int cols, int ld, float* out, float* workspace, size_t workspace_bytes, void* stream);
+
+/* Token layout + learned position embedding: x[z][n][c] = feat[z][c][n] + pos_embed[n][c]
+ * (reference src/model.py:136-141,170-171; index part bit-exact).  feat is the CNN map [Z,C,N]. */
+int rp_tokens_fwd(const float* feat, const float* pos_embed, float* x, int Z, int C, int N, void* stream);
+int rp_tokens_bwd(const float* dx, float* dfeat, int Z, int C, int N, void* stream);
+
+/* Fused softmax attention, N=576 tokens, d=64, heads packed along columns (col = h*64 + e):
+ *   O[z][i][h*64+:] = softmax_j(scale * q_i . k_j) v_j        (vision_transformer.py:325-329)
+ * q/k/v rows for image z: base + (z ^ xor)*576*ld + i*ld.  lse[z][h][i] = log sum_j exp(s_ij) saved
+ * for the backward.  stats_only != 0: only lse is produced (v, o ignored) -- used for the row and
+ * column normalisers of the dual softmax (vision_transformer.py:205-206). */
+int rp_attn_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int Z, int H, int ldq, int ldk,
+                int ldv, int ldo, int q_xor, int k_xor, float scale, int stats_only, void* stream);
+/* delta[z][h][i] = sum_e dO[z][i][h*64+e] * O[z][i][h*64+e] */
+int rp_attn_bwd_delta(const float* dout, const float* o, float* delta, int Z, int H, int ld, void* stream);
+/* dq, dk, dv of the above (recompute-based, two deterministic passes) */
+int rp_attn_bwd(const float* q, const float* k, const float* v, const float* dout, const float* lse, const float* delta,
+                float* dq, float* dk, float* dv, int Z, int H, int ldq, int ldk, int ldv, int lddo, int lddq, int lddk,
+                int lddv, float scale, void* stream);
+
+/* Quadratic positional features (closed form of get_positional_encodings, vision_transformer.py:90-158):
+ * pos[b][n] = (p3^2, p4^2, p3 p4, p3, p4, 1), p3 = lin[n%24]*iy_b, p4 = lin[n/24]*ix_b,
+ * ix = 1/((fx/(2cx))*2), iy = 1/((fy/(2cy))*2) from intrinsics[b][0] (fx,fy,cx,cy); intrinsics == NULL -> ix=iy=1. */
+int rp_posenc(const float* intrinsics, const float* lin24, float* pos, int B, void* stream);
+
+/* Essential Matrix Module (CrossAttention ess branch, vision_transformer.py:198-223), per image z, head h:
+ *   S = scale * q_{z^1} k_z^T ; A = rowsoftmax(S) o colsoftmax(S) = exp(2S - rlse_i - clse_j)
+ *   X_z = [v_z | pos | 0] (576 x 96, 70 live columns);  T = A X_z ;  F = X_z^T T  (70x70 live)
+ * rp_emm_build_x: gathers v from qkv (col 384 + h*64) and pos[z/2] into x[z][h][576][96].
+ * rp_emm_apply : T (optional store, [Z][H][576][96]) and per-workgroup partial F ([Z][H][6][96][96]).
+ *                swap != 0 exchanges the roles of q and k / rlse and clse (gives A^T X: used by the backward).
+ * rp_emm_finalize: g[z^1][c][h*70+a] = sum_wg Fpart[z][h][wg][a][c], zero-padded to ldg (=224) columns
+ *                (the reshape/transpose of vision_transformer.py:229-230 plus the output flip of :238).
+ */
+int rp_emm_build_x(const float* qkv, const float* pos, float* x, int Z, int H, int ldqkv, void* stream);
+int rp_emm_build_x_bwd(const float* dx, float* dqkv, int Z, int H, int ldqkv, void* stream); /* dqkv[:, 384+h*64+e] = dx[..][e] */
+int rp_emm_apply(const float* qkv, int ldqkv, const float* x, const float* rlse, const float* clse, float* t_out,
+                 float* f_part, int Z, int H, float scale, int swap, void* stream);
+int rp_emm_finalize(const float* f_part, float* g, int Z, int H, int ldg, void* stream);
+int rp_emm_finalize_bwd(const float* dg, float* df, int Z, int H, int ldg, void* stream); /* df[z][h][96][96] */
+/* rowdot: out[r] = sum_c a[r][c]*b[r][c], C = 96 */
+int rp_rowdot96(const float* a, const float* b, float* out, long long rows, void* stream);
+/* EMM gradient pass: owner side o (rows i if swap==0, cols j if swap!=0):
+ *   dS = 2 A dA - R rho_i - C gamma_j,  dA = W X^T (swap==0: W rows i) ;  d(owner operand) = scale * dS * other
+ * writes dqkv q-columns of image z^1 (swap==0) or k-columns of image z (swap!=0). */
+int rp_emm_grad(const float* qkv, int ldqkv, const float* x, const float* w, const float* rlse, const float* clse,
+                const float* rho, const float* gamma, float* dqkv, int Z, int H, float scale, int swap, void* stream);
+
+/* q / max(|q|, 0.01), slot 0 <- Gs  (normalize_preds, src/model.py:145-159) */
+int rp_pose_normalize_fwd(const float* pred, const float* gs, float* out, int B, void* stream);
+int rp_pose_normalize_bwd(const float* pred, const float* dout, float* dpred, int B, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RELPOSE_HIP_H */

@@ -1,0 +1,86 @@
+"""ctypes binding of librelpose_hip.so (declared in include/relpose_hip.h).
+
+PyTorch is only plumbing here: it owns device memory and the HIP stream; every hot-path op goes through this
+C ABI.  There is NO fallback: a missing library or a non-zero return code raises."""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p
+
+import torch  # noqa: F401  (must be imported first: it loads the HIP runtime this library binds to)
+
+from . import _build
+
+_LIB = None
+RP_ERRORS = {-1: "bad shape", -2: "misaligned pointer/stride", -3: "workspace too small", -4: "unsupported"}
+
+
+class RpGemm(Structure):
+    _fields_ = [("A", c_void_p), ("B", c_void_p), ("C", c_void_p),
+                ("M", c_int), ("N", c_int), ("K", c_int),
+                ("lda", c_int), ("ldb", c_int), ("ldc", c_int),
+                ("a_layout", c_int), ("b_layout", c_int), ("batch", c_int),
+                ("stride_a", c_longlong), ("stride_b", c_longlong), ("stride_c", c_longlong),
+                ("split_k", c_int), ("workspace", c_void_p), ("workspace_bytes", c_size_t),
+                ("bias", c_void_p), ("pre_out", c_void_p), ("act", c_int), ("dact", c_int),
+                ("aux", c_void_p), ("residual", c_void_p)]
+
+
+P, I, F, L = c_void_p, c_int, c_float, c_longlong
+_SIGS = {
+    "rp_abi_version": (c_int, []),
+    "rp_target_arch": (c_char_p, []),
+    "rp_gemm": (c_int, [POINTER(RpGemm), P]),
+    "rp_gemm_workspace_bytes": (c_size_t, [I, I, I]),
+    "rp_layernorm_fwd": (c_int, [P, P, P, P, P, P, I, I, F, P]),
+    "rp_layernorm_bwd_blocks": (c_int, [I]),
+    "rp_layernorm_bwd": (c_int, [P, P, P, P, P, P, P, P, P, I, I, P]),
+    "rp_colsum_workspace_bytes": (c_size_t, [I, I]),
+    "rp_colsum": (c_int, [P, I, I, I, P, P, c_size_t, P]),
+    "rp_tokens_fwd": (c_int, [P, P, P, I, I, I, P]),
+    "rp_tokens_bwd": (c_int, [P, P, I, I, I, P]),
+    "rp_attn_fwd": (c_int, [P, P, P, P, P, I, I, I, I, I, I, I, I, F, I, P]),
+    "rp_attn_bwd_delta": (c_int, [P, P, P, I, I, I, P]),
+    "rp_attn_bwd": (c_int, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, P]),
+    "rp_posenc": (c_int, [P, P, P, I, P]),
+    "rp_emm_build_x": (c_int, [P, P, P, I, I, I, P]),
+    "rp_emm_build_x_bwd": (c_int, [P, P, I, I, I, P]),
+    "rp_emm_apply": (c_int, [P, I, P, P, P, P, P, I, I, F, I, P]),
+    "rp_emm_finalize": (c_int, [P, P, I, I, I, P]),
+    "rp_emm_finalize_bwd": (c_int, [P, P, I, I, I, P]),
+    "rp_rowdot96": (c_int, [P, P, P, L, P]),
+    "rp_emm_grad": (c_int, [P, I, P, P, P, P, P, P, P, I, I, F, I, P]),
+    "rp_pose_normalize_fwd": (c_int, [P, P, P, I, P]),
+    "rp_pose_normalize_bwd": (c_int, [P, P, P, I, P]),
+}
+EXPORTS = tuple(_SIGS)
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load():
+    """Load (building if the .so is absent) and type the C ABI.  Raises on any failure."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = _build.LIB
+    if not os.path.exists(path):
+        _build.build(verbose=False)
+    try:
+        lib = ctypes.CDLL(path)
+    except OSError as e:
+        raise RuntimeError("rel_pose_amd: cannot load HIP extension %s (%s); there is no CPU fallback" % (path, e))
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)          # AttributeError = symbol missing = broken build
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        if rc < 0:
+            raise RuntimeError("rel_pose_amd: %s failed: %s (RP error %d)" % (what, RP_ERRORS.get(rc, "?"), rc))
+        raise RuntimeError("rel_pose_amd: %s failed: hipError %d" % (what, rc))

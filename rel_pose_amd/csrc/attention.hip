@@ -1,0 +1,314 @@
+// attention.hip -- fused softmax attention for N = 576 tokens, head dim 64 (rp_attn_fwd / rp_attn_bwd).
+//
+// Replaces  attn = softmax(q k^T * scale); x = attn @ v  of reference Attention.forward
+// (src/modules/vision_transformer.py:325-329) without materialising the 576x576 score matrix, and -- in
+// stats_only mode -- produces the row / column log-sum-exp normalisers of the dual softmax of
+// CrossAttention.forward (:205-206).
+//
+// Work split: one wave owns 32 query rows ("owner"); a workgroup of NW waves shares K/V tiles of 32 keys
+// staged in LDS (double buffered, one barrier per tile, next tile's global loads in flight during the
+// MFMAs of the current one).  Everything is computed TRANSPOSED so that all per-query softmax state is
+// lane-local (lane & 31 = query, half-wave = which 16 of the 32 keys):
+//   S^T[kv][q]  = sum_d K[kv][d] Q[q][d]      A = K (LDS, 8 x ds_read_b128 per lane), B = Q (32 VGPRs, pre-scaled)
+//   O^T[d][q]  += sum_kv V[kv][d] P[q][kv]    A = V (LDS, ds_read_b32 rows),          B = P = the S^T accumulators
+// i.e. the score accumulators feed the second MFMA directly as its B operand (register r of half-wave hi is
+// key acc_row(r,hi)), no LDS round trip, no cross-lane traffic except one xor-32 shuffle for the row max.
+// fp32 v_mfma_f32_32x32x2_f32 throughout: 64 MFMAs (4096 cycles) per 32x32 tile pair, exact fp32 products.
+#include "common.h"
+#include "../../include/relpose_hip.h"
+
+namespace {
+
+constexpr int NTOK = 576;
+constexpr int KST = 68;   // LDS row stride (floats) for tiles read along d with ds_read_b128
+constexpr int NTILE = NTOK / 32;
+
+struct AttnP {
+  const float* q; const float* k; const float* v;
+  float* o; float* lse;
+  int H, ldq, ldk, ldv, ldo, q_xor, k_xor;
+  float scale;
+};
+
+// cooperative global -> register prefetch of a [32][64] tile (rows 32, 16 float4 each)
+template <int NT>
+RP_DEV void tile_gload(const float* base, int ld, int tid, float4 (&r)[(512 + NT - 1) / NT]) {
+#pragma unroll
+  for (int j = 0; j < (512 + NT - 1) / NT; ++j) {
+    const int f = tid + NT * j;
+    if (f < 512) r[j] = ld4(base + (long long)(f >> 4) * ld + (f & 15) * 4);
+  }
+}
+template <int NT, int STRIDE>
+RP_DEV void tile_sstore(float* s, int tid, const float4 (&r)[(512 + NT - 1) / NT]) {
+#pragma unroll
+  for (int j = 0; j < (512 + NT - 1) / NT; ++j) {
+    const int f = tid + NT * j;
+    if (f < 512) st4(s + (f >> 4) * STRIDE + (f & 15) * 4, r[j]);
+  }
+}
+
+// S^T tile: s[r] = sum_d Ks[kv = acc_row(r,hi)][d] * breg[q = l31][d]; breg[t] holds d = 32*hi + t
+RP_DEV f32x16 score_tile(const float* Ks, int l31, int hi, const float (&breg)[32]) {
+  f32x16 s = zero16();
+  const float* kr = Ks + l31 * KST + 32 * hi;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const float4 kf = ld4(kr + 4 * c);
+    s = mfma32(kf.x, breg[4 * c + 0], s);
+    s = mfma32(kf.y, breg[4 * c + 1], s);
+    s = mfma32(kf.z, breg[4 * c + 2], s);
+    s = mfma32(kf.w, breg[4 * c + 3], s);
+  }
+  return s;
+}
+
+// acc^T[d][owner] += sum_t Ts[t = acc_row(r,hi)][d] * p[r]   for the two 32-wide d blocks (row-pattern reads)
+template <int STRIDE>
+RP_DEV void accum_tile(const float* Ts, int l31, int hi, const f32x16& p, f32x16& o0, f32x16& o1) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float* vr = Ts + acc_row(r, hi) * STRIDE + l31;
+    o0 = mfma32(vr[0], p[r], o0);
+    o1 = mfma32(vr[32], p[r], o1);
+  }
+}
+
+// store acc^T (rows d, cols owner) to out[owner row][d] with optional scale; 4-float runs per register group
+RP_DEV void store_ownerT(float* row_ptr, int hi, const f32x16& o0, const f32x16& o1, float mul) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    st4(row_ptr + 8 * g + 4 * hi, make_float4(o0[4 * g] * mul, o0[4 * g + 1] * mul, o0[4 * g + 2] * mul, o0[4 * g + 3] * mul));
+    st4(row_ptr + 32 + 8 * g + 4 * hi, make_float4(o1[4 * g] * mul, o1[4 * g + 1] * mul, o1[4 * g + 2] * mul, o1[4 * g + 3] * mul));
+  }
+}
+
+// load the owner operand (32 rows x 64) into registers: lane (row l31, half hi) keeps cols 32*hi .. +31
+RP_DEV void load_owner(const float* row_ptr, int hi, float mul, float (&reg)[32]) {
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const float4 x = ld4(row_ptr + 32 * hi + 4 * c);
+    reg[4 * c + 0] = x.x * mul; reg[4 * c + 1] = x.y * mul; reg[4 * c + 2] = x.z * mul; reg[4 * c + 3] = x.w * mul;
+  }
+}
+
+template <int NW, bool STATS>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnP p) {
+  constexpr int NT = NW * 64;
+  constexpr int NPF = (512 + NT - 1) / NT;
+  __shared__ __attribute__((aligned(16))) float Ks[2][32 * KST];
+  __shared__ __attribute__((aligned(16))) float Vs[STATS ? 1 : 2][STATS ? 4 : 32 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int h = blockIdx.y, z = blockIdx.z;
+  const int q0 = (blockIdx.x * NW + wave) * 32;
+  const float* qb = p.q + (long long)(z ^ p.q_xor) * NTOK * p.ldq + h * 64;
+  const float* kb = p.k + (long long)(z ^ p.k_xor) * NTOK * p.ldk + h * 64;
+  const float* vb = STATS ? nullptr : p.v + (long long)z * NTOK * p.ldv + h * 64;
+
+  float qreg[32];
+  load_owner(qb + (long long)(q0 + l31) * p.ldq, hi, p.scale, qreg);
+
+  f32x16 o0 = zero16(), o1 = zero16();
+  float m = -INFINITY, l = 0.f;
+
+  float4 kpre[NPF], vpre[NPF];
+  tile_gload<NT>(kb, p.ldk, tid, kpre);
+  if (!STATS) tile_gload<NT>(vb, p.ldv, tid, vpre);
+  tile_sstore<NT, KST>(Ks[0], tid, kpre);
+  if (!STATS) tile_sstore<NT, 64>(Vs[0], tid, vpre);
+  __syncthreads();
+
+  for (int t = 0; t < NTILE; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < NTILE) {
+      tile_gload<NT>(kb + (long long)(t + 1) * 32 * p.ldk, p.ldk, tid, kpre);
+      if (!STATS) tile_gload<NT>(vb + (long long)(t + 1) * 32 * p.ldv, p.ldv, tid, vpre);
+    }
+    f32x16 s = score_tile(Ks[cur], l31, hi, qreg);
+    float mx = s[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mn = fmaxf(m, mx);
+    const float alpha = expf(m - mn);
+    m = mn;
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s[r] = expf(s[r] - mn);
+      ps += s[r];
+    }
+    l = l * alpha + ps;
+    if (!STATS) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        o0[r] *= alpha;
+        o1[r] *= alpha;
+      }
+      accum_tile<64>(Vs[cur], l31, hi, s, o0, o1);
+    }
+    if (t + 1 < NTILE) {
+      tile_sstore<NT, KST>(Ks[cur ^ 1], tid, kpre);
+      if (!STATS) tile_sstore<NT, 64>(Vs[cur ^ 1], tid, vpre);
+    }
+    __syncthreads();
+  }
+  const float lt = l + __shfl_xor(l, 32, 64);
+  if (!STATS) store_ownerT(p.o + ((long long)z * NTOK + q0 + l31) * p.ldo + h * 64, hi, o0, o1, 1.0f / lt);
+  if (hi == 0) p.lse[((long long)z * p.H + h) * NTOK + q0 + l31] = m + logf(lt);
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward.  P = exp(S - lse_q);  dV = P^T dO;  dP = dO V^T;  dS = P o (dP - delta_q);
+//            dQ = scale * dS K;  dK = scale * dS^T Q        (S already contains scale)
+// Two deterministic passes (no atomics):
+//   dkdv: wave owns 32 keys (K, V rows in VGPRs); loops over query tiles {Q, dO, lse, delta} in LDS.
+//         S[q][kv] = sum_d Q[q][d] K[kv][d]   -> lane = key, regs = queries  (A = Q tile, B = K regs)
+//         dP[q][kv] = sum_d dO[q][d] V[kv][d]                                 (A = dO tile, B = V regs)
+//         dV^T[d][kv] += sum_q dO[q][d] P[q][kv] ; dK^T[d][kv] += sum_q Q[q][d] dS[q][kv]   (row-pattern reads)
+//   dq  : wave owns 32 queries (Q, dO rows in VGPRs, lse/delta lane-local); loops over key tiles {K, V}.
+//         S^T[kv][q], dP^T[kv][q] (A = K / V tile, B = Q / dO regs); dQ^T[d][q] += sum_kv K[kv][d] dS^T[kv][q]
+// ------------------------------------------------------------------------------------------------
+struct AttnBwdP {
+  const float* q; const float* k; const float* v; const float* dout; const float* lse; const float* delta;
+  float* dq; float* dk; float* dv;
+  int H, ldq, ldk, ldv, lddo, lddq, lddk, lddv;
+  float scale;
+};
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dkdv_kernel(AttnBwdP p) {
+  constexpr int NT = NW * 64;
+  constexpr int NPF = (512 + NT - 1) / NT;
+  __shared__ __attribute__((aligned(16))) float Qs[2][32 * KST];
+  __shared__ __attribute__((aligned(16))) float Ds[2][32 * KST];
+  __shared__ __attribute__((aligned(16))) float Ls[2][64];   // [0..31] lse, [32..63] delta of the query tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int h = blockIdx.y, z = blockIdx.z;
+  const int k0 = (blockIdx.x * NW + wave) * 32;
+  const float* qb = p.q + (long long)z * NTOK * p.ldq + h * 64;
+  const float* dob = p.dout + (long long)z * NTOK * p.lddo + h * 64;
+  const float* lseb = p.lse + ((long long)z * p.H + h) * NTOK;
+  const float* delb = p.delta + ((long long)z * p.H + h) * NTOK;
+
+  float kreg[32], vreg[32];
+  load_owner(p.k + ((long long)z * NTOK + k0 + l31) * p.ldk + h * 64, hi, p.scale, kreg);   // scale folded into K here
+  load_owner(p.v + ((long long)z * NTOK + k0 + l31) * p.ldv + h * 64, hi, 1.0f, vreg);
+
+  f32x16 dv0 = zero16(), dv1 = zero16(), dk0 = zero16(), dk1 = zero16();
+  float4 qpre[NPF], dpre[NPF];
+  float lpre = 0.f;
+  tile_gload<NT>(qb, p.ldq, tid, qpre);
+  tile_gload<NT>(dob, p.lddo, tid, dpre);
+  if (tid < 64) lpre = tid < 32 ? lseb[tid] : delb[tid - 32];
+  tile_sstore<NT, KST>(Qs[0], tid, qpre);
+  tile_sstore<NT, KST>(Ds[0], tid, dpre);
+  if (tid < 64) Ls[0][tid] = lpre;
+  __syncthreads();
+
+  for (int t = 0; t < NTILE; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < NTILE) {
+      tile_gload<NT>(qb + (long long)(t + 1) * 32 * p.ldq, p.ldq, tid, qpre);
+      tile_gload<NT>(dob + (long long)(t + 1) * 32 * p.lddo, p.lddo, tid, dpre);
+      if (tid < 64) lpre = tid < 32 ? lseb[(t + 1) * 32 + tid] : delb[(t + 1) * 32 + tid - 32];
+    }
+    f32x16 s = score_tile(Qs[cur], l31, hi, kreg);     // rows = queries acc_row(r,hi), lane = key
+    f32x16 dp = score_tile(Ds[cur], l31, hi, vreg);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qi = acc_row(r, hi);
+      const float pr = expf(s[r] - Ls[cur][qi]);
+      s[r] = pr;
+      dp[r] = pr * (dp[r] - Ls[cur][32 + qi]);
+    }
+    accum_tile<KST>(Ds[cur], l31, hi, s, dv0, dv1);     // dV^T += dO^T P
+    accum_tile<KST>(Qs[cur], l31, hi, dp, dk0, dk1);    // dK^T += Q^T dS
+    if (t + 1 < NTILE) {
+      tile_sstore<NT, KST>(Qs[cur ^ 1], tid, qpre);
+      tile_sstore<NT, KST>(Ds[cur ^ 1], tid, dpre);
+      if (tid < 64) Ls[cur ^ 1][tid] = lpre;
+    }
+    __syncthreads();
+  }
+  store_ownerT(p.dv + ((long long)z * NTOK + k0 + l31) * p.lddv + h * 64, hi, dv0, dv1, 1.0f);
+  store_ownerT(p.dk + ((long long)z * NTOK + k0 + l31) * p.lddk + h * 64, hi, dk0, dk1, p.scale);
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnBwdP p) {
+  constexpr int NT = NW * 64;
+  constexpr int NPF = (512 + NT - 1) / NT;
+  __shared__ __attribute__((aligned(16))) float Ks[2][32 * KST];
+  __shared__ __attribute__((aligned(16))) float Vs[2][32 * KST];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int h = blockIdx.y, z = blockIdx.z;
+  const int q0 = (blockIdx.x * NW + wave) * 32;
+  const float* kb = p.k + (long long)z * NTOK * p.ldk + h * 64;
+  const float* vb = p.v + (long long)z * NTOK * p.ldv + h * 64;
+
+  float qreg[32], dreg[32];
+  load_owner(p.q + ((long long)z * NTOK + q0 + l31) * p.ldq + h * 64, hi, p.scale, qreg);
+  load_owner(p.dout + ((long long)z * NTOK + q0 + l31) * p.lddo + h * 64, hi, 1.0f, dreg);
+  const float lse = p.lse[((long long)z * p.H + h) * NTOK + q0 + l31];
+  const float del = p.delta[((long long)z * p.H + h) * NTOK + q0 + l31];
+
+  f32x16 dq0 = zero16(), dq1 = zero16();
+  float4 kpre[NPF], vpre[NPF];
+  tile_gload<NT>(kb, p.ldk, tid, kpre);
+  tile_gload<NT>(vb, p.ldv, tid, vpre);
+  tile_sstore<NT, KST>(Ks[0], tid, kpre);
+  tile_sstore<NT, KST>(Vs[0], tid, vpre);
+  __syncthreads();
+  for (int t = 0; t < NTILE; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < NTILE) {
+      tile_gload<NT>(kb + (long long)(t + 1) * 32 * p.ldk, p.ldk, tid, kpre);
+      tile_gload<NT>(vb + (long long)(t + 1) * 32 * p.ldv, p.ldv, tid, vpre);
+    }
+    f32x16 s = score_tile(Ks[cur], l31, hi, qreg);     // S^T: rows = keys, lane = query
+    f32x16 dp = score_tile(Vs[cur], l31, hi, dreg);    // dP^T
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dp[r] = expf(s[r] - lse) * (dp[r] - del);
+    accum_tile<KST>(Ks[cur], l31, hi, dp, dq0, dq1);    // dQ^T += K^T dS^T
+    if (t + 1 < NTILE) {
+      tile_sstore<NT, KST>(Ks[cur ^ 1], tid, kpre);
+      tile_sstore<NT, KST>(Vs[cur ^ 1], tid, vpre);
+    }
+    __syncthreads();
+  }
+  store_ownerT(p.dq + ((long long)z * NTOK + q0 + l31) * p.lddq + h * 64, hi, dq0, dq1, p.scale);
+}
+
+}  // namespace
+
+extern "C" int rp_attn_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int Z, int H, int ldq,
+                           int ldk, int ldv, int ldo, int q_xor, int k_xor, float scale, int stats_only, void* stream) {
+  if (Z <= 0 || H <= 0) return RP_EBADSHAPE;
+  if ((q_xor | k_xor) & ~1) return RP_EBADSHAPE;
+  if ((q_xor || k_xor) && (Z & 1)) return RP_EBADSHAPE;
+  if ((ldq | ldk) & 3) return RP_EALIGN;
+  if (!stats_only && ((ldv | ldo) & 3)) return RP_EALIGN;
+  AttnP p{q, k, v, o, lse, H, ldq, ldk, ldv, ldo, q_xor, k_xor, scale};
+  constexpr int NW = 3;
+  dim3 grid(NTILE / NW, H, Z);
+  if (stats_only) hipLaunchKernelGGL((attn_fwd_kernel<NW, true>), grid, dim3(NW * 64), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((attn_fwd_kernel<NW, false>), grid, dim3(NW * 64), 0, (hipStream_t)stream, p);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
+extern "C" int rp_attn_bwd(const float* q, const float* k, const float* v, const float* dout, const float* lse,
+                           const float* delta, float* dq, float* dk, float* dv, int Z, int H, int ldq, int ldk, int ldv,
+                           int lddo, int lddq, int lddk, int lddv, float scale, void* stream) {
+  if (Z <= 0 || H <= 0) return RP_EBADSHAPE;
+  if ((ldq | ldk | ldv | lddo | lddq | lddk | lddv) & 3) return RP_EALIGN;
+  AttnBwdP p{q, k, v, dout, lse, delta, dq, dk, dv, H, ldq, ldk, ldv, lddo, lddq, lddk, lddv, scale};
+  constexpr int NW = 3;
+  dim3 grid(NTILE / NW, H, Z);
+  hipLaunchKernelGGL((attn_bwd_dkdv_kernel<NW>), grid, dim3(NW * 64), 0, (hipStream_t)stream, p);
+  RP_CHECK_LAUNCH();
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<NW>), grid, dim3(NW * 64), 0, (hipStream_t)stream, p);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}

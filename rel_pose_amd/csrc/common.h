@@ -1,0 +1,50 @@
+// common.h -- device helpers shared by the gfx950 kernels of librelpose_hip.so.
+//
+// MFMA primitive used everywhere: v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD, 157 TF chip peak).
+//   A operand: lane l holds A[i = l&31][k = l>>5]      (one fp32 VGPR)
+//   B operand: lane l holds B[k = l>>5][j = l&31]
+//   C/D      : 16 fp32 per lane; reg r of lane l is D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]
+// Because the contraction order is free, every kernel here pairs "k-step t" with the two half-waves
+// (hi = l>>5) however its data happens to be laid out; see the per-kernel comments.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define RP_DEV __device__ __forceinline__
+
+RP_DEV f32x16 mfma32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+
+// row of accumulator register r for half-wave hi
+RP_DEV constexpr int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+RP_DEV f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+
+RP_DEV float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+RP_DEV float gelu_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+RP_DEV float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+RP_DEV float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+RP_DEV void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+#define RP_CHECK_LAUNCH()                         \
+  do {                                            \
+    hipError_t e__ = hipGetLastError();           \
+    if (e__ != hipSuccess) return (int)e__;       \
+  } while (0)

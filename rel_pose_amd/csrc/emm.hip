@@ -1,0 +1,310 @@
+// emm.hip -- Essential Matrix Module kernels (rp_emm_apply, rp_emm_grad).
+//
+// Reference: CrossAttention.forward, ess branch (src/modules/vision_transformer.py:198-223), per image z of a
+// pair (partner z^1) and head h:
+//     S = scale * q_{z^1} k_z^T                       [576 x 576]
+//     A = softmax(S, -1) * softmax(S, -2) = exp(2 S - rlse_i - clse_j)      (dual softmax, :205-206)
+//     X = [v_z | pos | 0]                              [576 x 96], 70 live columns (:215-216)
+//     F = X^T A X                                      [70 x 70] (:222-223)
+// The 576x576 matrices never exist in memory: rlse / clse come from two stats-only passes of the
+// attention kernel; rp_emm_apply recomputes S tile by tile (one wave = 32 "owner" rows, tiles of 32 "loop"
+// rows staged in LDS), forms A in registers, accumulates T = A X with the score accumulators used directly as
+// the MFMA A operand, then contracts F_partial = X_blk^T T_blk per workgroup through LDS (the "LDS-tiled
+// outer product" of the task statement).  Six workgroup partials per (z, h) are summed in fixed order by
+// rp_emm_finalize (rowwise.hip) -> deterministic.
+// rp_emm_grad is the gradient pass (see DESIGN.md "EMM backward" for the algebra):
+//     dA = W X^T,  dS = 2 A dA - R rho_i - C gamma_j,  d owner = scale * dS * other
+#include "common.h"
+#include "../../include/relpose_hip.h"
+
+namespace {
+
+constexpr int NTOK = 576;
+constexpr int NTILE = NTOK / 32;
+constexpr int KST = 68;
+constexpr int XW = 96;      // padded width of X / T / W rows
+constexpr int NW = 3;       // waves per workgroup: 96 owner rows
+constexpr int NT = NW * 64;
+
+struct EmmP {
+  const float* qkv; int ld;
+  const float* x; const float* w;
+  const float* rlse; const float* clse; const float* rho; const float* gamma;
+  float* t_out; float* f_part; float* dqkv;
+  int H; float scale; int swap;
+};
+
+RP_DEV void kv_gload(const float* base, int ld, int tid, float4 (&r)[3]) {
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int f = tid + NT * j;
+    if (f < 512) r[j] = ld4(base + (long long)(f >> 4) * ld + (f & 15) * 4);
+  }
+}
+RP_DEV void kv_sstore(float* s, int tid, const float4 (&r)[3]) {
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int f = tid + NT * j;
+    if (f < 512) st4(s + (f >> 4) * KST + (f & 15) * 4, r[j]);
+  }
+}
+
+RP_DEV f32x16 score_tile(const float* Ks, int l31, int hi, const float (&breg)[32]) {
+  f32x16 s = zero16();
+  const float* kr = Ks + l31 * KST + 32 * hi;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const float4 kf = ld4(kr + 4 * c);
+    s = mfma32(kf.x, breg[4 * c + 0], s);
+    s = mfma32(kf.y, breg[4 * c + 1], s);
+    s = mfma32(kf.z, breg[4 * c + 2], s);
+    s = mfma32(kf.w, breg[4 * c + 3], s);
+  }
+  return s;
+}
+
+RP_DEV void load_owner(const float* row_ptr, int hi, float mul, float (&reg)[32]) {
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const float4 x = ld4(row_ptr + 32 * hi + 4 * c);
+    reg[4 * c + 0] = x.x * mul; reg[4 * c + 1] = x.y * mul; reg[4 * c + 2] = x.z * mul; reg[4 * c + 3] = x.w * mul;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void emm_apply_kernel(EmmP p) {
+  // LDS carve: loop phase  Ks[2][32*68] | Xs[2][32*96] | Cl[2][32]   (10560 floats)
+  //            F phase     Ts[96][96]                                   ( 9216 floats, aliases the above)
+  __shared__ __attribute__((aligned(16))) float lds[2 * 32 * KST + 2 * 32 * XW + 64];
+  float* Ks = lds;
+  float* Xs = lds + 2 * 32 * KST;
+  float* Cl = Xs + 2 * 32 * XW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int h = blockIdx.y, z = blockIdx.z;
+  const int wg0 = blockIdx.x * (NW * 32);
+  const int o0 = wg0 + wave * 32;
+  const int own_img = p.swap ? z : (z ^ 1), own_col = (p.swap ? 192 : 0) + h * 64;
+  const int loop_img = p.swap ? (z ^ 1) : z, loop_col = (p.swap ? 0 : 192) + h * 64;
+  const long long zh = (long long)z * p.H + h;
+  const float* own_lse = (p.swap ? p.clse : p.rlse) + zh * NTOK;
+  const float* loop_lse = (p.swap ? p.rlse : p.clse) + zh * NTOK;
+  const float* lb = p.qkv + (long long)loop_img * NTOK * p.ld + loop_col;
+  const float* xb = p.x + zh * NTOK * XW;
+
+  float oreg[32];
+  load_owner(p.qkv + ((long long)own_img * NTOK + o0 + l31) * p.ld + own_col, hi, p.scale, oreg);
+  const float ls_o = own_lse[o0 + l31];
+
+  f32x16 tacc[3] = {zero16(), zero16(), zero16()};
+  float4 kpre[3], xpre[4];
+  float cpre = 0.f;
+  auto x_gload = [&](int t) {   // 32 rows x 24 float4 = 768 float4 -> 4 per thread
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xpre[j] = ld4(xb + (long long)t * 32 * XW + (tid + NT * j) * 4);
+  };
+  auto x_sstore = [&](float* s) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) st4(s + (tid + NT * j) * 4, xpre[j]);
+  };
+  kv_gload(lb, p.ld, tid, kpre);
+  x_gload(0);
+  if (tid < 32) cpre = loop_lse[tid];
+  kv_sstore(Ks, tid, kpre);
+  x_sstore(Xs);
+  if (tid < 32) Cl[tid] = cpre;
+  __syncthreads();
+
+  for (int t = 0; t < NTILE; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < NTILE) {
+      kv_gload(lb + (long long)(t + 1) * 32 * p.ld, p.ld, tid, kpre);
+      x_gload(t + 1);
+      if (tid < 32) cpre = loop_lse[(t + 1) * 32 + tid];
+    }
+    f32x16 s = score_tile(Ks + cur * 32 * KST, l31, hi, oreg);   // S^T[loop][owner]
+    const float* cl = Cl + cur * 32;
+    const float* xs = Xs + cur * 32 * XW;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = expf(2.0f * s[r] - ls_o - cl[acc_row(r, hi)]);
+    // T[owner][c] += sum_loop A[owner][loop] X[loop][c] : A operand = s (lane = owner), B operand = X rows
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float* xr = xs + acc_row(r, hi) * XW + l31;
+      tacc[0] = mfma32(s[r], xr[0], tacc[0]);
+      tacc[1] = mfma32(s[r], xr[32], tacc[1]);
+      tacc[2] = mfma32(s[r], xr[64], tacc[2]);
+    }
+    if (t + 1 < NTILE) {
+      kv_sstore(Ks + (cur ^ 1) * 32 * KST, tid, kpre);
+      x_sstore(Xs + (cur ^ 1) * 32 * XW);
+      if (tid < 32) Cl[(cur ^ 1) * 32 + tid] = cpre;
+    }
+    __syncthreads();
+  }
+
+  if (p.t_out) {
+    float* tb = p.t_out + (zh * NTOK + o0) * XW;
+#pragma unroll
+    for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tb[acc_row(r, hi) * XW + 32 * nb + l31] = tacc[nb][r];
+  }
+  if (!p.f_part) return;
+
+  // ---- F_partial[a][c] = sum_{i in this workgroup's 96 rows} X[i][a] T[i][c] ----------------------
+  float* Ts = lds;
+#pragma unroll
+  for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Ts[(wave * 32 + acc_row(r, hi)) * XW + 32 * nb + l31] = tacc[nb][r];
+  __syncthreads();
+  f32x16 facc[3] = {zero16(), zero16(), zero16()};
+  const float* xa = xb + (long long)wg0 * XW + 32 * wave + l31;   // column a = 32*wave + l31 of X rows
+#pragma unroll 4
+  for (int t = 0; t < 48; ++t) {
+    const int i = 48 * hi + t;
+    const float av = xa[(long long)i * XW];
+    const float* tr = Ts + i * XW + l31;
+    facc[0] = mfma32(av, tr[0], facc[0]);
+    facc[1] = mfma32(av, tr[32], facc[1]);
+    facc[2] = mfma32(av, tr[64], facc[2]);
+  }
+  float* fb = p.f_part + ((zh * (NTOK / (NW * 32)) + blockIdx.x) * XW + 32 * wave) * XW;
+#pragma unroll
+  for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) fb[acc_row(r, hi) * XW + 32 * nb + l31] = facc[nb][r];
+}
+
+// ------------------------------------------------------------------------------------------------
+constexpr int XG = 72;       // live columns of X / W used by the dA contraction (70 rounded up to even, x4)
+constexpr int XGS = 76;      // LDS row stride for the X tile read along c with ds_read_b128
+
+__global__ __launch_bounds__(NT) void emm_grad_kernel(EmmP p) {
+  __shared__ __attribute__((aligned(16))) float Ks[2][32 * KST];
+  __shared__ __attribute__((aligned(16))) float Xs[2][32 * XGS];
+  __shared__ float Ll[2][64];   // loop-side lse [0..31] and rho/gamma [32..63]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int h = blockIdx.y, z = blockIdx.z;
+  const int o0 = (blockIdx.x * NW + wave) * 32;
+  const int own_img = p.swap ? z : (z ^ 1), own_col = (p.swap ? 192 : 0) + h * 64;
+  const int loop_img = p.swap ? (z ^ 1) : z, loop_col = (p.swap ? 0 : 192) + h * 64;
+  const long long zh = (long long)z * p.H + h;
+  const float* own_lse = (p.swap ? p.clse : p.rlse) + zh * NTOK;
+  const float* loop_lse = (p.swap ? p.rlse : p.clse) + zh * NTOK;
+  const float* own_g = (p.swap ? p.gamma : p.rho) + zh * NTOK;
+  const float* loop_g = (p.swap ? p.rho : p.gamma) + zh * NTOK;
+  const float* lb = p.qkv + (long long)loop_img * NTOK * p.ld + loop_col;
+  const float* xb = p.x + zh * NTOK * XW;
+
+  float oreg[32], wreg[36];
+  load_owner(p.qkv + ((long long)own_img * NTOK + o0 + l31) * p.ld + own_col, hi, p.scale, oreg);
+  {
+    const float* wr = p.w + (zh * NTOK + o0 + l31) * XW + 36 * hi;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+      const float4 v = ld4(wr + 4 * c);
+      wreg[4 * c] = v.x; wreg[4 * c + 1] = v.y; wreg[4 * c + 2] = v.z; wreg[4 * c + 3] = v.w;
+    }
+  }
+  const float ls_o = own_lse[o0 + l31], g_o = own_g[o0 + l31];
+
+  f32x16 d0 = zero16(), d1 = zero16();
+  float4 kpre[3], xpre[3];
+  float lpre = 0.f;
+  auto x_gload = [&](int t) {   // 32 rows x 18 float4 (72 cols) = 576 float4 -> 3 per thread
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int f = tid + NT * j;
+      xpre[j] = ld4(xb + ((long long)t * 32 + f / 18) * XW + (f % 18) * 4);
+    }
+  };
+  auto x_sstore = [&](float* s) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int f = tid + NT * j;
+      st4(s + (f / 18) * XGS + (f % 18) * 4, xpre[j]);
+    }
+  };
+  kv_gload(lb, p.ld, tid, kpre);
+  x_gload(0);
+  if (tid < 64) lpre = tid < 32 ? loop_lse[tid] : loop_g[tid - 32];
+  kv_sstore(Ks[0], tid, kpre);
+  x_sstore(Xs[0]);
+  if (tid < 64) Ll[0][tid] = lpre;
+  __syncthreads();
+
+  for (int t = 0; t < NTILE; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < NTILE) {
+      kv_gload(lb + (long long)(t + 1) * 32 * p.ld, p.ld, tid, kpre);
+      x_gload(t + 1);
+      if (tid < 64) lpre = tid < 32 ? loop_lse[(t + 1) * 32 + tid] : loop_g[(t + 1) * 32 + tid - 32];
+    }
+    f32x16 s = score_tile(Ks[cur], l31, hi, oreg);      // S^T[loop][owner]
+    f32x16 da = zero16();                                // dA^T[loop][owner] = sum_c X[loop][c] W[owner][c]
+    {
+      const float* xr = Xs[cur] + l31 * XGS + 36 * hi;
+#pragma unroll
+      for (int c = 0; c < 9; ++c) {
+        const float4 xf = ld4(xr + 4 * c);
+        da = mfma32(xf.x, wreg[4 * c + 0], da);
+        da = mfma32(xf.y, wreg[4 * c + 1], da);
+        da = mfma32(xf.z, wreg[4 * c + 2], da);
+        da = mfma32(xf.w, wreg[4 * c + 3], da);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int li = acc_row(r, hi);
+      const float eo = expf(s[r] - ls_o);                // owner-side softmax factor
+      const float el = expf(s[r] - Ll[cur][li]);         // loop-side softmax factor
+      s[r] = 2.0f * eo * el * da[r] - eo * g_o - el * Ll[cur][32 + li];
+    }
+    // d owner^T[d][owner] += sum_loop other[loop][d] dS^T[loop][owner]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float* kr = Ks[cur] + acc_row(r, hi) * KST + l31;
+      d0 = mfma32(kr[0], s[r], d0);
+      d1 = mfma32(kr[32], s[r], d1);
+    }
+    if (t + 1 < NTILE) {
+      kv_sstore(Ks[cur ^ 1], tid, kpre);
+      x_sstore(Xs[cur ^ 1]);
+      if (tid < 64) Ll[cur ^ 1][tid] = lpre;
+    }
+    __syncthreads();
+  }
+  float* orow = p.dqkv + ((long long)own_img * NTOK + o0 + l31) * p.ld + own_col;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    st4(orow + 8 * g + 4 * hi, make_float4(d0[4 * g] * p.scale, d0[4 * g + 1] * p.scale, d0[4 * g + 2] * p.scale, d0[4 * g + 3] * p.scale));
+    st4(orow + 32 + 8 * g + 4 * hi, make_float4(d1[4 * g] * p.scale, d1[4 * g + 1] * p.scale, d1[4 * g + 2] * p.scale, d1[4 * g + 3] * p.scale));
+  }
+}
+
+}  // namespace
+
+extern "C" int rp_emm_apply(const float* qkv, int ldqkv, const float* x, const float* rlse, const float* clse,
+                            float* t_out, float* f_part, int Z, int H, float scale, int swap, void* stream) {
+  if (Z <= 0 || (Z & 1) || H <= 0 || (ldqkv & 3)) return RP_EBADSHAPE;
+  if (swap && f_part) return RP_EUNSUPPORTED;
+  EmmP p{};
+  p.qkv = qkv; p.ld = ldqkv; p.x = x; p.rlse = rlse; p.clse = clse; p.t_out = t_out; p.f_part = f_part;
+  p.H = H; p.scale = scale; p.swap = swap ? 1 : 0;
+  hipLaunchKernelGGL(emm_apply_kernel, dim3(NTILE / NW, H, Z), dim3(NT), 0, (hipStream_t)stream, p);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
+extern "C" int rp_emm_grad(const float* qkv, int ldqkv, const float* x, const float* w, const float* rlse,
+                           const float* clse, const float* rho, const float* gamma, float* dqkv, int Z, int H,
+                           float scale, int swap, void* stream) {
+  if (Z <= 0 || (Z & 1) || H <= 0 || (ldqkv & 3)) return RP_EBADSHAPE;
+  EmmP p{};
+  p.qkv = qkv; p.ld = ldqkv; p.x = x; p.w = w; p.rlse = rlse; p.clse = clse; p.rho = rho; p.gamma = gamma;
+  p.dqkv = dqkv; p.H = H; p.scale = scale; p.swap = swap ? 1 : 0;
+  hipLaunchKernelGGL(emm_grad_kernel, dim3(NTILE / NW, H, Z), dim3(NT), 0, (hipStream_t)stream, p);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}

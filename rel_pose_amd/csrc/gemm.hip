@@ -1,0 +1,276 @@
+// gemm.hip -- fp32 MFMA contraction with fused epilogue (rp_gemm).
+//
+// Replaces nn.Linear forward / dX / dW of the reference's ViT blocks, EMM projection and pose regressor
+// (reference src/modules/vision_transformer.py:323,331,191-195,233-234; vit_layers/mlp.py:20-26;
+// src/model.py:91-98).  One kernel template, 4 operand layouts x 6 tile shapes.
+//
+// Tiling (gfx950): 256 threads = 4 waves in a 2x2 grid; each wave owns (32*TM) x (32*TN) of C as TM*TN
+// v_mfma_f32_32x32x2_f32 accumulators; BK = 32.  Global -> registers (float4, issued one k-tile ahead so
+// HBM/L2 latency hides under the MFMAs of the current tile) -> LDS -> MFMA operands.
+// k-step pairing inside a k-tile: step t in [0,16): half-wave 0 supplies k = t, half-wave 1 supplies
+// k = 16 + t, so a K-contiguous operand row is read as 4 x ds_read_b128 (row stride 36 floats: the 16
+// lanes of a b128 group land on 16 distinct 16-byte slots); an MN-contiguous operand is read as
+// conflict-free ds_read_b32 rows.
+#include "common.h"
+#include "../../include/relpose_hip.h"
+
+namespace {
+
+struct GemmP {
+  const float* A;
+  const float* B;
+  float* C;
+  int M, N, K;
+  int lda, ldb, ldc;
+  long long sa, sb, sc;
+  int split_k;
+  int k_per_split;
+  const float* bias;
+  float* pre_out;
+  int act, dact;
+  const float* aux;
+  const float* residual;
+};
+
+RP_DEV float epilogue(float v, int m, int n, const GemmP& p) {
+  if (p.bias) v += p.bias[n];
+  const long long off = (long long)m * p.ldc + n;
+  if (p.pre_out) p.pre_out[off] = v;
+  if (p.act == 1) v = gelu_exact(v);
+  else if (p.act == 2) v = fmaxf(v, 0.f);
+  if (p.dact == 1) v *= gelu_grad(p.aux[off]);
+  else if (p.dact == 2) v = p.aux[off] > 0.f ? v : 0.f;
+  if (p.residual) v += p.residual[off];
+  return v;
+}
+
+template <int ALAY, int BLAY, int TM, int TN>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
+  constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32;
+  constexpr int KST = BK + 4;                       // padded row stride of a K-contiguous tile
+  constexpr int A_FLOATS = ALAY == 0 ? BM * KST : BK * BM;
+  constexpr int B_FLOATS = BLAY == 0 ? BN * KST : BK * BN;
+  constexpr int NA = BM / 32, NB = BN / 32;         // float4 per thread per k-tile
+  __shared__ __attribute__((aligned(16))) float lds[A_FLOATS + B_FLOATS];
+  float* As = lds;
+  float* Bs = lds + A_FLOATS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wm0 = (wave >> 1) * 32 * TM, wn0 = (wave & 1) * 32 * TN;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int zb = blockIdx.z / p.split_k, zs = blockIdx.z % p.split_k;
+  const float* A = p.A + zb * p.sa;
+  const float* B = p.B + zb * p.sb;
+  const int kbeg = zs * p.k_per_split;
+  const int kend = min(p.K, kbeg + p.k_per_split);
+  const int nkt = (kend - kbeg + BK - 1) / BK;
+
+  float4 ra[NA], rb[NB];
+  auto gload = [&](int kt) {
+    const int k0 = kbeg + kt * BK;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int f = tid + 256 * j;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ALAY == 0) {
+        const int gm = m0 + (f >> 3), gk = k0 + (f & 7) * 4;
+        if (gm < p.M && gk < kend) v = ld4(A + (long long)gm * p.lda + gk);
+      } else {
+        const int gk = k0 + f / (BM / 4), gm = m0 + (f % (BM / 4)) * 4;
+        if (gk < kend && gm < p.M) v = ld4(A + (long long)gk * p.lda + gm);
+      }
+      ra[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int f = tid + 256 * j;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (BLAY == 0) {
+        const int gn = n0 + (f >> 3), gk = k0 + (f & 7) * 4;
+        if (gn < p.N && gk < kend) v = ld4(B + (long long)gn * p.ldb + gk);
+      } else {
+        const int gk = k0 + f / (BN / 4), gn = n0 + (f % (BN / 4)) * 4;
+        if (gk < kend && gn < p.N) v = ld4(B + (long long)gk * p.ldb + gn);
+      }
+      rb[j] = v;
+    }
+  };
+  auto sstore = [&]() {
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int f = tid + 256 * j;
+      if (ALAY == 0) st4(As + (f >> 3) * KST + (f & 7) * 4, ra[j]);
+      else st4(As + (f / (BM / 4)) * BM + (f % (BM / 4)) * 4, ra[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int f = tid + 256 * j;
+      if (BLAY == 0) st4(Bs + (f >> 3) * KST + (f & 7) * 4, rb[j]);
+      else st4(Bs + (f / (BN / 4)) * BN + (f % (BN / 4)) * 4, rb[j]);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = zero16();
+
+  if (nkt > 0) {
+    gload(0);
+    sstore();
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    if (kt + 1 < nkt) gload(kt + 1);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      float a[TM][8], b[TN][8];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if (ALAY == 0) {
+          const float* s = As + (wm0 + 32 * i + l31) * KST + 16 * hi + 8 * half;
+          const float4 x = ld4(s), y = ld4(s + 4);
+          a[i][0] = x.x; a[i][1] = x.y; a[i][2] = x.z; a[i][3] = x.w;
+          a[i][4] = y.x; a[i][5] = y.y; a[i][6] = y.z; a[i][7] = y.w;
+        } else {
+#pragma unroll
+          for (int t = 0; t < 8; ++t) a[i][t] = As[(16 * hi + 8 * half + t) * BM + wm0 + 32 * i + l31];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (BLAY == 0) {
+          const float* s = Bs + (wn0 + 32 * j + l31) * KST + 16 * hi + 8 * half;
+          const float4 x = ld4(s), y = ld4(s + 4);
+          b[j][0] = x.x; b[j][1] = x.y; b[j][2] = x.z; b[j][3] = x.w;
+          b[j][4] = y.x; b[j][5] = y.y; b[j][6] = y.z; b[j][7] = y.w;
+        } else {
+#pragma unroll
+          for (int t = 0; t < 8; ++t) b[j][t] = Bs[(16 * hi + 8 * half + t) * BN + wn0 + 32 * j + l31];
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(a[i][t], b[j][t], acc[i][j]);
+    }
+    __syncthreads();
+    if (kt + 1 < nkt) {
+      sstore();
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue -------------------------------------------------------------------------------
+  float* C = p.C + zb * p.sc;
+  const bool partial = p.split_k > 1;
+  if (partial) C = p.C + (long long)blockIdx.z * p.M * p.N;   // workspace slab [z][M][N]
+  const int ldc = partial ? p.N : p.ldc;
+  GemmP q = p;   // batch offsets for the epilogue operands
+  q.pre_out = p.pre_out ? p.pre_out + zb * p.sc : nullptr;
+  q.aux = p.aux ? p.aux + zb * p.sc : nullptr;
+  q.residual = p.residual ? p.residual + zb * p.sc : nullptr;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn0 + 32 * j + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm0 + 32 * i + acc_row(r, hi);
+        if (m < p.M && n < p.N) {
+          float v = acc[i][j][r];
+          if (!partial) v = epilogue(v, m, n, q);
+          C[(long long)m * ldc + n] = v;
+        }
+      }
+    }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, const float* ws) {
+  const long long total = (long long)p.M * p.N;
+  const long long idx = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (idx >= total) return;
+  float4 s = ld4(ws + idx);
+  for (int z = 1; z < p.split_k; ++z) {
+    const float4 t = ld4(ws + z * total + idx);
+    s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+  }
+  const int m = (int)(idx / p.N), n = (int)(idx % p.N);   // N % 4 == 0: the float4 stays in one row
+  float o[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) p.C[(long long)m * p.ldc + n + e] = epilogue(o[e], m, n + e, p);
+}
+
+template <int ALAY, int BLAY, int TM, int TN>
+int launch(const GemmP& p, int nz, hipStream_t st) {
+  dim3 grid((p.N + 64 * TN - 1) / (64 * TN), (p.M + 64 * TM - 1) / (64 * TM), nz);
+  hipLaunchKernelGGL((gemm_kernel<ALAY, BLAY, TM, TN>), grid, dim3(256), 0, st, p);
+  return 0;
+}
+
+template <int ALAY, int BLAY>
+int launch_tiles(const GemmP& p, int nz, int tm, int tn, hipStream_t st) {
+  if (tm == 1) {
+    if (tn == 1) return launch<ALAY, BLAY, 1, 1>(p, nz, st);
+    if (tn == 2) return launch<ALAY, BLAY, 1, 2>(p, nz, st);
+    return launch<ALAY, BLAY, 1, 3>(p, nz, st);
+  }
+  if (tn == 1) return launch<ALAY, BLAY, 2, 1>(p, nz, st);
+  if (tn == 2) return launch<ALAY, BLAY, 2, 2>(p, nz, st);
+  return launch<ALAY, BLAY, 2, 3>(p, nz, st);
+}
+
+}  // namespace
+
+extern "C" size_t rp_gemm_workspace_bytes(int M, int N, int split_k) {
+  return split_k > 1 ? (size_t)split_k * (size_t)M * (size_t)N * sizeof(float) : 0;
+}
+
+extern "C" int rp_gemm(const RpGemm* g, void* stream) {
+  if (!g || g->M <= 0 || g->N <= 0 || g->K <= 0) return RP_EBADSHAPE;
+  if (g->a_layout < 0 || g->a_layout > 1 || g->b_layout < 0 || g->b_layout > 1) return RP_EBADSHAPE;
+  if ((g->lda | g->ldb | g->ldc) & 3) return RP_EALIGN;
+  if ((g->a_layout == 0 || g->b_layout == 0) && (g->K & 3)) return RP_EALIGN;
+  if (g->a_layout == 1 && (g->M & 3)) return RP_EALIGN;
+  if (g->b_layout == 1 && (g->N & 3)) return RP_EALIGN;
+  if (((uintptr_t)g->A | (uintptr_t)g->B | (uintptr_t)g->C) & 15) return RP_EALIGN;
+  const int batch = g->batch > 0 ? g->batch : 1;
+  const int split = g->split_k > 0 ? g->split_k : 1;
+  if (batch > 1 && split > 1) return RP_EUNSUPPORTED;
+  if (split > 1) {
+    if (g->N & 3) return RP_EALIGN;
+    if (!g->workspace || g->workspace_bytes < rp_gemm_workspace_bytes(g->M, g->N, split)) return RP_EWORKSPACE;
+  }
+  GemmP p;
+  p.A = g->A; p.B = g->B; p.C = split > 1 ? g->workspace : g->C;
+  p.M = g->M; p.N = g->N; p.K = g->K;
+  p.lda = g->lda; p.ldb = g->ldb; p.ldc = g->ldc;
+  p.sa = g->stride_a; p.sb = g->stride_b; p.sc = g->stride_c;
+  p.split_k = split;
+  const int ktiles = (g->K + 31) / 32;
+  p.k_per_split = ((ktiles + split - 1) / split) * 32;
+  p.bias = g->bias; p.pre_out = g->pre_out; p.act = g->act; p.dact = g->dact; p.aux = g->aux; p.residual = g->residual;
+  const int tm = g->M <= 64 ? 1 : 2;
+  const int tn = (g->N % 192 == 0) ? 3 : (g->N <= 64 ? 1 : 2);
+  hipStream_t st = (hipStream_t)stream;
+  const int nz = batch * split;
+  if (g->a_layout == 0 && g->b_layout == 0) launch_tiles<0, 0>(p, nz, tm, tn, st);
+  else if (g->a_layout == 0 && g->b_layout == 1) launch_tiles<0, 1>(p, nz, tm, tn, st);
+  else if (g->a_layout == 1 && g->b_layout == 0) launch_tiles<1, 0>(p, nz, tm, tn, st);
+  else launch_tiles<1, 1>(p, nz, tm, tn, st);
+  RP_CHECK_LAUNCH();
+  if (split > 1) {
+    GemmP r = p;
+    r.C = g->C;
+    const long long total = (long long)g->M * g->N;
+    const int blocks = (int)((total / 4 + 255) / 256);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, r, (const float*)g->workspace);
+    RP_CHECK_LAUNCH();
+  }
+  return RP_OK;
+}

@@ -1,0 +1,458 @@
+// rowwise.hip -- HBM-bound row/column kernels around the MFMA contractions:
+// LayerNorm fwd/bwd (reference vision_transformer.py:396 eps=1e-6; uses at :352-353,292,295; model.py:178),
+// deterministic column sums (bias / affine / pos_embed gradients), the token layout + pos_embed add
+// (model.py:136-141,170-171), closed-form positional features (vision_transformer.py:90-158),
+// pose normalisation (model.py:145-159) and the small gather/scatter kernels of the EMM.
+// All of these move each byte once with wave-coalesced 256-byte rows; none uses MFMA.
+#include "common.h"
+#include "../../include/relpose_hip.h"
+
+namespace {
+
+constexpr int LN_MAXJ = 8;  // C <= 512
+
+// one wave per row; lane holds elements lane + 64*j
+template <int J>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int rows,
+                                                     float eps) {
+  constexpr int C = 64 * J;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (long long)row * C;
+  float v[J];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    v[j] = xr[lane + 64 * j];
+    s += v[j];
+  }
+  const float mu = wave_sum(s) * (1.0f / C);
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const float d = v[j] - mu;
+    q += d * d;
+  }
+  const float rs = 1.0f / sqrtf(wave_sum(q) * (1.0f / C) + eps);
+  float* yr = y + (long long)row * C;
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int c = lane + 64 * j;
+    yr[c] = (v[j] - mu) * rs * gamma[c] + beta[c];
+  }
+  if (lane == 0) {
+    if (mean) mean[row] = mu;
+    if (rstd) rstd[row] = rs;
+  }
+}
+
+constexpr int LNB_ROWS = 64;  // rows per block in the backward (4 waves x 16 rows)
+
+template <int J>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const float* __restrict__ add,
+                                                     float* __restrict__ dx, float* __restrict__ dgp,
+                                                     float* __restrict__ dbp, int rows) {
+  constexpr int C = 64 * J;
+  __shared__ float red[2][4][C];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float g[J], dg[J], db[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    g[j] = gamma[lane + 64 * j];
+    dg[j] = 0.f;
+    db[j] = 0.f;
+  }
+  const int r0 = blockIdx.x * LNB_ROWS + wave * (LNB_ROWS / 4);
+  for (int rr = 0; rr < LNB_ROWS / 4; ++rr) {
+    const int row = r0 + rr;
+    if (row >= rows) break;
+    const float mu = mean[row], rs = rstd[row];
+    float xh[J], dxh[J];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const long long o = (long long)row * C + lane + 64 * j;
+      const float d = dy[o];
+      xh[j] = (x[o] - mu) * rs;
+      dxh[j] = d * g[j];
+      s1 += dxh[j];
+      s2 += dxh[j] * xh[j];
+      dg[j] += d * xh[j];
+      db[j] += d;
+    }
+    const float c1 = wave_sum(s1) * (1.0f / C), c2 = wave_sum(s2) * (1.0f / C);
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const long long o = (long long)row * C + lane + 64 * j;
+      float v = rs * (dxh[j] - c1 - xh[j] * c2);
+      if (add) v += add[o];
+      dx[o] = v;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    red[0][wave][lane + 64 * j] = dg[j];
+    red[1][wave][lane + 64 * j] = db[j];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    dgp[(long long)blockIdx.x * C + c] = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+    dbp[(long long)blockIdx.x * C + c] = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+  }
+}
+
+// column sums: block (bx, by): columns bx*256 + tid, rows [by*rpb, (by+1)*rpb)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, int rows, int cols, int ld,
+                                                     int rpb, float* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  const int r0 = blockIdx.y * rpb, r1 = min(rows, r0 + rpb);
+  float s = 0.f;
+  for (int r = r0; r < r1; ++r) s += in[(long long)r * ld + c];
+  out[(long long)blockIdx.y * cols + c] = s;
+}
+
+// x[z][n][c] = feat[z][c][n] + pe[n][c]   (32x32 LDS tile transpose)
+__global__ __launch_bounds__(256) void tokens_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ pe,
+                                                         float* __restrict__ x, int C, int N) {
+  __shared__ float t[32][33];
+  const int z = blockIdx.z, c0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = c0 + ty + 8 * k;
+    t[ty + 8 * k][tx] = feat[((long long)z * C + c) * N + n0 + tx];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int n = n0 + ty + 8 * k, c = c0 + tx;
+    x[((long long)z * N + n) * C + c] = t[tx][ty + 8 * k] + pe[(long long)n * C + c];
+  }
+}
+
+__global__ __launch_bounds__(256) void tokens_bwd_kernel(const float* __restrict__ dx, float* __restrict__ dfeat, int C,
+                                                         int N) {
+  __shared__ float t[32][33];
+  const int z = blockIdx.z, c0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int n = n0 + ty + 8 * k;
+    t[ty + 8 * k][tx] = dx[((long long)z * N + n) * C + c0 + tx];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = c0 + ty + 8 * k;
+    dfeat[((long long)z * C + c) * N + n0 + tx] = t[tx][ty + 8 * k];
+  }
+}
+
+__global__ __launch_bounds__(256) void posenc_kernel(const float* __restrict__ intr, const float* __restrict__ lin,
+                                                     float* __restrict__ pos, int B) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= B * 576) return;
+  const int b = idx / 576, n = idx % 576;
+  float ix = 1.f, iy = 1.f;
+  if (intr) {
+    const float fx = intr[b * 8 + 0], fy = intr[b * 8 + 1], cx = intr[b * 8 + 2], cy = intr[b * 8 + 3];
+    ix = 1.0f / ((fx / (cx * 2.0f)) * 2.0f);
+    iy = 1.0f / ((fy / (cy * 2.0f)) * 2.0f);
+  }
+  float p3 = lin[n % 24], p4 = lin[n / 24];
+  if (intr) {
+    p3 = p3 * iy;
+    p4 = p4 * ix;
+  }
+  float* o = pos + (long long)idx * 6;
+  o[0] = p3 * p3;
+  o[1] = p4 * p4;
+  o[2] = p3 * p4;
+  o[3] = p3;
+  o[4] = p4;
+  o[5] = 1.0f;
+}
+
+// x[z][h][n][0:64] = qkv[z][n][384 + h*64 + e]; [64:70] = pos[z/2][n]; [70:96] = 0
+__global__ __launch_bounds__(256) void emm_build_x_kernel(const float* __restrict__ qkv, const float* __restrict__ pos,
+                                                          float* __restrict__ x, int H, int ld) {
+  const int z = blockIdx.z, h = blockIdx.y;
+  const int n = blockIdx.x * 8 + (threadIdx.x >> 5);  // 8 rows per block, 32 threads x 3 cols each
+  const int t = threadIdx.x & 31;
+  float* xr = x + (((long long)z * H + h) * 576 + n) * 96;
+  const float* vr = qkv + ((long long)z * 576 + n) * ld + 384 + h * 64;
+  xr[t] = vr[t];
+  xr[32 + t] = vr[32 + t];
+  float v = 0.f;
+  if (t < 6) v = pos[((long long)(z >> 1) * 576 + n) * 6 + t];
+  xr[64 + t] = v;
+}
+
+__global__ __launch_bounds__(256) void emm_build_x_bwd_kernel(const float* __restrict__ dx, float* __restrict__ dqkv,
+                                                              int H, int ld) {
+  const int z = blockIdx.z, h = blockIdx.y;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int t = threadIdx.x & 63;
+  dqkv[((long long)z * 576 + n) * ld + 384 + h * 64 + t] = dx[(((long long)z * H + h) * 576 + n) * 96 + t];
+}
+
+// g[z^1][c][h*70 + a] = sum_wg fp[z][h][wg][a][c]; zero pad to ldg
+__global__ __launch_bounds__(256) void emm_finalize_kernel(const float* __restrict__ fp, float* __restrict__ g, int H,
+                                                           int ldg, int nwg) {
+  const int z = blockIdx.y, c = blockIdx.x;  // c in [0,70)
+  float* gr = g + ((long long)(z ^ 1) * 70 + c) * ldg;
+  for (int k = threadIdx.x; k < ldg; k += 256) {
+    float s = 0.f;
+    if (k < H * 70) {
+      const int h = k / 70, a = k % 70;
+      const float* f = fp + (((long long)z * H + h) * nwg) * 9216 + a * 96 + c;
+      for (int w = 0; w < nwg; ++w) s += f[(long long)w * 9216];
+    }
+    gr[k] = s;
+  }
+}
+
+// df[z][h][a][c] (96x96, zero outside 70x70) = dg[z^1][c][h*70+a]
+__global__ __launch_bounds__(256) void emm_finalize_bwd_kernel(const float* __restrict__ dg, float* __restrict__ df,
+                                                               int H, int ldg) {
+  const int z = blockIdx.z, h = blockIdx.y, a = blockIdx.x;  // a in [0,96)
+  float* o = df + (((long long)z * H + h) * 96 + a) * 96;
+  for (int c = threadIdx.x; c < 96; c += 256) {
+    float v = 0.f;
+    if (a < 70 && c < 70) v = dg[((long long)(z ^ 1) * 70 + c) * ldg + h * 70 + a];
+    o[c] = v;
+  }
+}
+
+// out[r] = sum_c a[r][c] b[r][c], C = 96; one wave per row pair... 32 lanes x 3
+__global__ __launch_bounds__(256) void rowdot96_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                       float* __restrict__ out, long long rows) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float* ar = a + row * 96;
+  const float* br = b + row * 96;
+  float s = ar[lane] * br[lane];
+  if (lane < 32) s += ar[64 + lane] * br[64 + lane];
+  s = wave_sum(s);
+  if (lane == 0) out[row] = s;
+}
+
+// delta[z][h][i] = sum_e dO[z][i][h*64+e] * O[z][i][h*64+e]; one wave per (z,i,h)
+__global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict__ dout, const float* __restrict__ o,
+                                                         float* __restrict__ delta, int H, int ld, long long total) {
+  const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);  // index over (z*576+i)*H + h
+  if (w >= total) return;
+  const int lane = threadIdx.x & 63;
+  const long long zi = w / H;
+  const int h = (int)(w % H);
+  const long long off = zi * ld + h * 64 + lane;
+  const float s = wave_sum(dout[off] * o[off]);
+  if (lane == 0) {
+    const long long z = zi / 576;
+    const int i = (int)(zi % 576);
+    delta[(z * H + h) * 576 + i] = s;
+  }
+}
+
+__global__ void pose_norm_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ gs,
+                                     float* __restrict__ out, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float* p = pred + b * 14 + 7;
+  float* o = out + b * 14;
+  for (int i = 0; i < 7; ++i) o[i] = gs[b * 14 + i];
+  for (int i = 0; i < 3; ++i) o[7 + i] = p[i];
+  const float n = sqrtf(p[3] * p[3] + p[4] * p[4] + p[5] * p[5] + p[6] * p[6]);
+  const float d = fmaxf(n, 0.01f);
+  for (int i = 3; i < 7; ++i) o[7 + i] = p[i] / d;
+}
+
+__global__ void pose_norm_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ dout,
+                                     float* __restrict__ dpred, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float* p = pred + b * 14 + 7;
+  const float* g = dout + b * 14 + 7;
+  float* d = dpred + b * 14;
+  for (int i = 0; i < 7; ++i) d[i] = 0.f;
+  for (int i = 0; i < 3; ++i) d[7 + i] = g[i];
+  const float n = sqrtf(p[3] * p[3] + p[4] * p[4] + p[5] * p[5] + p[6] * p[6]);
+  if (n > 0.01f) {
+    float dot = 0.f;
+    for (int i = 3; i < 7; ++i) dot += p[i] * g[i];
+    for (int i = 3; i < 7; ++i) d[7 + i] = g[i] / n - p[i] * dot / (n * n * n);
+  } else {
+    for (int i = 3; i < 7; ++i) d[7 + i] = g[i] / 0.01f;
+  }
+}
+
+}  // namespace
+
+#define LN_DISPATCH(J, KERNEL, GRID, ...)                                                   \
+  case J:                                                                                   \
+    hipLaunchKernelGGL((KERNEL<J>), GRID, dim3(256), 0, st, __VA_ARGS__);                   \
+    break;
+
+extern "C" int rp_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                                float* rstd, int rows, int C, float eps, void* stream) {
+  if (rows <= 0 || C <= 0 || (C & 63) || C > 64 * LN_MAXJ) return RP_EBADSHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((rows + 3) / 4);
+  switch (C / 64) {
+    LN_DISPATCH(1, ln_fwd_kernel, grid, x, gamma, beta, y, mean, rstd, rows, eps)
+    LN_DISPATCH(2, ln_fwd_kernel, grid, x, gamma, beta, y, mean, rstd, rows, eps)
+    LN_DISPATCH(3, ln_fwd_kernel, grid, x, gamma, beta, y, mean, rstd, rows, eps)
+    LN_DISPATCH(4, ln_fwd_kernel, grid, x, gamma, beta, y, mean, rstd, rows, eps)
+    LN_DISPATCH(6, ln_fwd_kernel, grid, x, gamma, beta, y, mean, rstd, rows, eps)
+    LN_DISPATCH(8, ln_fwd_kernel, grid, x, gamma, beta, y, mean, rstd, rows, eps)
+    default: return RP_EUNSUPPORTED;
+  }
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
+extern "C" int rp_layernorm_bwd_blocks(int rows) { return (rows + LNB_ROWS - 1) / LNB_ROWS; }
+
+extern "C" int rp_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
+                                const float* rstd, const float* add, float* dx, float* dgamma_part, float* dbeta_part,
+                                int rows, int C, void* stream) {
+  if (rows <= 0 || C <= 0 || (C & 63) || C > 64 * LN_MAXJ) return RP_EBADSHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(rp_layernorm_bwd_blocks(rows));
+  switch (C / 64) {
+    LN_DISPATCH(1, ln_bwd_kernel, grid, dy, x, gamma, mean, rstd, add, dx, dgamma_part, dbeta_part, rows)
+    LN_DISPATCH(2, ln_bwd_kernel, grid, dy, x, gamma, mean, rstd, add, dx, dgamma_part, dbeta_part, rows)
+    LN_DISPATCH(3, ln_bwd_kernel, grid, dy, x, gamma, mean, rstd, add, dx, dgamma_part, dbeta_part, rows)
+    LN_DISPATCH(4, ln_bwd_kernel, grid, dy, x, gamma, mean, rstd, add, dx, dgamma_part, dbeta_part, rows)
+    LN_DISPATCH(6, ln_bwd_kernel, grid, dy, x, gamma, mean, rstd, add, dx, dgamma_part, dbeta_part, rows)
+    LN_DISPATCH(8, ln_bwd_kernel, grid, dy, x, gamma, mean, rstd, add, dx, dgamma_part, dbeta_part, rows)
+    default: return RP_EUNSUPPORTED;
+  }
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
+static int colsum_stage1_rows(int rows) {
+  int rpb = 256;
+  while ((rows + rpb - 1) / rpb > 512) rpb *= 2;
+  return rpb;
+}
+
+extern "C" size_t rp_colsum_workspace_bytes(int rows, int cols) {
+  const int rpb = colsum_stage1_rows(rows);
+  const int nb = (rows + rpb - 1) / rpb;
+  return nb > 1 ? (size_t)nb * cols * sizeof(float) : 0;
+}
+
+extern "C" int rp_colsum(const float* in, int rows, int cols, int ld, float* out, float* workspace,
+                         size_t workspace_bytes, void* stream) {
+  if (rows <= 0 || cols <= 0) return RP_EBADSHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const int rpb = colsum_stage1_rows(rows);
+  const int nb = (rows + rpb - 1) / rpb;
+  const int gx = (cols + 255) / 256;
+  if (nb == 1) {
+    hipLaunchKernelGGL(colsum_kernel, dim3(gx, 1), dim3(256), 0, st, in, rows, cols, ld, rpb, out);
+    RP_CHECK_LAUNCH();
+    return RP_OK;
+  }
+  if (!workspace || workspace_bytes < rp_colsum_workspace_bytes(rows, cols)) return RP_EWORKSPACE;
+  hipLaunchKernelGGL(colsum_kernel, dim3(gx, nb), dim3(256), 0, st, in, rows, cols, ld, rpb, workspace);
+  RP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(colsum_kernel, dim3(gx, 1), dim3(256), 0, st, (const float*)workspace, nb, cols, cols, nb, out);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
+extern "C" int rp_tokens_fwd(const float* feat, const float* pos_embed, float* x, int Z, int C, int N, void* stream) {
+  if (Z <= 0 || (C & 31) || (N & 31)) return RP_EBADSHAPE;
+  hipLaunchKernelGGL(tokens_fwd_kernel, dim3(N / 32, C / 32, Z), dim3(256), 0, (hipStream_t)stream, feat, pos_embed, x,
+                     C, N);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
+extern "C" int rp_tokens_bwd(const float* dx, float* dfeat, int Z, int C, int N, void* stream) {
+  if (Z <= 0 || (C & 31) || (N & 31)) return RP_EBADSHAPE;
+  hipLaunchKernelGGL(tokens_bwd_kernel, dim3(N / 32, C / 32, Z), dim3(256), 0, (hipStream_t)stream, dx, dfeat, C, N);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
+extern "C" int rp_posenc(const float* intrinsics, const float* lin24, float* pos, int B, void* stream) {
+  if (B <= 0) return RP_EBADSHAPE;
+  hipLaunchKernelGGL(posenc_kernel, dim3((B * 576 + 255) / 256), dim3(256), 0, (hipStream_t)stream, intrinsics, lin24,
+                     pos, B);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
+extern "C" int rp_emm_build_x(const float* qkv, const float* pos, float* x, int Z, int H, int ldqkv, void* stream) {
+  if (Z <= 0 || (Z & 1) || H <= 0) return RP_EBADSHAPE;
+  hipLaunchKernelGGL(emm_build_x_kernel, dim3(576 / 8, H, Z), dim3(256), 0, (hipStream_t)stream, qkv, pos, x, H, ldqkv);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
+extern "C" int rp_emm_build_x_bwd(const float* dx, float* dqkv, int Z, int H, int ldqkv, void* stream) {
+  if (Z <= 0 || H <= 0) return RP_EBADSHAPE;
+  hipLaunchKernelGGL(emm_build_x_bwd_kernel, dim3(576 / 4, H, Z), dim3(256), 0, (hipStream_t)stream, dx, dqkv, H,
+                     ldqkv);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
+extern "C" int rp_emm_finalize(const float* f_part, float* g, int Z, int H, int ldg, void* stream) {
+  if (Z <= 0 || (Z & 1) || H * 70 > ldg) return RP_EBADSHAPE;
+  hipLaunchKernelGGL(emm_finalize_kernel, dim3(70, Z), dim3(256), 0, (hipStream_t)stream, f_part, g, H, ldg, 6);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
+extern "C" int rp_emm_finalize_bwd(const float* dg, float* df, int Z, int H, int ldg, void* stream) {
+  if (Z <= 0 || (Z & 1) || H * 70 > ldg) return RP_EBADSHAPE;
+  hipLaunchKernelGGL(emm_finalize_bwd_kernel, dim3(96, H, Z), dim3(256), 0, (hipStream_t)stream, dg, df, H, ldg);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
+extern "C" int rp_rowdot96(const float* a, const float* b, float* out, long long rows, void* stream) {
+  if (rows <= 0) return RP_EBADSHAPE;
+  hipLaunchKernelGGL(rowdot96_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, b, out,
+                     rows);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
+extern "C" int rp_attn_bwd_delta(const float* dout, const float* o, float* delta, int Z, int H, int ld, void* stream) {
+  if (Z <= 0 || H <= 0) return RP_EBADSHAPE;
+  const long long total = (long long)Z * 576 * H;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dout, o,
+                     delta, H, ld, total);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
+extern "C" int rp_pose_normalize_fwd(const float* pred, const float* gs, float* out, int B, void* stream) {
+  if (B <= 0) return RP_EBADSHAPE;
+  hipLaunchKernelGGL(pose_norm_fwd_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, pred, gs, out, B);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
+extern "C" int rp_pose_normalize_bwd(const float* pred, const float* dout, float* dpred, int B, void* stream) {
+  if (B <= 0) return RP_EBADSHAPE;
+  hipLaunchKernelGGL(pose_norm_bwd_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, pred, dout, dpred, B);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
+extern "C" int rp_abi_version(void) { return 1; }
+extern "C" const char* rp_target_arch(void) { return "gfx950"; }

@@ -1,0 +1,105 @@
+"""ViTEss -- drop-in for reference src/model.py (same constructor args, forward signature, attribute names and
+state_dict keys), with the ViT + Essential-Matrix-Module hot path on hand-written gfx950 kernels.
+
+forward(images, Gs, intrinsics=None, inference=False)      reference src/model.py:161-191
+  images      [B,2,3,H,W] fp32 BGR 0..255
+  Gs          SE3-like (.data [B,2,7]) or numpy [2,7]
+  intrinsics  [B,2,4] (fx,fy,cx,cy) in pixels -- rescaled IN PLACE to the 24x24 grid like the reference (:100-109)
+returns [SE3([B,2,7])]  (or numpy [2,7] of element 0 when inference=True)
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .modules.extractor import ResidualBlock
+from .modules.resnet import resnet18
+from .modules.vision_transformer import _create_vision_transformer
+from .se3 import SE3
+
+
+class ViTEss(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        noess = getattr(args, "noess", None)
+        if noess:
+            raise NotImplementedError("--noess ablation is out of scope (SURVEY.md 8a row a14)")
+        if not getattr(args, "fusion_transformer", False):
+            raise NotImplementedError("only --fusion_transformer models exist in the reference's scripts/*.sh")
+        self.noess = None
+        self.total_num_features = 192
+        self.feature_resolution = (24, 24)
+        self.num_images = 2
+        self.pose_size = 7
+        self.num_patches = 24 * 24
+        self.H2 = args.fc_hidden_size
+
+        self.flatten = nn.Flatten(0, 1)
+        self.resnet = resnet18(pretrained=True)
+        self.resnet.fc = nn.Identity()
+        self.extractor_final_conv = ResidualBlock(128, self.total_num_features, "batch", kernel_size=5)
+
+        self.num_heads = 3
+        self.transformer_depth = args.transformer_depth
+        self.fusion_transformer = _create_vision_transformer(
+            "vit_tiny_patch16_384", patch_size=16, embed_dim=self.total_num_features, depth=args.transformer_depth,
+            num_heads=self.num_heads, cross_features=args.cross_features, use_single_softmax=args.use_single_softmax,
+            no_pos_encoding=args.no_pos_encoding, noess=noess, l1_pos_encoding=args.l1_pos_encoding)
+        nn.init.xavier_uniform_(self.fusion_transformer.pos_embed)     # src/model.py:54-56
+        self.pos_encoding = None
+
+        hd = self.total_num_features // self.num_heads
+        self.H = int(self.num_heads * 2 * (hd + 6) * hd)               # 26880, src/model.py:61
+        self.pose_regressor = nn.Sequential(
+            nn.Linear(self.H, self.H2), nn.ReLU(), nn.Linear(self.H2, self.H2), nn.ReLU(),
+            nn.Linear(self.H2, self.num_images * self.pose_size), nn.Unflatten(1, (self.num_images, self.pose_size)))
+
+    # -- src/model.py:100-109 ---------------------------------------------------------------------
+    def update_intrinsics(self, input_shape, intrinsics):
+        sizey, sizex = self.feature_resolution
+        scalex = sizex / input_shape[-1]
+        scaley = sizey / input_shape[-2]
+        intrinsics[:, :, [0, 2]] = scalex * intrinsics[:, :, [0, 2]]
+        intrinsics[:, :, [1, 3]] = scaley * intrinsics[:, :, [1, 3]]
+        return intrinsics
+
+    # -- src/model.py:111-143 ---------------------------------------------------------------------
+    def cnn_map(self, images, intrinsics=None):
+        """preprocessing + CNN front-end -> [2B,192,24,24] (PyTorch-ROCm / MIOpen: 'next' row 8f-1)."""
+        images = images[:, :, [2, 1, 0]] / 255.0
+        mean = torch.as_tensor([0.485, 0.456, 0.406], device=images.device)
+        std = torch.as_tensor([0.229, 0.224, 0.225], device=images.device)
+        images = images.sub_(mean[:, None, None]).div_(std[:, None, None])
+        if intrinsics is not None:
+            intrinsics = self.update_intrinsics(images.shape, intrinsics)
+        x = F.interpolate(self.flatten(images), size=224)
+        r = self.resnet
+        x = r.maxpool(r.relu(r.bn1(r.conv1(x))))
+        x = r.layer2(r.layer1(x))
+        return self.extractor_final_conv(x), intrinsics
+
+    def extract_features(self, images, intrinsics=None):
+        """tokens [2B,576,192] WITHOUT pos_embed (reference return value, src/model.py:136-143)."""
+        fmap, intrinsics = self.cnn_map(images, intrinsics)
+        zero_pe = torch.zeros_like(self.fusion_transformer.pos_embed[0])
+        return ops.TokensFn.apply(fmap, zero_pe), intrinsics
+
+    def forward_tokens(self, fmap, Gs_data, intrinsics=None):
+        """hot path: CNN map [2B,192,24,24] (or [2B,192,576]) -> normalised poses [B,2,7]."""
+        ft = self.fusion_transformer
+        x = ops.TokensFn.apply(fmap, ft.pos_embed[0])
+        for layer in range(self.transformer_depth):
+            x = ft.blocks[layer](x, intrinsics=intrinsics)
+        pr = self.pose_regressor
+        return ops.HeadFn.apply(x, Gs_data, ft.norm.weight, ft.norm.bias, pr[0].weight, pr[0].bias, pr[2].weight,
+                                pr[2].bias, pr[4].weight, pr[4].bias)
+
+    def forward(self, images, Gs, intrinsics=None, inference=False):
+        if not hasattr(Gs, "data") or isinstance(Gs, np.ndarray):
+            Gs = SE3(torch.from_numpy(np.asarray(Gs)).unsqueeze(0).to(images.device).float())
+        fmap, intrinsics = self.cnn_map(images, intrinsics)
+        out = self.forward_tokens(fmap, Gs.data.to(torch.float32), intrinsics)
+        if inference:
+            return out[0].detach().cpu().numpy()
+        return [SE3(out)]

@@ -1,0 +1,462 @@
+"""Host-side op layer: thin, typed wrappers over the C ABI (include/relpose_hip.h) plus the
+torch.autograd.Function classes that stitch the HIP kernels into the reference's modules.
+
+Granularity: one autograd Function per reference module on the hot path --
+  TokensFn        src/model.py:136-141,170-171          (token layout + pos_embed)
+  BlockFn         vision_transformer.py:349-354 (Block = LN, Attention :321-333, LN, Mlp mlp.py:20-26)
+  CrossBlockFn    vision_transformer.py:285-296 (CrossBlock = LN, CrossAttention/EMM :188-238, LN, Mlp)
+  HeadFn          src/model.py:178,189,91-98,145-159    (final LN, regressor, quaternion normalise)
+so every residual add, bias, GELU/ReLU and their derivatives is fused into a kernel epilogue and autograd never
+inserts an elementwise kernel of its own.  PyTorch is used for memory, streams and the autograd graph only.
+All tensors are fp32, contiguous, on the GPU; anything else raises (there is no CPU path).
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+
+N_TOK = 576
+DIM = 192
+HEADS = 3
+LN_EPS = 1e-6
+XW = 96          # padded width of the EMM's augmented value rows (64 + 6 -> 96)
+GW = 224         # padded K of proj_fundamental (3*70 = 210 -> 224)
+NWG = 6          # workgroup partials per (image, head) in rp_emm_apply
+
+
+# ------------------------------------------------------------------------------------------------
+# plumbing
+# ------------------------------------------------------------------------------------------------
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise RuntimeError("rel_pose_amd ops need contiguous fp32 GPU tensors (no CPU fallback exists); got "
+                               "%s %s contiguous=%s" % (t.device, t.dtype, t.is_contiguous()))
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _st():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _empty(*shape, like):
+    return torch.empty(shape, device=like.device, dtype=torch.float32)
+
+
+def pick_split_k(M, N, K, target_wgs=512, min_ktiles=8):
+    tm = 1 if M <= 64 else 2
+    tn = 3 if N % 192 == 0 else (1 if N <= 64 else 2)
+    tiles = -(-M // (64 * tm)) * -(-N // (64 * tn))
+    ktiles = -(-K // 32)
+    if tiles >= 256 or ktiles < 2 * min_ktiles:
+        return 1
+    return max(1, min(ktiles // min_ktiles, -(-target_wgs // tiles)))
+
+
+def gemm(A, B, M, N, K, *, a_layout=0, b_layout=0, lda=None, ldb=None, out=None, ldc=None, bias=None, act=0,
+         pre_out=None, dact=0, aux=None, residual=None, split_k=None, batch=1, strides=(0, 0, 0)):
+    """C[M,N] = epilogue(op(A) op(B)); see RpGemm in include/relpose_hip.h."""
+    lib = _lib.load()
+    _chk(A, B, out, bias, pre_out, aux, residual)
+    if lda is None:
+        lda = K if a_layout == 0 else M
+    if ldb is None:
+        ldb = K if b_layout == 0 else N
+    if out is None:
+        out = _empty(*((batch, M, N) if batch > 1 else (M, N)), like=A)
+    if ldc is None:
+        ldc = N
+    if split_k is None:
+        split_k = pick_split_k(M, N, K) if batch == 1 and N % 4 == 0 else 1
+    g = _lib.RpGemm()
+    g.A, g.B, g.C = A.data_ptr(), B.data_ptr(), out.data_ptr()
+    g.M, g.N, g.K = M, N, K
+    g.lda, g.ldb, g.ldc = lda, ldb, ldc
+    g.a_layout, g.b_layout, g.batch = a_layout, b_layout, batch
+    g.stride_a, g.stride_b, g.stride_c = strides
+    g.split_k = split_k
+    ws = None
+    if split_k > 1:
+        nbytes = lib.rp_gemm_workspace_bytes(M, N, split_k)
+        ws = torch.empty(nbytes // 4, device=A.device, dtype=torch.float32)
+        g.workspace, g.workspace_bytes = ws.data_ptr(), nbytes
+    g.bias = None if bias is None else bias.data_ptr()
+    g.pre_out = None if pre_out is None else pre_out.data_ptr()
+    g.act, g.dact = act, dact
+    g.aux = None if aux is None else aux.data_ptr()
+    g.residual = None if residual is None else residual.data_ptr()
+    _lib.check(lib.rp_gemm(ctypes.byref(g), _st()), "rp_gemm")
+    return out
+
+
+def linear(x, W, b=None, act=0, want_pre=False, residual=None):
+    """y = act(x W^T + b) (+ residual); x [M,K], W [N,K]."""
+    M, K = x.shape
+    N = W.shape[0]
+    pre = _empty(M, N, like=x) if want_pre else None
+    y = gemm(x, W, M, N, K, bias=b, act=act, pre_out=pre, residual=residual)
+    return (y, pre) if want_pre else y
+
+
+def linear_dx(dy, W, dact=0, aux=None):
+    """dx = (dy W) o act'(aux); dy [M,N], W [N,K] -> [M,K]."""
+    M, N = dy.shape
+    K = W.shape[1]
+    return gemm(dy, W, M, K, N, b_layout=1, dact=dact, aux=aux)
+
+
+def linear_dw(dy, x):
+    """dW = dy^T x; dy [M,N], x [M,K] -> [N,K]  (reduction over the M token rows, split-K)."""
+    M, N = dy.shape
+    K = x.shape[1]
+    return gemm(dy, x, N, K, M, a_layout=1, b_layout=1)
+
+
+def colsum(t2d):
+    lib = _lib.load()
+    _chk(t2d)
+    rows, cols = t2d.shape
+    out = _empty(cols, like=t2d)
+    nbytes = lib.rp_colsum_workspace_bytes(rows, cols)
+    ws = torch.empty(max(nbytes // 4, 1), device=t2d.device, dtype=torch.float32)
+    _lib.check(lib.rp_colsum(_p(t2d), rows, cols, cols, _p(out), _p(ws), nbytes, _st()), "rp_colsum")
+    return out
+
+
+def layernorm_fwd(x2d, gamma, beta, eps=LN_EPS, want_stats=True):
+    lib = _lib.load()
+    _chk(x2d, gamma, beta)
+    rows, C = x2d.shape
+    y = torch.empty_like(x2d)
+    mean = _empty(rows, like=x2d) if want_stats else None
+    rstd = _empty(rows, like=x2d) if want_stats else None
+    _lib.check(lib.rp_layernorm_fwd(_p(x2d), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, C, eps, _st()),
+               "rp_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x2d, gamma, mean, rstd, add=None):
+    """returns dx (+add), dgamma, dbeta"""
+    lib = _lib.load()
+    _chk(dy, x2d, gamma, mean, rstd, add)
+    rows, C = x2d.shape
+    nblk = lib.rp_layernorm_bwd_blocks(rows)
+    dx = torch.empty_like(x2d)
+    part = _empty(2, nblk, C, like=x2d)
+    _lib.check(lib.rp_layernorm_bwd(_p(dy), _p(x2d), _p(gamma), _p(mean), _p(rstd), _p(add), _p(dx), _p(part[0]),
+                                    _p(part[1]), rows, C, _st()), "rp_layernorm_bwd")
+    return dx, colsum(part[0]), colsum(part[1])
+
+
+def attn_fwd(qkv, Z, stats_only=False, q_off=0, k_off=DIM, v_off=2 * DIM, q_xor=0, k_xor=0):
+    """qkv [Z*576, 576] packed (q | k | v, head-major columns).  Returns (o [Z*576,192] or None, lse [Z,H,576])."""
+    lib = _lib.load()
+    _chk(qkv)
+    ld = qkv.shape[1]
+    o = None if stats_only else _empty(Z * N_TOK, DIM, like=qkv)
+    lse = _empty(Z, HEADS, N_TOK, like=qkv)
+    base = qkv.data_ptr()
+    P = ctypes.c_void_p
+    _lib.check(lib.rp_attn_fwd(P(base + 4 * q_off), P(base + 4 * k_off), P(base + 4 * v_off), _p(o), _p(lse), Z, HEADS,
+                               ld, ld, ld, DIM, q_xor, k_xor, (DIM // HEADS) ** -0.5, 1 if stats_only else 0, _st()),
+               "rp_attn_fwd")
+    return o, lse
+
+
+def attn_bwd(qkv, o, lse, do, Z):
+    lib = _lib.load()
+    _chk(qkv, o, lse, do)
+    ld = qkv.shape[1]
+    delta = _empty(Z, HEADS, N_TOK, like=qkv)
+    _lib.check(lib.rp_attn_bwd_delta(_p(do), _p(o), _p(delta), Z, HEADS, DIM, _st()), "rp_attn_bwd_delta")
+    dqkv = torch.empty_like(qkv)
+    P = ctypes.c_void_p
+    b, d = qkv.data_ptr(), dqkv.data_ptr()
+    _lib.check(lib.rp_attn_bwd(P(b), P(b + 4 * DIM), P(b + 8 * DIM), _p(do), _p(lse), _p(delta), P(d), P(d + 4 * DIM),
+                               P(d + 8 * DIM), Z, HEADS, ld, ld, ld, DIM, ld, ld, ld, (DIM // HEADS) ** -0.5, _st()),
+               "rp_attn_bwd")
+    return dqkv
+
+
+_LIN24 = {}
+
+
+def lin24(device):
+    """torch.linspace(-1, 1, 24) exactly as the reference builds it (vision_transformer.py:110-111)."""
+    key = str(device)
+    if key not in _LIN24:
+        _LIN24[key] = torch.linspace(-1, 1, steps=24, dtype=torch.float32).to(device)
+    return _LIN24[key]
+
+
+def posenc(intrinsics, B, device):
+    lib = _lib.load()
+    _chk(intrinsics)
+    pos = torch.empty(B, N_TOK, 6, device=device, dtype=torch.float32)
+    _lib.check(lib.rp_posenc(_p(intrinsics), _p(lin24(device)), _p(pos), B, _st()), "rp_posenc")
+    return pos
+
+
+def emm_build_x(qkv, pos, Z):
+    lib = _lib.load()
+    _chk(qkv, pos)
+    x = _empty(Z, HEADS, N_TOK, XW, like=qkv)
+    _lib.check(lib.rp_emm_build_x(_p(qkv), _p(pos), _p(x), Z, HEADS, qkv.shape[1], _st()), "rp_emm_build_x")
+    return x
+
+
+def emm_stats(qkv, Z):
+    """row / column log-sum-exp of S_z = scale q_{z^1} k_z^T."""
+    _, rlse = attn_fwd(qkv, Z, stats_only=True, q_off=0, k_off=DIM, q_xor=1, k_xor=0)
+    _, clse = attn_fwd(qkv, Z, stats_only=True, q_off=DIM, k_off=0, q_xor=0, k_xor=1)
+    return rlse, clse
+
+
+def emm_apply(qkv, x, rlse, clse, Z, swap=False, want_t=True, want_f=True):
+    lib = _lib.load()
+    _chk(qkv, x, rlse, clse)
+    t = _empty(Z, HEADS, N_TOK, XW, like=qkv) if want_t else None
+    f = _empty(Z, HEADS, NWG, XW, XW, like=qkv) if (want_f and not swap) else None
+    _lib.check(lib.rp_emm_apply(_p(qkv), qkv.shape[1], _p(x), _p(rlse), _p(clse), _p(t), _p(f), Z, HEADS,
+                                (DIM // HEADS) ** -0.5, 1 if swap else 0, _st()), "rp_emm_apply")
+    return t, f
+
+
+def emm_finalize(fpart, Z):
+    lib = _lib.load()
+    g = _empty(Z * 70, GW, like=fpart)
+    _lib.check(lib.rp_emm_finalize(_p(fpart), _p(g), Z, HEADS, GW, _st()), "rp_emm_finalize")
+    return g
+
+
+def emm_finalize_bwd(dg, Z):
+    lib = _lib.load()
+    _chk(dg)
+    df = _empty(Z, HEADS, XW, XW, like=dg)
+    _lib.check(lib.rp_emm_finalize_bwd(_p(dg), _p(df), Z, HEADS, GW, _st()), "rp_emm_finalize_bwd")
+    return df
+
+
+def rowdot96(a, b):
+    lib = _lib.load()
+    _chk(a, b)
+    rows = a.numel() // XW
+    out = _empty(*a.shape[:-1], like=a)
+    _lib.check(lib.rp_rowdot96(_p(a), _p(b), _p(out), rows, _st()), "rp_rowdot96")
+    return out
+
+
+def _bmm96(X, D, transpose_d, residual=None):
+    """[ZH,576,96] x [ZH,96,96](^T) -> [ZH,576,96]"""
+    ZH = X.shape[0] * X.shape[1]
+    out = torch.empty_like(X)
+    gemm(X, D, N_TOK, XW, XW, b_layout=0 if transpose_d else 1, out=out, residual=residual, split_k=1, batch=ZH,
+         strides=(N_TOK * XW, XW * XW, N_TOK * XW))
+    return out
+
+
+def emm_backward(qkv, x, t, rlse, clse, df, Z):
+    """Gradient of F = X^T A X wrt qkv (q, k through A; v through X).  df: [Z,H,96,96] zero-padded."""
+    lib = _lib.load()
+    scale = (DIM // HEADS) ** -0.5
+    w = _bmm96(x, df, False)        # W  = X dF      (rows i)
+    wp = _bmm96(x, df, True)        # W' = X dF^T    (rows j)
+    u, _ = emm_apply(qkv, x, rlse, clse, Z, swap=True, want_f=False)     # U = A^T X
+    rho = rowdot96(w, t)            # rho_i   = sum_j A_ij dA_ij
+    gam = rowdot96(wp, u)           # gamma_j = sum_i A_ij dA_ij
+    dx = _bmm96(t, df, True)
+    dx = _bmm96(u, df, False, residual=dx)                     # dX = T dF^T + U dF
+    dqkv = torch.empty_like(qkv)
+    ld = qkv.shape[1]
+    _lib.check(lib.rp_emm_grad(_p(qkv), ld, _p(x), _p(w), _p(rlse), _p(clse), _p(rho), _p(gam), _p(dqkv), Z, HEADS,
+                               scale, 0, _st()), "rp_emm_grad(q)")
+    _lib.check(lib.rp_emm_grad(_p(qkv), ld, _p(x), _p(wp), _p(rlse), _p(clse), _p(rho), _p(gam), _p(dqkv), Z, HEADS,
+                               scale, 1, _st()), "rp_emm_grad(k)")
+    _lib.check(lib.rp_emm_build_x_bwd(_p(dx), _p(dqkv), Z, HEADS, ld, _st()), "rp_emm_build_x_bwd")
+    return dqkv
+
+
+# ------------------------------------------------------------------------------------------------
+# autograd Functions
+# ------------------------------------------------------------------------------------------------
+class TokensFn(torch.autograd.Function):
+    """x[z][n][c] = feat[z][c][n] + pos_embed[n][c]  (src/model.py:136-141,170-171)."""
+
+    @staticmethod
+    def forward(ctx, feat, pos_embed):
+        lib = _lib.load()
+        feat = feat.contiguous()
+        _chk(feat, pos_embed)
+        Z, C = feat.shape[0], feat.shape[1]
+        N = feat.numel() // (Z * C)
+        x = _empty(Z, N, C, like=feat)
+        _lib.check(lib.rp_tokens_fwd(_p(feat), _p(pos_embed), _p(x), Z, C, N, _st()), "rp_tokens_fwd")
+        ctx.shape = tuple(feat.shape)
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        lib = _lib.load()
+        dx = dx.contiguous()
+        Z, N, C = dx.shape
+        dfeat = _empty(*ctx.shape, like=dx)
+        _lib.check(lib.rp_tokens_bwd(_p(dx), _p(dfeat), Z, C, N, _st()), "rp_tokens_bwd")
+        dpe = colsum(dx.view(Z, N * C)).view(1, N, C)
+        return dfeat, dpe
+
+
+def _mlp_fwd(xn, w1, b1, w2, b2, residual, train):
+    if train:
+        h, hpre = linear(xn, w1, b1, act=1, want_pre=True)
+    else:
+        h, hpre = linear(xn, w1, b1, act=1), None
+    y = linear(h, w2, b2, residual=residual)
+    return y, h, hpre
+
+
+def _mlp_bwd(dy, xn, h, hpre, w1, w2):
+    dh = linear_dx(dy, w2, dact=1, aux=hpre)          # grad wrt fc1 pre-activation (GELU' fused)
+    dw2, db2 = linear_dw(dy, h), colsum(dy)
+    dxn = linear_dx(dh, w1)
+    dw1, db1 = linear_dw(dh, xn), colsum(dh)
+    return dxn, dw1, db1, dw2, db2
+
+
+class BlockFn(torch.autograd.Function):
+    """Block.forward (vision_transformer.py:349-354) on x [Z,576,192]."""
+
+    @staticmethod
+    def forward(ctx, x, n1w, n1b, qkv_w, qkv_b, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b):
+        train = any(ctx.needs_input_grad)   # (grad mode is off inside Function.forward)
+        x = x.contiguous()
+        Z = x.shape[0]
+        x2 = x.view(Z * N_TOK, DIM)
+        xn1, m1, r1 = layernorm_fwd(x2, n1w, n1b)
+        qkv = linear(xn1, qkv_w, qkv_b)
+        o, lse = attn_fwd(qkv, Z)
+        x1 = linear(o, proj_w, proj_b, residual=x2)
+        xn2, m2, r2 = layernorm_fwd(x1, n2w, n2b)
+        y, h, hpre = _mlp_fwd(xn2, fc1_w, fc1_b, fc2_w, fc2_b, x1, train)
+        if train:
+            ctx.save_for_backward(x2, m1, r1, xn1, qkv, o, lse, x1, m2, r2, xn2, h, hpre, n1w, qkv_w, proj_w, n2w,
+                                  fc1_w, fc2_w)
+            ctx.Z = Z
+        return y.view(Z, N_TOK, DIM)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x2, m1, r1, xn1, qkv, o, lse, x1, m2, r2, xn2, h, hpre, n1w, qkv_w, proj_w, n2w, fc1_w,
+         fc2_w) = ctx.saved_tensors
+        Z = ctx.Z
+        dy = dy.contiguous().view(Z * N_TOK, DIM)
+        dxn2, dfc1w, dfc1b, dfc2w, dfc2b = _mlp_bwd(dy, xn2, h, hpre, fc1_w, fc2_w)
+        dx1, dn2w, dn2b = layernorm_bwd(dxn2, x1, n2w, m2, r2, add=dy)
+        do = linear_dx(dx1, proj_w)
+        dprojw, dprojb = linear_dw(dx1, o), colsum(dx1)
+        dqkv = attn_bwd(qkv, o, lse, do, Z)
+        dxn1 = linear_dx(dqkv, qkv_w)
+        dqkvw, dqkvb = linear_dw(dqkv, xn1), colsum(dqkv)
+        dx, dn1w, dn1b = layernorm_bwd(dxn1, x2, n1w, m1, r1, add=dx1)
+        return (dx.view(Z, N_TOK, DIM), dn1w, dn1b, dqkvw, dqkvb, dprojw, dprojb, dn2w, dn2b, dfc1w, dfc1b, dfc2w,
+                dfc2b)
+
+
+class CrossBlockFn(torch.autograd.Function):
+    """CrossBlock.forward, ess branch (vision_transformer.py:285-296): x [2B,576,192] -> [2B,70,192]."""
+
+    @staticmethod
+    def forward(ctx, x, pos, n1w, n1b, qkv_w, qkv_b, pf_w, pf_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b):
+        train = any(ctx.needs_input_grad)   # (grad mode is off inside Function.forward)
+        x = x.contiguous()
+        Z = x.shape[0]
+        x2 = x.view(Z * N_TOK, DIM)
+        xn, m1, r1 = layernorm_fwd(x2, n1w, n1b)
+        qkv = linear(xn, qkv_w, qkv_b)
+        rlse, clse = emm_stats(qkv, Z)
+        xa = emm_build_x(qkv, pos, Z)
+        t, fpart = emm_apply(qkv, xa, rlse, clse, Z, swap=False, want_t=train)
+        g = emm_finalize(fpart, Z)                                     # [Z*70, 224]
+        pf_wp = torch.nn.functional.pad(pf_w, (0, GW - pf_w.shape[1])).contiguous()
+        f = linear(g, pf_wp, pf_b)                                     # [Z*70, 192]
+        fn, m2, r2 = layernorm_fwd(f, n2w, n2b)
+        y, h, hpre = _mlp_fwd(fn, fc1_w, fc1_b, fc2_w, fc2_b, f, train)
+        if train:
+            ctx.save_for_backward(x2, m1, r1, xn, qkv, rlse, clse, xa, t, g, f, m2, r2, fn, h, hpre, n1w, qkv_w, pf_wp,
+                                  n2w, fc1_w, fc2_w)
+            ctx.Z = Z
+            ctx.pf_cols = pf_w.shape[1]
+        return y.view(Z, 70, DIM)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x2, m1, r1, xn, qkv, rlse, clse, xa, t, g, f, m2, r2, fn, h, hpre, n1w, qkv_w, pf_wp, n2w, fc1_w,
+         fc2_w) = ctx.saved_tensors
+        Z = ctx.Z
+        dy = dy.contiguous().view(Z * 70, DIM)
+        dfn, dfc1w, dfc1b, dfc2w, dfc2b = _mlp_bwd(dy, fn, h, hpre, fc1_w, fc2_w)
+        df_, dn2w, dn2b = layernorm_bwd(dfn, f, n2w, m2, r2, add=dy)
+        dg = linear_dx(df_, pf_wp)                                      # [Z*70, 224]
+        dpfw = linear_dw(df_, g)[:, :ctx.pf_cols].contiguous()
+        dpfb = colsum(df_)
+        dF = emm_finalize_bwd(dg, Z)
+        dqkv = emm_backward(qkv, xa, t, rlse, clse, dF, Z)
+        dxn = linear_dx(dqkv, qkv_w)
+        dqkvw, dqkvb = linear_dw(dqkv, xn), colsum(dqkv)
+        dx, dn1w, dn1b = layernorm_bwd(dxn, x2, n1w, m1, r1)
+        return (dx.view(Z, N_TOK, DIM), None, dn1w, dn1b, dqkvw, dqkvb, dpfw, dpfb, dn2w, dn2b, dfc1w, dfc1b, dfc2w,
+                dfc2b)
+
+
+class HeadFn(torch.autograd.Function):
+    """final LayerNorm -> flatten [B,26880] -> 26880-512-512-14 MLP -> quaternion normalise
+    (src/model.py:178,189,91-98,145-159).  y: [2B,70,192]; gs: [B,2,7] -> [B,2,7]."""
+
+    @staticmethod
+    def forward(ctx, y, gs, nw, nb, w0, b0, w2, b2, w4, b4):
+        lib = _lib.load()
+        train = any(ctx.needs_input_grad)   # (grad mode is off inside Function.forward)
+        y = y.contiguous()
+        Z = y.shape[0]
+        B = Z // 2
+        y2 = y.view(Z * 70, DIM)
+        fn, m, r = layernorm_fwd(y2, nw, nb)
+        feats = fn.view(B, 2 * 70 * DIM)
+        h1 = linear(feats, w0, b0, act=2)
+        h2 = linear(h1, w2, b2, act=2)
+        w4p = torch.nn.functional.pad(w4, (0, 0, 0, 2)).contiguous()    # 14 -> 16 output rows (float4 alignment)
+        b4p = torch.nn.functional.pad(b4, (0, 2)).contiguous()
+        pred = linear(h2, w4p, b4p)[:, :14].contiguous()               # [B,14] == [B,2,7]
+        gs = gs.contiguous()
+        _chk(gs)
+        out = _empty(B, 2, 7, like=y)
+        _lib.check(lib.rp_pose_normalize_fwd(_p(pred), _p(gs), _p(out), B, _st()), "rp_pose_normalize_fwd")
+        if train:
+            ctx.save_for_backward(y2, m, r, fn, h1, h2, pred, nw, w0, w2, w4p)
+            ctx.B = B
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        y2, m, r, fn, h1, h2, pred, nw, w0, w2, w4p = ctx.saved_tensors
+        B = ctx.B
+        dout = dout.contiguous()
+        dpred = _empty(B, 14, like=dout)
+        _lib.check(lib.rp_pose_normalize_bwd(_p(pred), _p(dout), _p(dpred), B, _st()), "rp_pose_normalize_bwd")
+        dp16 = torch.nn.functional.pad(dpred, (0, 2)).contiguous()
+        dh2 = linear_dx(dp16, w4p, dact=2, aux=h2)
+        dw4, db4 = linear_dw(dp16, h2)[:14].contiguous(), colsum(dpred)
+        dh1 = linear_dx(dh2, w2, dact=2, aux=h1)
+        dw2, db2 = linear_dw(dh2, h1), colsum(dh2)
+        feats = fn.view(B, -1)
+        dfeats = linear_dx(dh1, w0)
+        dw0, db0 = linear_dw(dh1, feats), colsum(dh1)
+        dy, dnw, dnb = layernorm_bwd(dfeats.view(-1, DIM), y2, nw, m, r)
+        return dy.view(2 * B, 70, DIM), None, dnw, dnb, dw0, db0, dw2, db2, dw4, db4

@@ -1,0 +1,269 @@
+"""GPU parity tests, kernel by kernel, through the C ABI (ctypes) on a real MI355X.
+
+References: (i) the CPU oracle (oracle/relpose_oracle.py, pinned against the real reference by
+tests/test_oracle_golden.py) evaluated in fp64; (ii) for op-level checks at larger sizes, the same op written
+in plain PyTorch fp64 on the GPU.  Tolerances are stated per test; index/layout ops are bit-exact.
+Measured errors are appended to gpurun_out/test_report.txt.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def report(name, **kv):
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "test_report.txt"), "a") as f:
+        f.write(name + ": " + ", ".join("%s=%.3e" % (k, v) for k, v in kv.items()) + "\n")
+
+
+def rel(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    from rel_pose_amd import _lib, ops as o
+    _lib.load()
+    return o
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed + int(np.prod(shape)) % 9973)
+    return (torch.randn(*shape, generator=g) * scale).cuda()
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 192, 192), (1152, 576, 192), (200, 768, 192), (70, 192, 224), (64, 512, 2688),
+                                   (33, 16, 512), (1152, 192, 768), (130, 100, 36)])
+@pytest.mark.parametrize("al,bl", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_layouts(ops, M, N, K, al, bl):
+    if (al == 1 and M % 4) or (bl == 1 and N % 4):
+        pytest.skip("contiguous extent must be a multiple of 4")
+    A = rnd(M, K, seed=1)
+    Bm = rnd(N, K, seed=2)
+    ref = A.double() @ Bm.double().t()
+    Ain = A if al == 0 else A.t().contiguous()
+    Bin = Bm if bl == 0 else Bm.t().contiguous()
+    out = ops.gemm(Ain, Bin, M, N, K, a_layout=al, b_layout=bl, split_k=1)
+    e = rel(out, ref)
+    report("gemm[%d,%d,%d|%d%d]" % (M, N, K, al, bl), rel=e)
+    assert e < 2e-6
+    # A = I with an asymmetric B catches transposed C writes
+    if M == K and al == 0 and bl == 0:
+        eye = torch.eye(M, device="cuda")
+        assert torch.equal(ops.gemm(eye, Bm, M, N, K, split_k=1), Bm.t().contiguous())
+
+
+def test_gemm_epilogues_splitk_batch(ops):
+    M, N, K = 300, 192, 768
+    A, W, b, R = rnd(M, K, seed=3), rnd(N, K, seed=4, scale=0.05), rnd(N, seed=5), rnd(M, N, seed=6)
+    pre_ref = A.double() @ W.double().t() + b.double()
+    gelu = lambda x: 0.5 * x * (1 + torch.erf(x / math.sqrt(2.0)))
+    y, pre = ops.linear(A, W, b, act=1, want_pre=True, residual=R)
+    assert rel(pre, pre_ref) < 2e-6
+    assert rel(y, gelu(pre_ref) + R.double()) < 2e-6
+    y2 = ops.linear(A, W, b, act=2)
+    assert rel(y2, pre_ref.clamp_min(0)) < 2e-6
+    # derivative epilogues
+    aux = rnd(M, N, seed=7)
+    x64 = aux.double().requires_grad_(True)
+    gelu(x64).sum().backward()
+    d1 = ops.gemm(A, W, M, N, K, dact=1, aux=aux)
+    assert rel(d1, (A.double() @ W.double().t()) * x64.grad) < 2e-6
+    d2 = ops.gemm(A, W, M, N, K, dact=2, aux=aux)
+    assert rel(d2, (A.double() @ W.double().t()) * (aux > 0)) < 2e-6
+    # split-K (deterministic: two runs bit-identical) incl. epilogue in the reduce kernel
+    for sk in (2, 5, 24):
+        o1 = ops.gemm(A, W, M, N, K, bias=b, act=2, residual=R, split_k=sk)
+        o2 = ops.gemm(A, W, M, N, K, bias=b, act=2, residual=R, split_k=sk)
+        assert torch.equal(o1, o2)
+        assert rel(o1, pre_ref.clamp_min(0) + R.double()) < 2e-6
+    # weight-gradient form: dW = dY^T X over many rows, auto split-K
+    Mt = 4608
+    dY, X = rnd(Mt, 192, seed=8), rnd(Mt, 768, seed=9)
+    dw = ops.linear_dw(dY, X)
+    e = rel(dw, dY.double().t() @ X.double())
+    report("gemm_dw", rel=e)
+    assert e < 2e-6
+    dx = ops.linear_dx(dY, rnd(192, 768, seed=10))
+    assert rel(dx, dY.double() @ rnd(192, 768, seed=10).double()) < 2e-6
+    # batched 576x96 @ 96x96 (EMM backward shapes)
+    Xb, Db = rnd(2, 3, 576, 96, seed=11), rnd(2, 3, 96, 96, seed=12)
+    assert rel(ops._bmm96(Xb, Db, False), Xb.double() @ Db.double()) < 2e-6
+    assert rel(ops._bmm96(Xb, Db, True, residual=Xb), Xb.double() @ Db.double().transpose(-1, -2) + Xb.double()) < 2e-6
+    # regressor shape: M=2 rows, K=26880, split-K
+    F_, W0 = rnd(2, 26880, seed=13), rnd(512, 26880, seed=14, scale=0.01)
+    e = rel(ops.linear(F_, W0, act=2), (F_.double() @ W0.double().t()).clamp_min(0))
+    report("gemm_regressor", rel=e)
+    assert e < 5e-6
+
+
+def test_gemm_errors_are_loud(ops):
+    A = rnd(64, 30)
+    with pytest.raises(RuntimeError):
+        ops.gemm(A, rnd(64, 30), 64, 64, 30)          # K % 4 != 0 -> RP_EALIGN
+    with pytest.raises(RuntimeError):
+        ops.gemm(torch.zeros(64, 32), torch.zeros(64, 32), 64, 64, 32)      # CPU tensors: no fallback
+
+
+# ------------------------------------------------------------------------------------------------ rowwise
+def test_layernorm_fwd_bwd(ops):
+    rows, C = 1000, 192
+    x, g, b, dy, add = rnd(rows, C, seed=1), rnd(C, seed=2) * 0.2 + 1, rnd(C, seed=3), rnd(rows, C, seed=4), rnd(rows, C, seed=5)
+    y, mean, rstd = ops.layernorm_fwd(x, g, b)
+    x64 = x.double().requires_grad_(True)
+    g64, b64 = g.double().requires_grad_(True), b.double().requires_grad_(True)
+    y64 = torch.nn.functional.layer_norm(x64, (C,), g64, b64, 1e-6)
+    assert rel(y, y64) < 2e-6
+    (y64 * dy.double()).sum().backward()
+    dx, dg, db = ops.layernorm_bwd(dy, x, g, mean, rstd, add=add)
+    e = max(rel(dx, x64.grad + add.double()), rel(dg, g64.grad), rel(db, b64.grad))
+    report("layernorm", rel=e)
+    assert e < 5e-6
+
+
+def test_colsum_tokens_posenc_pose(ops, golden):
+    t = rnd(5000, 576, seed=1)
+    assert rel(ops.colsum(t), t.double().sum(0)) < 2e-6
+    assert torch.equal(ops.colsum(t), ops.colsum(t))
+    # token layout: bit-exact permutation (pos_embed = 0), then the add
+    feat = rnd(4, 192, 24, 24, seed=2)
+    pe = rnd(576, 192, seed=3)
+    tok = ops.TokensFn.apply(feat, torch.zeros_like(pe))
+    assert torch.equal(tok, feat.reshape(4, 192, 576).permute(0, 2, 1).contiguous())
+    tok2 = ops.TokensFn.apply(feat, pe)
+    assert torch.equal(tok2, feat.reshape(4, 192, 576).permute(0, 2, 1) + pe)
+    f2 = feat.clone().requires_grad_(True)
+    p2 = pe.clone().requires_grad_(True)
+    cot = rnd(4, 576, 192, seed=4)
+    (ops.TokensFn.apply(f2, p2) * cot).sum().backward()
+    assert torch.equal(f2.grad, cot.permute(0, 2, 1).reshape(4, 192, 24, 24))
+    assert rel(p2.grad, cot.double().sum(0)) < 1e-6
+    # positional features vs the reference's own output (golden) and the no-intrinsics case bit-exact
+    intr = torch.tensor([[32.373, 25.898, 12.0, 12.0], [18.0, 21.0, 12.0, 9.0]])[:, None, :].repeat(1, 2, 1).contiguous().cuda()
+    pos = ops.posenc(intr, 2, intr.device)
+    e = rel(pos, torch.as_tensor(golden["posenc_intr_f32"]))
+    report("posenc", rel=e)
+    assert e < 3e-7
+    assert np.array_equal(ops.posenc(None, 2, intr.device).cpu().numpy(), golden["posenc_none_f32"])
+    # pose normalisation fwd/bwd
+    from oracle import relpose_oracle as O
+    pred = rnd(5, 2, 7, seed=5)
+    pred[3, 1, 3:] *= 1e-3                                    # exercises the max(|q|, 0.01) clamp
+    gs = rnd(5, 2, 7, seed=6)
+    ref = O.normalize_preds(gs.cpu().double(), pred.cpu().double())
+    out = torch.empty_like(pred)
+    from rel_pose_amd import _lib
+    lib = _lib.load()
+    _lib.check(lib.rp_pose_normalize_fwd(ops._p(pred), ops._p(gs), ops._p(out), 5, ops._st()), "norm")
+    assert rel(out, ref) < 1e-6 and torch.equal(out[:, 0], gs[:, 0])
+    p64 = pred.cpu().double().requires_grad_(True)
+    cot = rnd(5, 2, 7, seed=7)
+    (O.normalize_preds(gs.cpu().double(), p64) * cot.cpu().double()).sum().backward()
+    dpred = torch.empty_like(pred)
+    _lib.check(lib.rp_pose_normalize_bwd(ops._p(pred), ops._p(cot), ops._p(dpred), 5, ops._st()), "normb")
+    assert rel(dpred, p64.grad) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _attn_ref(qkv, Z):
+    q, k, v = qkv.double().view(Z, 576, 3, 3, 64).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-1, -2)) * 0.125
+    o = (s.softmax(-1) @ v).transpose(1, 2).reshape(Z * 576, 192)
+    return o, torch.logsumexp(s, -1), s
+
+
+def test_attention_fwd_bwd(ops):
+    Z = 4
+    qkv = rnd(Z * 576, 576, seed=1)
+    qkv[:, :384] *= 1.7          # sharper softmax
+    qkv[5, :64] *= 6.0           # one spiky query row (forces a big online-softmax rescale)
+    o, lse = ops.attn_fwd(qkv, Z)
+    q64 = qkv.double().requires_grad_(True)
+    o_ref, lse_ref, _ = _attn_ref(q64, Z)
+    e_o, e_l = rel(o, o_ref), rel(lse, lse_ref)
+    report("attn_fwd", o=e_o, lse=e_l)
+    assert e_o < 5e-6 and e_l < 2e-6
+    do = rnd(Z * 576, 192, seed=2)
+    (o_ref * do.double()).sum().backward()
+    dqkv = ops.attn_bwd(qkv, o, lse, do, Z)
+    e = [rel(dqkv[:, i * 192:(i + 1) * 192], q64.grad[:, i * 192:(i + 1) * 192]) for i in range(3)]
+    report("attn_bwd", dq=e[0], dk=e[1], dv=e[2])
+    assert max(e) < 2e-5
+
+
+def test_attention_stats_partner(ops):
+    Z = 4
+    qkv = rnd(Z * 576, 576, seed=3)
+    rlse, clse = ops.emm_stats(qkv, Z)
+    t = qkv.double().view(Z, 576, 3, 3, 64).permute(2, 0, 3, 1, 4)
+    q, k = t[0], t[1]
+    qp = q[[1, 0, 3, 2]]                                    # partner image's queries
+    s = (qp @ k.transpose(-1, -2)) * 0.125                  # S_z[i][j]
+    assert rel(rlse, torch.logsumexp(s, -1)) < 2e-6
+    assert rel(clse, torch.logsumexp(s, -2)) < 2e-6
+
+
+# ------------------------------------------------------------------------------------------------ EMM
+def _emm_ref(qkv, pos, Z):
+    """fp64 F_z = X^T A X, T = A X, U = A^T X per (z,h)."""
+    t = qkv.double().view(Z, 576, 3, 3, 64).permute(2, 0, 3, 1, 4)
+    q, k, v = t[0], t[1], t[2]
+    perm = [z ^ 1 for z in range(Z)]
+    s = (q[perm] @ k.transpose(-1, -2)) * 0.125
+    a = s.softmax(-1) * s.softmax(-2)
+    pe = pos.double()[[z // 2 for z in range(Z)]].unsqueeze(1).expand(Z, 3, 576, 6)
+    x = torch.cat([v, pe], dim=-1)
+    T = a @ x
+    return x.transpose(-1, -2) @ T, T, a.transpose(-1, -2) @ x, x, a
+
+
+def test_emm_forward_pieces(ops):
+    Z = 4
+    qkv = rnd(Z * 576, 576, seed=4)
+    intr = torch.tensor([[30.0, 26.0, 12.0, 12.0], [18.0, 21.0, 12.0, 9.0]])[:, None, :].repeat(1, 2, 1).contiguous().cuda()
+    pos = ops.posenc(intr, Z // 2, qkv.device)
+    F_ref, T_ref, U_ref, x_ref, _ = _emm_ref(qkv, pos, Z)
+    rlse, clse = ops.emm_stats(qkv, Z)
+    xa = ops.emm_build_x(qkv, pos, Z)
+    assert torch.equal(xa[..., :70].double(), x_ref.float().double()) and float(xa[..., 70:].abs().max()) == 0.0
+    t, fpart = ops.emm_apply(qkv, xa, rlse, clse, Z)
+    u, _ = ops.emm_apply(qkv, xa, rlse, clse, Z, swap=True, want_f=False)
+    F = fpart.double().sum(2)
+    e = dict(T=rel(t[..., :70], T_ref), U=rel(u[..., :70], U_ref), F=rel(F[..., :70, :70], F_ref))
+    report("emm_fwd", **e)
+    assert max(e.values()) < 1e-5
+    assert float(F[..., 70:, :].abs().max()) == 0.0 and float(F[..., :, 70:].abs().max()) == 0.0
+    g = ops.emm_finalize(fpart, Z)                     # [Z*70, 224]
+    g_ref = F_ref[[z ^ 1 for z in range(Z)]].reshape(Z, 210, 70).transpose(-1, -2)      # vision_transformer.py:229-230,238
+    assert rel(g.view(Z, 70, 224)[..., :210], g_ref) < 1e-5
+    assert float(g.view(Z, 70, 224)[..., 210:].abs().max()) == 0.0
+
+
+def test_emm_backward(ops):
+    Z = 2
+    qkv = rnd(Z * 576, 576, seed=5)
+    intr = torch.tensor([[30.0, 26.0, 12.0, 12.0]])[:, None, :].repeat(1, 2, 1).contiguous().cuda()
+    pos = ops.posenc(intr, 1, qkv.device)
+    dF = torch.zeros(Z, 3, 96, 96, device="cuda")
+    dF[..., :70, :70] = rnd(Z, 3, 70, 70, seed=6)
+    q64 = qkv.double().requires_grad_(True)
+    F_ref, _, _, _, _ = _emm_ref(q64, pos, Z)
+    (F_ref * dF[..., :70, :70].double()).sum().backward()
+    rlse, clse = ops.emm_stats(qkv, Z)
+    xa = ops.emm_build_x(qkv, pos, Z)
+    t, _ = ops.emm_apply(qkv, xa, rlse, clse, Z)
+    dqkv = ops.emm_backward(qkv, xa, t, rlse, clse, dF, Z)
+    e = [rel(dqkv[:, i * 192:(i + 1) * 192], q64.grad[:, i * 192:(i + 1) * 192]) for i in range(3)]
+    report("emm_bwd", dq=e[0], dk=e[1], dv=e[2])
+    assert max(e) < 5e-5

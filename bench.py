@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""bench.py -- rel_pose hot path on MI355X: image-pairs/sec, fwd+bwd, synthetic 384x384 pairs.
+
+    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Workload (BASELINE.json metric / configs[2] shape, "train.py ... batch 64, 1xMI355X fwd+bwd" on the synthetic
+inputs of configs[1]): one train.py step = ViTEss.forward on [64,2,3,384,384] pairs per GPU (CNN front-end on
+MIOpen, ViT + Essential Matrix Module + regressor on this repo's HIP kernels) + geodesic loss + backward +
+(N>1: DDP gradient all-reduce over RCCL) + grad-clip + Adam step.  Inputs are resident in HBM before the timed
+region.  One JSON line on rank 0; see DESIGN.md "Measurement" for how `roofline` and `cpu_baseline` are formed.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+FLOPS_FWD_PER_PAIR = 8588216320      # GEMM flops of the ViT+EMM+regressor hot path, forward
+METRIC = "image-pairs/sec fwd+bwd @384x384, 1/2/4/8 MI355X; R,t err vs ref"
+
+
+def model_args():
+    return types.SimpleNamespace(noess="", pool_size=60, fc_hidden_size=512, fusion_transformer=True,
+                                 transformer_depth=6, cross_features=False, use_single_softmax=False,
+                                 no_pos_encoding=False, l1_pos_encoding=False)
+
+
+def synthetic_batch(B, hw, device, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    images = torch.floor(torch.rand(B, 2, 3, hw, hw, generator=g) * 255.0)
+    q = torch.randn(B, 4, generator=g)
+    q = q / q.norm(dim=-1, keepdim=True)
+    q = q * torch.where(q[:, 3:] < 0, -1.0, 1.0)
+    t = torch.rand(B, 3, generator=g) * 2 - 1
+    poses = torch.zeros(B, 2, 7)
+    poses[:, :, 6] = 1.0
+    poses[:, 1] = torch.cat([t, q], dim=-1)
+    intr = torch.tensor([hw / 2.0] * 4).repeat(B, 2, 1)          # (fx,fy,cx,cy) = (192,...) at 384
+    return images.to(device), poses.to(device), intr.to(device)
+
+
+def cpu_baseline(hw, budget_s=20.0):
+    """The oracle (CPU restatement, kind 'port') timed on this box's host cores: fwd+bwd of the same step
+    (CNN + ViT/EMM incl. the reference's host positional-encoding loop + regressor + loss) on a bounded sample."""
+    from oracle import relpose_oracle as O
+    from rel_pose_amd.se3 import SE3
+    from rel_pose_amd.losses import geodesic_loss_tensors
+    ncpu = os.cpu_count() or 1
+    Bc = 4
+    shapes = dict(O.vit_param_shapes())
+    shapes.update(O.cnn_param_shapes())
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v)
+          for k, v in O.make_state(shapes).items()}
+    images, poses, intr = synthetic_batch(Bc, hw, "cpu", 1)
+
+    t_start = time.perf_counter()
+
+    def step():
+        i2 = intr.clone()
+        x = O.preprocess(images)
+        O.update_intrinsics(images.shape[-2:], i2)
+        tokens = O.tokens_from_cnn(O.cnn_features(sd, x, train=True))
+        pos = O.positional_encodings_loop(Bc, i2)                       # the reference's 576-iteration host loop
+        xx = tokens + sd["fusion_transformer.pos_embed"]
+        for l in range(5):
+            xx = O.block(sd, "fusion_transformer.blocks.%d." % l, xx)
+        xx = O.cross_block(sd, "fusion_transformer.blocks.5.", xx, i2, pos=pos)
+        feats = O.layernorm(xx, sd["fusion_transformer.norm.weight"], sd["fusion_transformer.norm.bias"])
+        Gs = SE3.IdentityLike(SE3(poses))
+        est = O.normalize_preds(Gs.data, O.regress(sd, feats, Bc))
+        ltr, lrot = geodesic_loss_tensors(SE3(poses), [SE3(est)])
+        (10 * ltr + 10 * lrot).backward()
+        for v in sd.values():
+            if v.is_floating_point() and v.grad is not None:
+                v.grad = None
+
+    # pick the thread count that is best FOR THE CPU (oversubscribing a 256-thread host makes the oracle's many
+    # small ops crawl): one timed step per candidate, then spend the budget on the winner
+    best = None
+    for th in sorted({min(ncpu, c) for c in (8, 16, 32, 64)}):
+        torch.set_num_threads(th)
+        step()
+        t0 = time.perf_counter()
+        step()
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[1]:
+            best = (th, dt)
+        if time.perf_counter() - t_start > 0.5 * budget_s:
+            break
+    cores = best[0]
+    torch.set_num_threads(cores)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        step()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > 0.5 * budget_s or n >= 50:
+            break
+    return {"value": round(Bc * n / el, 3), "unit": "image-pairs/sec", "cores": cores, "kind": "port",
+            "sample": "%d steps of %d synthetic %dx%d pairs, fwd+bwd (CNN + ViT/EMM incl. host pos-enc loop + loss), "
+                      "torch-CPU oracle, %d of %d host threads (best of 8/16/32/64), %.1f s"
+                      % (n, Bc, hw, hw, cores, ncpu, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="image pairs per GPU")
+    ap.add_argument("--hw", type=int, default=384)
+    ap.add_argument("--mode", default="train", choices=("train", "fwd"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scope", default="full", choices=("full", "hot"),
+                    help="full = images -> CNN -> hot path (the metric); hot = synthetic CNN maps -> hot path only "
+                         "(kernel profiling; not the headline number)")
+    ap.add_argument("--timer-instance", default="0,0,2,3", help="gemm_kernel<aL,bL,TM,TN> instance timed for `roofline`")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node N" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank)
+
+    from rel_pose_amd import _lib, ops
+    from rel_pose_amd.losses import geodesic_loss_tensors
+    from rel_pose_amd.model import ViTEss
+    from rel_pose_amd.se3 import SE3
+    _lib.load()
+
+    torch.manual_seed(0)
+    model = ViTEss(model_args()).to(dev)
+    for p in list(model.resnet.layer3.parameters()) + list(model.resnet.layer4.parameters()):
+        p.requires_grad = False                                        # reference train.py:60-64
+    train = args.mode == "train"
+    model.train(train)
+    net = model
+    if world > 1 and train:
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], find_unused_parameters=False)
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=5e-4, weight_decay=1e-5)
+    images, poses, intr = synthetic_batch(args.batch, args.hw, dev, 1234 + rank)
+    Ps = SE3(poses)
+    Gs = SE3.IdentityLike(Ps)
+
+    hot = args.scope == "hot"
+    if hot:
+        if world > 1:
+            raise SystemExit("--scope hot is a single-GPU profiling aid")
+        fmap = torch.rand(2 * args.batch, 192, 24, 24, device=dev)      # post-ReLU-like CNN map
+        i24 = (intr * (24.0 / args.hw)).contiguous()
+
+        def net(_images, Gs_, intrinsics=None):                          # noqa: F811
+            return [SE3(model.forward_tokens(fmap, Gs_.data, i24))]
+
+    def step():
+        if train:
+            opt.zero_grad(set_to_none=True)
+            est = net(images, Gs, intrinsics=intr.clone())
+            ltr, lrot = geodesic_loss_tensors(Ps, est)
+            loss = 10.0 * ltr + 10.0 * lrot
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 2.5)
+            opt.step()
+            return loss
+        with torch.no_grad():
+            return net(images, Gs, intrinsics=intr.clone())[0].data
+
+    timer = ops.KernelTimer([int(v) for v in args.timer_instance.split(",")])
+    ops.TIMER = timer
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = step()
+    fence()
+    el = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        tt = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    finite = bool(torch.isfinite(last).all())
+
+    if rank == 0:
+        n_launch, t_launch, flops = timer.summary()
+        achieved = flops / max(n_launch, 1) / max(t_launch, 1e-12) / 1e12
+        pairs = world * args.batch * args.steps
+        rec = {
+            "metric": METRIC, "value": round(pairs / el, 2), "unit": "image-pairs/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("train.py step (ViTEss fwd + geodesic loss + bwd + grad all-reduce + clip + Adam)"
+                                    if train else "ViTEss.forward, eval, no_grad") +
+                                   ", synthetic %dx%d pairs" % (args.hw, args.hw),
+                       "scope": args.scope, "pairs_per_gpu": args.batch, "global_batch_pairs": world * args.batch,
+                       "parallelism": "dp%d" % world, "finite": finite,
+                       "hot_path_share": "ViT+EMM+regressor on HIP kernels; ResNet front-end on MIOpen (SURVEY 8f-1)"},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "kernel": "gemm_kernel<%s>" % args.timer_instance, "launches_timed": n_launch,
+                         "avg_launch_us": round(t_launch * 1e6, 2),
+                         "flops_per_launch_avg": flops / max(n_launch, 1),
+                         "hot_path_tflops_whole_step": round((3 if train else 1) * FLOPS_FWD_PER_PAIR * pairs / el / 1e12, 2)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            rec["cpu_baseline"] = cpu_baseline(args.hw)
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -68,6 +68,7 @@ typedef struct RpGemm {
   int dact;
   const float* aux; /* ld = ldc */
   const float* residual; /* ld = ldc */
+  int trans_c; /* split_k > 1 only, no epilogue operands: store C^T, i.e. C[n*ldc + m] */
 } RpGemm;
 int rp_gemm(const RpGemm* g, void* stream);
 size_t rp_gemm_workspace_bytes(int M, int N, int split_k);

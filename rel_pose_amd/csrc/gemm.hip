@@ -13,8 +13,12 @@
 // conflict-free ds_read_b32 rows.
 #include "common.h"
 #include "../../include/relpose_hip.h"
+#include <stdlib.h>
 
 namespace {
+
+enum { EPI_RAW = 0, EPI_BIAS, EPI_BIAS_RES, EPI_RES, EPI_BIAS_GELU, EPI_BIAS_GELU_PRE, EPI_BIAS_RELU, EPI_DGELU,
+       EPI_DRELU, EPI_GENERIC };
 
 struct GemmP {
   const float* A;
@@ -30,6 +34,8 @@ struct GemmP {
   int act, dact;
   const float* aux;
   const float* residual;
+  int epi_mode;
+  int trans_c;
 };
 
 RP_DEV float epilogue(float v, int m, int n, const GemmP& p) {
@@ -58,8 +64,34 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
   const int wm0 = (wave >> 1) * 32 * TM, wn0 = (wave & 1) * 32 * TN;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int zb = blockIdx.z / p.split_k, zs = blockIdx.z % p.split_k;
+  // XCD-aware tile order (workgroup b runs on XCD b % 8, each XCD has a private L2): XCD x owns the row
+  // panels mt = x (mod 8) and walks all N tiles of one panel back to back, so an A panel is pulled from
+  // HBM/MALL into ONE L2 once and the weight panel stays L2-resident everywhere.
+  const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
+  int mt, nt;
+  int zid = blockIdx.z;
+  if (p.split_k > 1) {
+    // split-K launch (1-D grid over tiles x splits): split z runs on XCD z % 8 and walks all its tiles back to back,
+    // so the (M-tile, N-tile) workgroups that read the same K chunk of A and B hit the same L2.
+    const int T = ntm * ntn;
+    const int j = blockIdx.x >> 3;
+    zid = (blockIdx.x & 7) + 8 * (j / T);
+    if (zid >= p.split_k) return;
+    const int t = j % T;
+    mt = t / ntn;
+    nt = t % ntn;
+  } else if (ntm >= 16) {
+    const int xs = blockIdx.x >> 3;
+    mt = (xs / ntn) * 8 + (blockIdx.x & 7);
+    nt = xs % ntn;
+    if (mt >= ntm) return;
+  } else {                       // few row panels: plain order (the remap would park whole XCDs)
+    mt = blockIdx.x / ntn;
+    nt = blockIdx.x % ntn;
+  }
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int zb = p.split_k > 1 ? 0 : zid, zs = p.split_k > 1 ? zid : 0;
+
   const float* A = p.A + zb * p.sa;
   const float* B = p.B + zb * p.sb;
   const int kbeg = zs * p.k_per_split;
@@ -67,8 +99,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   const int nkt = (kend - kbeg + BK - 1) / BK;
 
   float4 ra[NA], rb[NB];
+  const bool mn_inside = (m0 + BM <= p.M) && (n0 + BN <= p.N);
   auto gload = [&](int kt) {
     const int k0 = kbeg + kt * BK;
+    if (mn_inside && k0 + BK <= kend) {      // wave-uniform fast path: no per-lane guards
+#pragma unroll
+      for (int j = 0; j < NA; ++j) {
+        const int f = tid + 256 * j;
+        if (ALAY == 0) ra[j] = ld4(A + (long long)(m0 + (f >> 3)) * p.lda + k0 + (f & 7) * 4);
+        else ra[j] = ld4(A + (long long)(k0 + f / (BM / 4)) * p.lda + m0 + (f % (BM / 4)) * 4);
+      }
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int f = tid + 256 * j;
+        if (BLAY == 0) rb[j] = ld4(B + (long long)(n0 + (f >> 3)) * p.ldb + k0 + (f & 7) * 4);
+        else rb[j] = ld4(B + (long long)(k0 + f / (BN / 4)) * p.ldb + n0 + (f % (BN / 4)) * 4);
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
       const int f = tid + 256 * j;
@@ -165,30 +213,49 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     }
   }
 
-  // ---- epilogue -------------------------------------------------------------------------------
+  // ---- epilogue: one wave-uniform switch, then straight-line code per element --------------------
   float* C = p.C + zb * p.sc;
   const bool partial = p.split_k > 1;
-  if (partial) C = p.C + (long long)blockIdx.z * p.M * p.N;   // workspace slab [z][M][N]
+  if (partial) C = p.C + (long long)zid * p.M * p.N;   // workspace slab [z][M][N]
   const int ldc = partial ? p.N : p.ldc;
-  GemmP q = p;   // batch offsets for the epilogue operands
-  q.pre_out = p.pre_out ? p.pre_out + zb * p.sc : nullptr;
-  q.aux = p.aux ? p.aux + zb * p.sc : nullptr;
-  q.residual = p.residual ? p.residual + zb * p.sc : nullptr;
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wn0 + 32 * j + l31;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm0 + 32 * i + acc_row(r, hi);
-        if (m < p.M && n < p.N) {
-          float v = acc[i][j][r];
-          if (!partial) v = epilogue(v, m, n, q);
-          C[(long long)m * ldc + n] = v;
-        }
-      }
+  const float* bias = p.bias;
+  float* pre_out = p.pre_out ? p.pre_out + zb * p.sc : nullptr;
+  const float* aux = p.aux ? p.aux + zb * p.sc : nullptr;
+  const float* res = p.residual ? p.residual + zb * p.sc : nullptr;
+  const int mode = partial ? EPI_RAW : p.epi_mode;
+  const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+
+#define RP_EPI_LOOP(BODY)                                                              \
+  _Pragma("unroll") for (int i = 0; i < TM; ++i)                                       \
+  _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                     \
+    const int n = n0 + wn0 + 32 * j + l31;                                             \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                   \
+      const int m = m0 + wm0 + 32 * i + acc_row(r, hi);                                \
+      if (interior || (m < p.M && n < p.N)) {                                          \
+        const long long off = (long long)m * ldc + n;                                  \
+        float v = acc[i][j][r];                                                        \
+        BODY;                                                                          \
+        C[off] = v;                                                                    \
+      }                                                                                \
+    }                                                                                  \
+  }
+  switch (mode) {
+    case EPI_RAW: RP_EPI_LOOP((void)0) break;
+    case EPI_BIAS: RP_EPI_LOOP(v += bias[n]) break;
+    case EPI_BIAS_RES: RP_EPI_LOOP(v += bias[n] + res[off]) break;
+    case EPI_RES: RP_EPI_LOOP(v += res[off]) break;
+    case EPI_BIAS_GELU: RP_EPI_LOOP(v = gelu_exact(v + bias[n])) break;
+    case EPI_BIAS_GELU_PRE: RP_EPI_LOOP(v += bias[n]; pre_out[off] = v; v = gelu_exact(v)) break;
+    case EPI_BIAS_RELU: RP_EPI_LOOP(v = fmaxf(v + bias[n], 0.f)) break;
+    case EPI_DGELU: RP_EPI_LOOP(v *= gelu_grad(aux[off])) break;
+    case EPI_DRELU: RP_EPI_LOOP(v = aux[off] > 0.f ? v : 0.f) break;
+    default: {
+      GemmP q = p;
+      q.pre_out = pre_out; q.aux = aux; q.residual = res;
+      RP_EPI_LOOP(v = epilogue(v, m, n, q))
     }
+  }
+#undef RP_EPI_LOOP
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, const float* ws) {
@@ -203,12 +270,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, const float
   const int m = (int)(idx / p.N), n = (int)(idx % p.N);   // N % 4 == 0: the float4 stays in one row
   float o[4] = {s.x, s.y, s.z, s.w};
 #pragma unroll
-  for (int e = 0; e < 4; ++e) p.C[(long long)m * p.ldc + n + e] = epilogue(o[e], m, n + e, p);
+  for (int e = 0; e < 4; ++e) {
+    const float v = epilogue(o[e], m, n + e, p);
+    if (p.trans_c) p.C[(long long)(n + e) * p.ldc + m] = v;
+    else p.C[(long long)m * p.ldc + n + e] = v;
+  }
 }
 
 template <int ALAY, int BLAY, int TM, int TN>
 int launch(const GemmP& p, int nz, hipStream_t st) {
-  dim3 grid((p.N + 64 * TN - 1) / (64 * TN), (p.M + 64 * TM - 1) / (64 * TM), nz);
+  const int ntn = (p.N + 64 * TN - 1) / (64 * TN), ntm = (p.M + 64 * TM - 1) / (64 * TM);
+  dim3 grid(ntm >= 16 ? ntn * ((ntm + 7) / 8) * 8 : ntn * ntm, 1, nz);
+  if (p.split_k > 1) grid = dim3(ntn * ntm * ((p.split_k + 7) / 8) * 8, 1, 1);
   hipLaunchKernelGGL((gemm_kernel<ALAY, BLAY, TM, TN>), grid, dim3(256), 0, st, p);
   return 0;
 }
@@ -255,8 +328,33 @@ extern "C" int rp_gemm(const RpGemm* g, void* stream) {
   const int ktiles = (g->K + 31) / 32;
   p.k_per_split = ((ktiles + split - 1) / split) * 32;
   p.bias = g->bias; p.pre_out = g->pre_out; p.act = g->act; p.dact = g->dact; p.aux = g->aux; p.residual = g->residual;
-  const int tm = g->M <= 64 ? 1 : 2;
-  const int tn = (g->N % 192 == 0) ? 3 : (g->N <= 64 ? 1 : 2);
+  {
+    const bool b = g->bias, pr = g->pre_out, rs = g->residual;
+    int m = EPI_GENERIC;
+    if (g->dact == 0) {
+      if (g->act == 0 && !pr) m = b ? (rs ? EPI_BIAS_RES : EPI_BIAS) : (rs ? EPI_RES : EPI_RAW);
+      else if (g->act == 1 && b && !rs) m = pr ? EPI_BIAS_GELU_PRE : EPI_BIAS_GELU;
+      else if (g->act == 2 && b && !rs && !pr) m = EPI_BIAS_RELU;
+    } else if (!b && !pr && !rs && g->act == 0 && g->aux) {
+      m = g->dact == 1 ? EPI_DGELU : EPI_DRELU;
+    }
+    p.epi_mode = m;
+  }
+  p.trans_c = g->trans_c;
+  if (g->trans_c && (split == 1 || g->bias || g->pre_out || g->aux || g->residual)) return RP_EUNSUPPORTED;
+  // tile shape (TM,TN) = wave tile in 32x32 units; measured on MI355X (tools/gemm_tiles.py): with fp32 MFMA (64
+  // cycles per 32x32x2) operand reuse is cheap and occupancy wins -- 128x64 / 64x192 tiles beat 128x192.
+  int tm = g->M <= 64 ? 1 : 2;
+  int tn = g->N <= 64 ? 1 : 2;
+  if (g->M > 64) {
+    const bool reads_mn = g->aux || g->residual;
+    if (g->a_layout == 0 && g->b_layout == 0) { tm = 2; tn = 1; }
+    else if (g->N % 192 == 0 && !reads_mn) { tm = 1; tn = 3; }
+    else { tm = 2; tn = 1; }
+  }
+  if (const char* ov = getenv("RP_GEMM_TILE")) {   // tuning aid only: "TM,TN"
+    if (ov[0] >= '1' && ov[0] <= '2' && ov[1] == ',' && ov[2] >= '1' && ov[2] <= '3') { tm = ov[0] - '0'; tn = ov[2] - '0'; }
+  }
   hipStream_t st = (hipStream_t)stream;
   const int nz = batch * split;
   if (g->a_layout == 0 && g->b_layout == 0) launch_tiles<0, 0>(p, nz, tm, tn, st);

@@ -106,15 +106,29 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   }
 }
 
-// column sums: block (bx, by): columns bx*256 + tid, rows [by*rpb, (by+1)*rpb)
+// column sums: block (bx, by) = 64 columns x 4 row lanes; rows [by*rpb, (by+1)*rpb); 4 independent loads in flight
+// per thread, 256-byte coalesced row segments; fixed summation order (deterministic).
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, int rows, int cols, int ld,
                                                      int rpb, float* __restrict__ out) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= cols) return;
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   const int r0 = blockIdx.y * rpb, r1 = min(rows, r0 + rpb);
-  float s = 0.f;
-  for (int r = r0; r < r1; ++r) s += in[(long long)r * ld + c];
-  out[(long long)blockIdx.y * cols + c] = s;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < cols) {
+    const float* base = in + c;
+    int r = r0 + rl;
+    for (; r + 12 < r1; r += 16) {
+      s0 += base[(long long)r * ld];
+      s1 += base[(long long)(r + 4) * ld];
+      s2 += base[(long long)(r + 8) * ld];
+      s3 += base[(long long)(r + 12) * ld];
+    }
+    for (; r < r1; r += 4) s0 += base[(long long)r * ld];
+  }
+  red[rl][cl] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (rl == 0 && c < cols) out[(long long)blockIdx.y * cols + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
 
 // x[z][n][c] = feat[z][c][n] + pe[n][c]   (32x32 LDS tile transpose)
@@ -341,7 +355,7 @@ extern "C" int rp_layernorm_bwd(const float* dy, const float* x, const float* ga
 
 static int colsum_stage1_rows(int rows) {
   int rpb = 256;
-  while ((rows + rpb - 1) / rpb > 512) rpb *= 2;
+  while ((rows + rpb - 1) / rpb > 1024) rpb *= 2;
   return rpb;
 }
 
@@ -357,7 +371,7 @@ extern "C" int rp_colsum(const float* in, int rows, int cols, int ld, float* out
   hipStream_t st = (hipStream_t)stream;
   const int rpb = colsum_stage1_rows(rows);
   const int nb = (rows + rpb - 1) / rpb;
-  const int gx = (cols + 255) / 256;
+  const int gx = (cols + 63) / 64;
   if (nb == 1) {
     hipLaunchKernelGGL(colsum_kernel, dim3(gx, 1), dim3(256), 0, st, in, rows, cols, ld, rpb, out);
     RP_CHECK_LAUNCH();

@@ -50,9 +50,19 @@ def _empty(*shape, like):
     return torch.empty(shape, device=like.device, dtype=torch.float32)
 
 
-def pick_split_k(M, N, K, target_wgs=512, min_ktiles=8):
-    tm = 1 if M <= 64 else 2
-    tn = 3 if N % 192 == 0 else (1 if N <= 64 else 2)
+def gemm_tile(M, N, a_layout, b_layout, reads_mn=False):
+    """(TM, TN) that rp_gemm picks (mirrors csrc/gemm.hip)."""
+    if M <= 64:
+        return 1, (1 if N <= 64 else 2)
+    if a_layout == 0 and b_layout == 0:
+        return 2, 1
+    if N % 192 == 0 and not reads_mn:
+        return 1, 3
+    return 2, 1
+
+
+def pick_split_k(M, N, K, a_layout=0, b_layout=0, target_wgs=288, min_ktiles=8):
+    tm, tn = gemm_tile(M, N, a_layout, b_layout)
     tiles = -(-M // (64 * tm)) * -(-N // (64 * tn))
     ktiles = -(-K // 32)
     if tiles >= 256 or ktiles < 2 * min_ktiles:
@@ -60,8 +70,36 @@ def pick_split_k(M, N, K, target_wgs=512, min_ktiles=8):
     return max(1, min(ktiles // min_ktiles, -(-target_wgs // tiles)))
 
 
+class KernelTimer:
+    """HIP-event timing of every launch of ONE gemm_kernel<a_layout,b_layout,TM,TN> instance on torch's current
+    stream (bench.py's `roofline` object).  Off unless bench.py installs one."""
+
+    def __init__(self, instance):
+        self.instance = tuple(instance)
+        self.events = []
+        self.flops = 0.0
+        self.enabled = False
+
+    def reset(self):
+        self.events, self.flops = [], 0.0
+
+    def summary(self):
+        """-> (launches, mean seconds per launch, total algorithmic flops); call after a device sync."""
+        n = len(self.events)
+        tot = sum(s.elapsed_time(e) for s, e in self.events) * 1e-3
+        return n, (tot / n if n else 0.0), self.flops
+
+
+TIMER = None
+
+
+def gemm_instance(M, N, a_layout, b_layout, reads_mn=False):
+    """(a_layout, b_layout, TM, TN) that rp_gemm dispatches to (mirrors the selection in csrc/gemm.hip)."""
+    return (a_layout, b_layout) + gemm_tile(M, N, a_layout, b_layout, reads_mn)
+
+
 def gemm(A, B, M, N, K, *, a_layout=0, b_layout=0, lda=None, ldb=None, out=None, ldc=None, bias=None, act=0,
-         pre_out=None, dact=0, aux=None, residual=None, split_k=None, batch=1, strides=(0, 0, 0)):
+         pre_out=None, dact=0, aux=None, residual=None, split_k=None, batch=1, strides=(0, 0, 0), trans_c=False):
     """C[M,N] = epilogue(op(A) op(B)); see RpGemm in include/relpose_hip.h."""
     lib = _lib.load()
     _chk(A, B, out, bias, pre_out, aux, residual)
@@ -74,7 +112,7 @@ def gemm(A, B, M, N, K, *, a_layout=0, b_layout=0, lda=None, ldb=None, out=None,
     if ldc is None:
         ldc = N
     if split_k is None:
-        split_k = pick_split_k(M, N, K) if batch == 1 and N % 4 == 0 else 1
+        split_k = pick_split_k(M, N, K, a_layout, b_layout) if batch == 1 and N % 4 == 0 else 1
     g = _lib.RpGemm()
     g.A, g.B, g.C = A.data_ptr(), B.data_ptr(), out.data_ptr()
     g.M, g.N, g.K = M, N, K
@@ -92,6 +130,17 @@ def gemm(A, B, M, N, K, *, a_layout=0, b_layout=0, lda=None, ldb=None, out=None,
     g.act, g.dact = act, dact
     g.aux = None if aux is None else aux.data_ptr()
     g.residual = None if residual is None else residual.data_ptr()
+    g.trans_c = 1 if trans_c else 0
+    tm = TIMER
+    if (tm is not None and tm.enabled and split_k == 1 and
+            gemm_instance(M, N, a_layout, b_layout, aux is not None or residual is not None) == tm.instance):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(lib.rp_gemm(ctypes.byref(g), _st()), "rp_gemm")
+        e1.record()
+        tm.events.append((e0, e1))
+        tm.flops += 2.0 * M * N * K * batch
+        return out
     _lib.check(lib.rp_gemm(ctypes.byref(g), _st()), "rp_gemm")
     return out
 
@@ -116,6 +165,12 @@ def linear_dw(dy, x):
     """dW = dy^T x; dy [M,N], x [M,K] -> [N,K]  (reduction over the M token rows, split-K)."""
     M, N = dy.shape
     K = x.shape[1]
+    if K > N and M >= 4096:
+        # wide-K' weight (fc2: [192,768]): contract as (x^T dy) so the long extent is the row-panel dimension, and let
+        # the split-K reduce write the transpose
+        sk = max(2, pick_split_k(K, N, M, 1, 1))
+        out = _empty(N, K, like=dy)
+        return gemm(x, dy, K, N, M, a_layout=1, b_layout=1, out=out, ldc=K, split_k=sk, trans_c=True)
     return gemm(dy, x, N, K, M, a_layout=1, b_layout=1)
 
 

@@ -1,0 +1,55 @@
+"""Batch-of-pairs data parallelism (the only parallelism in rel_pose: reference train.py:28-36,66-67,128-130).
+
+One process per GPU; pairs are independent units, so the forward needs no collective and the backward needs exactly one
+exchange: the gradient all-reduce(mean) of the 19.26 M trainable fp32 values (77 MB), issued by
+torch.nn.parallel.DistributedDataParallel in buckets that overlap the backward.  Backend "nccl" is RCCL on ROCm
+(xGMI between the 8 GPUs of a node); "gloo" is used for the CPU tests.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def setup(rank, world_size, backend=None, master_addr="127.0.0.1", master_port="12356"):
+    os.environ.setdefault("MASTER_ADDR", master_addr)
+    os.environ.setdefault("MASTER_PORT", str(master_port))
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    dist.init_process_group(backend=backend, init_method="env://", world_size=world_size, rank=rank)
+    torch.manual_seed(0)                                            # reference train.py:35
+    if backend == "nccl":
+        torch.cuda.set_device(rank % torch.cuda.device_count())
+    return backend
+
+
+def shard_pairs(num_pairs, rank, world_size):
+    """Indices of the pairs rank `rank` owns: r, r+W, r+2W, ... (what DistributedSampler(shuffle=False) yields;
+    the tail is padded by wrapping so every rank gets the same count, as DistributedSampler does)."""
+    per = -(-num_pairs // world_size)
+    idx = [(rank + i * world_size) % num_pairs for i in range(per)]
+    return idx
+
+
+def wrap(model, device_ids=None):
+    """DDP with the reference's settings (train.py:66-67)."""
+    return torch.nn.parallel.DistributedDataParallel(model, device_ids=device_ids, find_unused_parameters=False)
+
+
+def allreduce_mean_(tensors):
+    """Explicit bucketed mean all-reduce (used when DDP is bypassed, e.g. under graph capture)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    flat = torch.cat([t.reshape(-1) for t in tensors])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat /= dist.get_world_size()
+    o = 0
+    for t in tensors:
+        n = t.numel()
+        t.copy_(flat[o:o + n].view_as(t))
+        o += n
+
+
+def cleanup():
+    if dist.is_initialized():
+        dist.destroy_process_group()

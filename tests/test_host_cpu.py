@@ -1,0 +1,144 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol include/relpose_hip.h declares (no compute),
+host-side logic (module tree / state_dict contract, tile + split-K selection, SE3 algebra, loss), and that the
+product path fails loudly without a GPU."""
+import ctypes
+import json
+import os
+import re
+import types
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def make_args(**kw):
+    a = types.SimpleNamespace(noess="", pool_size=60, fc_hidden_size=512, fusion_transformer=True, transformer_depth=6,
+                              cross_features=False, use_single_softmax=False, no_pos_encoding=False,
+                              l1_pos_encoding=False)
+    a.__dict__.update(kw)
+    return a
+
+
+def test_library_exports_every_declared_symbol():
+    from rel_pose_amd import _lib
+    header = open(os.path.join(ROOT, "include", "relpose_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(rp_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 20
+    lib = ctypes.CDLL(_lib.lib_path())
+    for sym in declared:
+        assert hasattr(lib, sym), "missing export: " + sym
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    typed = _lib.load()
+    assert typed.rp_abi_version() == 1 and typed.rp_target_arch() == b"gfx950"
+    assert typed.rp_gemm_workspace_bytes(576, 192, 103) == 103 * 576 * 192 * 4
+    assert typed.rp_layernorm_bwd_blocks(73728) == 1152
+
+
+def test_state_dict_contract_and_dropin_alias():
+    from rel_pose_amd.model import ViTEss
+    from src.model import ViTEss as Alias
+    assert Alias is ViTEss
+    m = ViTEss(make_args())
+    with open(os.path.join(ROOT, "tests", "golden", "state_dict_keys.json")) as f:
+        ref = json.load(f)
+    sd = m.state_dict()
+    assert set(sd) == set(ref) and all(list(sd[k].shape) == ref[k] for k in ref)
+    assert sd["extractor_final_conv.downsample.1.weight"].data_ptr() == sd["extractor_final_conv.norm3.weight"].data_ptr()
+    assert sum(p.numel() for p in m.parameters()) == 29751950
+    frozen = list(m.resnet.layer3.parameters()) + list(m.resnet.layer4.parameters())       # train.py:60-64
+    trainable = sum(p.numel() for p in m.parameters()) - sum(p.numel() for p in frozen)
+    assert trainable == 19258510                                                           # 77.0 MB all-reduce
+    # checkpoints saved under DDP carry a "module." prefix (train.py:191-194, demo.py:60-61)
+    m2 = ViTEss(make_args())
+    m2.load_state_dict({k.replace("module.", ""): v for k, v in {"module." + k: v for k, v in sd.items()}.items()})
+
+
+def test_unsupported_variants_are_rejected_loudly():
+    from rel_pose_amd.model import ViTEss
+    for kw in (dict(noess="1"), dict(cross_features=True), dict(use_single_softmax=True), dict(no_pos_encoding=True),
+               dict(l1_pos_encoding=True), dict(fusion_transformer=False)):
+        with pytest.raises(NotImplementedError):
+            ViTEss(make_args(**kw))
+
+
+def test_no_cpu_fallback():
+    from rel_pose_amd import ops
+    from rel_pose_amd.model import ViTEss
+    with pytest.raises(RuntimeError):
+        ops.linear(torch.zeros(8, 192), torch.zeros(192, 192))
+    if not torch.cuda.is_available():
+        m = ViTEss(make_args()).eval()
+        with pytest.raises(RuntimeError):
+            m.forward_tokens(torch.zeros(2, 192, 24, 24), torch.zeros(1, 2, 7), None)
+
+
+def test_update_intrinsics_mutates_caller_tensor():
+    from rel_pose_amd.model import ViTEss
+    m = ViTEss(make_args())
+    intr = torch.tensor([[[517.97, 517.97, 320.0, 240.0]] * 2])
+    out = m.update_intrinsics((1, 2, 3, 384, 512), intr)
+    assert out is intr
+    assert torch.allclose(intr[0, 0], torch.tensor([517.97 * 24 / 512, 517.97 * 24 / 384, 15.0, 15.0]))
+
+
+def test_gemm_tile_and_splitk_selection():
+    from rel_pose_amd import ops
+    assert ops.gemm_instance(73728, 576, 0, 0) == (0, 0, 2, 1)
+    assert ops.gemm_instance(73728, 768, 0, 1) == (0, 1, 1, 3)
+    assert ops.gemm_instance(73728, 768, 0, 1, reads_mn=True) == (0, 1, 2, 1)
+    assert ops.gemm_instance(64, 512, 0, 0) == (0, 0, 1, 2)
+    assert ops.pick_split_k(73728, 768, 192) == 1               # plenty of tiles
+    sk = ops.pick_split_k(576, 192, 73728, 1, 1)                # weight gradient: 9 tiles, 2304 k-tiles
+    assert 16 <= sk <= 64
+    assert ops.pick_split_k(64, 512, 26880) > 32                # regressor layer 0 at batch 64
+    assert ops.pick_split_k(64, 26880, 512) <= 2
+
+
+def test_se3_algebra_and_loss():
+    from scipy.spatial.transform import Rotation as R
+    from rel_pose_amd.se3 import SE3
+    from rel_pose_amd.losses import geodesic_loss
+    rng = np.random.default_rng(0)
+    q = R.random(6, random_state=1)
+    t = rng.normal(size=(6, 3))
+    G = SE3(torch.tensor(np.concatenate([t, q.as_quat()], -1)).view(3, 2, 7))
+    I = (G * G.inv()).data
+    assert torch.allclose(I[..., :3], torch.zeros(3, 2, 3, dtype=I.dtype), atol=1e-12)
+    assert torch.allclose(I[..., 3:].abs(), torch.tensor([0, 0, 0, 1.0], dtype=I.dtype).expand(3, 2, 4), atol=1e-12)
+    # composition matches 4x4 matrices
+    def mat(d):
+        M = np.tile(np.eye(4), (d.shape[0], 1, 1))
+        M[:, :3, :3] = R.from_quat(d[:, 3:]).as_matrix()
+        M[:, :3, 3] = d[:, :3]
+        return M
+    a, b = G.data[:, 0].numpy(), G.data[:, 1].numpy()
+    ab = (G[:, 0] * G[:, 1]).data.numpy()
+    assert np.allclose(mat(ab), mat(a) @ mat(b), atol=1e-12)
+    # log: rotation part = rotation vector, translation part = V^-1 t (check via scipy matrix log)
+    from scipy.linalg import logm
+    lg = G[:, 0].log().numpy()
+    for i in range(3):
+        L = np.real(logm(mat(a[i:i + 1])[0]))
+        assert np.allclose(lg[i, 3:], [L[2, 1], L[0, 2], L[1, 0]], atol=1e-9)
+        assert np.allclose(lg[i, :3], L[:3, 3], atol=1e-9)
+    # loss is zero at the ground truth and differentiable
+    Ps = SE3(G.data.float())
+    est = G.data.float().clone().requires_grad_(True)
+    ltr, lrot, metrics = geodesic_loss(Ps, [SE3(est)])
+    assert float(ltr) < 1e-5 and float(lrot) < 1e-3 and set(metrics) == {"train_geo_loss_tr", "train_geo_loss_rot"}
+    est2 = (G.data.float() + 0.1).requires_grad_(True)
+    ltr, lrot, _ = geodesic_loss(Ps, [SE3(est2)])
+    (ltr + lrot).backward()
+    assert torch.isfinite(est2.grad).all() and float(ltr) > 0
+
+
+def test_identity_like_and_indexing():
+    from rel_pose_amd.se3 import SE3
+    P = SE3(torch.randn(4, 2, 7))
+    I = SE3.IdentityLike(P)
+    assert I.data.shape == (4, 2, 7) and torch.equal(I.data[..., 6], torch.ones(4, 2)) and float(I.data[..., :6].abs().sum()) == 0
+    assert I[:, :1].data.shape == (4, 1, 7) and I[0][1].data.shape == (7,)

@@ -16,6 +16,7 @@
 // fp32 v_mfma_f32_32x32x2_f32 throughout: 64 MFMAs (4096 cycles) per 32x32 tile pair, exact fp32 products.
 #include "common.h"
 #include "../../include/relpose_hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -92,8 +93,8 @@ RP_DEV void load_owner(const float* row_ptr, int hi, float mul, float (&reg)[32]
   }
 }
 
-template <int NW, bool STATS>
-__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnP p) {
+template <int NW, bool STATS, int WPS>
+__global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_kernel(AttnP p) {
   constexpr int NT = NW * 64;
   constexpr int NPF = (512 + NT - 1) / NT;
   __shared__ __attribute__((aligned(16))) float Ks[2][32 * KST];
@@ -176,8 +177,8 @@ struct AttnBwdP {
   float scale;
 };
 
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void attn_bwd_dkdv_kernel(AttnBwdP p) {
+template <int NW, int WPS>
+__global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dkdv_kernel(AttnBwdP p) {
   constexpr int NT = NW * 64;
   constexpr int NPF = (512 + NT - 1) / NT;
   __shared__ __attribute__((aligned(16))) float Qs[2][32 * KST];
@@ -235,8 +236,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkdv_kernel(AttnBwdP p) {
   store_ownerT(p.dk + ((long long)z * NTOK + k0 + l31) * p.lddk + h * 64, hi, dk0, dk1, p.scale);
 }
 
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnBwdP p) {
+template <int NW, int WPS>
+__global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dq_kernel(AttnBwdP p) {
   constexpr int NT = NW * 64;
   constexpr int NPF = (512 + NT - 1) / NT;
   __shared__ __attribute__((aligned(16))) float Ks[2][32 * KST];
@@ -292,8 +293,11 @@ extern "C" int rp_attn_fwd(const float* q, const float* k, const float* v, float
   AttnP p{q, k, v, o, lse, H, ldq, ldk, ldv, ldo, q_xor, k_xor, scale};
   constexpr int NW = 3;
   dim3 grid(NTILE / NW, H, Z);
-  if (stats_only) hipLaunchKernelGGL((attn_fwd_kernel<NW, true>), grid, dim3(NW * 64), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL((attn_fwd_kernel<NW, false>), grid, dim3(NW * 64), 0, (hipStream_t)stream, p);
+  const char* ov = getenv("RP_ATTN_WPS");   // tuning aid: "f,k,q" waves/SIMD bounds
+  const int wf = ov ? ov[0] - '0' : 2;
+  if (stats_only) hipLaunchKernelGGL((attn_fwd_kernel<NW, true, 2>), grid, dim3(NW * 64), 0, (hipStream_t)stream, p);
+  else if (wf == 3) hipLaunchKernelGGL((attn_fwd_kernel<NW, false, 3>), grid, dim3(NW * 64), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((attn_fwd_kernel<NW, false, 2>), grid, dim3(NW * 64), 0, (hipStream_t)stream, p);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }
@@ -306,9 +310,13 @@ extern "C" int rp_attn_bwd(const float* q, const float* k, const float* v, const
   AttnBwdP p{q, k, v, dout, lse, delta, dq, dk, dv, H, ldq, ldk, ldv, lddo, lddq, lddk, lddv, scale};
   constexpr int NW = 3;
   dim3 grid(NTILE / NW, H, Z);
-  hipLaunchKernelGGL((attn_bwd_dkdv_kernel<NW>), grid, dim3(NW * 64), 0, (hipStream_t)stream, p);
+  const char* ov = getenv("RP_ATTN_WPS");
+  const int wk = ov ? ov[2] - '0' : 2, wq = ov ? ov[4] - '0' : 2;
+  if (wk == 2) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<NW, 2>), grid, dim3(NW * 64), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((attn_bwd_dkdv_kernel<NW, 1>), grid, dim3(NW * 64), 0, (hipStream_t)stream, p);
   RP_CHECK_LAUNCH();
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<NW>), grid, dim3(NW * 64), 0, (hipStream_t)stream, p);
+  if (wq == 3) hipLaunchKernelGGL((attn_bwd_dq_kernel<NW, 3>), grid, dim3(NW * 64), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((attn_bwd_dq_kernel<NW, 2>), grid, dim3(NW * 64), 0, (hipStream_t)stream, p);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }

@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""train.py -- MI355X counterpart of the reference's trainer (reference train.py:28-212), same CLI flags.
+
+One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI), batch-of-pairs data parallel through
+DistributedDataParallel: the only exchange per step is the gradient all-reduce.  The model is the drop-in ViTEss of
+rel_pose_amd (HIP hot path).  Datasets (Matterport / InteriorNet / StreetLearn readers, reference
+src/data_readers/*) are out of scope: `--dataset synthetic` (default here) streams
+seeded random pairs of the real tensor shapes so the whole loop -- forward, geodesic loss, backward, clip, Adam,
+OneCycle schedule, checkpoint save / auto-resume with the reference's file layout and keys -- runs anywhere.
+
+    python train.py --name run0 --gpus 1 --batch 64 --steps 100 --fusion_transformer          # single GPU
+    python -m torch.distributed.run --nproc-per-node 8 train.py --name run0 --gpus 8 ...       # one rank per GPU
+"""
+import argparse
+import os
+import time
+from collections import OrderedDict
+from datetime import datetime
+
+import torch
+import torch.distributed as dist
+
+from rel_pose_amd import parallel
+from rel_pose_amd.losses import geodesic_loss
+from rel_pose_amd.model import ViTEss
+from rel_pose_amd.se3 import SE3
+
+
+class SyntheticPairs(torch.utils.data.Dataset):
+    """(images [2,3,H,W] BGR 0..255, poses [2,7], intrinsics [2,4]) like RGBDDataset.__getitem__
+    (reference src/data_readers/base.py:45-97; pose convention of matterport.py:44-54)."""
+
+    def __init__(self, n, hw=(384, 512), seed=0):
+        self.n, self.hw, self.seed = n, hw, seed
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        g = torch.Generator().manual_seed(self.seed * 1000003 + i)
+        H, W = self.hw
+        images = torch.floor(torch.rand(2, 3, H, W, generator=g) * 255.0)
+        q = torch.randn(4, generator=g)
+        q = q / q.norm()
+        if q[3] < 0:
+            q = -q
+        poses = torch.zeros(2, 7)
+        poses[:, 6] = 1.0
+        poses[1] = torch.cat([torch.rand(3, generator=g) * 2 - 1, q])
+        intr = torch.tensor([[517.97, 517.97, 320.0, 240.0]] * 2) * torch.tensor([W / 640.0, H / 480.0, W / 640.0, H / 480.0])
+        return images, poses, intr
+
+
+def find_resume(name):
+    """Auto-resume rule of the reference (train.py:255-275)."""
+    d = "output/%s/checkpoints" % name
+    if not os.path.isdir(d):
+        return None
+    ck = [f for f in os.listdir(d) if f.endswith(".pth")]
+    if not ck:
+        return None
+    if "most_recent_ckpt.pth" in ck:
+        return os.path.join(d, "most_recent_ckpt.pth")
+    return os.path.join(d, "%06d.pth" % max(int(f[:-4]) for f in ck))
+
+
+def run(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    ddp = world > 1 and not args.no_ddp
+    if ddp:
+        parallel.setup(rank, world, backend="nccl")
+    torch.manual_seed(0)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    model = ViTEss(args).to(dev).train()
+    for p in list(model.resnet.layer3.parameters()) + list(model.resnet.layer4.parameters()):
+        p.requires_grad = False
+    net = parallel.wrap(model, [local]) if ddp else model
+    opt = torch.optim.Adam(net.parameters(), lr=args.lr, weight_decay=args.weight_decay)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, args.lr, args.steps, pct_start=min(0.99, args.warmup / args.steps),
+                                                div_factor=25, cycle_momentum=False)
+    resume = args.ckpt or find_resume(args.name)
+    if resume:
+        ck = torch.load(resume, map_location=dev)
+        sd = ck["model"]
+        if not ddp:
+            sd = OrderedDict((k.replace("module.", ""), v) for k, v in sd.items())
+        net.load_state_dict(sd, strict=not args.ckpt)
+        opt.load_state_dict(ck["optimizer"])
+        if "scheduler" in ck and not args.ckpt:
+            sched.load_state_dict(ck["scheduler"])
+        if rank == 0:
+            print("resumed from", resume)
+
+    if args.dataset != "synthetic":
+        raise SystemExit("dataset readers are out of scope here (no datasets in this environment): use --dataset synthetic")
+    db = SyntheticPairs(args.batch * world * 50, tuple(args.image_size))
+    sampler = torch.utils.data.distributed.DistributedSampler(db, num_replicas=world, rank=rank, shuffle=True) if ddp else None
+    loader = torch.utils.data.DataLoader(db, batch_size=args.batch, sampler=sampler, shuffle=sampler is None,
+                                         num_workers=args.num_workers, pin_memory=True, drop_last=True)
+    os.makedirs("output/%s/checkpoints" % args.name, exist_ok=True)
+    step, t0 = 0, time.time()
+    while step < args.steps:
+        if sampler is not None:
+            sampler.set_epoch(step)
+        for images, poses, intr in loader:
+            images, poses, intr = images.to(dev, non_blocking=True), poses.to(dev), intr.to(dev)
+            Ps = SE3(poses)
+            Gs = SE3.IdentityLike(Ps)
+            opt.zero_grad(set_to_none=True)
+            est = net(images, Gs, intrinsics=intr)
+            ltr, lrot, metrics = geodesic_loss(Ps, est)
+            (args.w_tr * ltr + args.w_rot * lrot).backward()
+            torch.nn.utils.clip_grad_norm_(net.parameters(), args.clip)
+            opt.step()
+            sched.step()
+            step += 1
+            if rank == 0 and step % 20 == 0:
+                print("step %6d  %s  %.1f pairs/s" % (step, metrics, step * args.batch * world / (time.time() - t0)), flush=True)
+            if rank == 0 and (step % 10000 == 0 or step >= args.steps):
+                torch.save({"model": net.state_dict(), "optimizer": opt.state_dict(), "scheduler": sched.state_dict()},
+                           "output/%s/checkpoints/%06d.pth" % (args.name, step))
+            if step >= args.steps:
+                break
+    if rank == 0:
+        print("finished training!")
+    if ddp:
+        parallel.cleanup()
+
+
+def parser():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--w_tr", type=float, default=10.0)
+    ap.add_argument("--w_rot", type=float, default=10.0)
+    ap.add_argument("--warmup", type=int, default=10000)
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=120000)
+    ap.add_argument("--lr", type=float, default=5e-4)
+    ap.add_argument("--clip", type=float, default=2.5)
+    ap.add_argument("--weight_decay", type=float, default=1e-5)
+    ap.add_argument("--num_workers", type=int, default=4)
+    ap.add_argument("--no_ddp", action="store_true", default=False)
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--ckpt", help="checkpoint to restore")
+    ap.add_argument("--name", default="bla")
+    ap.add_argument("--datapath")
+    ap.add_argument("--image_size", default=[384, 512], nargs=2, type=int)
+    ap.add_argument("--exp")
+    ap.add_argument("--use_mini_dataset", action="store_true")
+    ap.add_argument("--streetlearn_interiornet_type", default="", choices=("", "T"))
+    ap.add_argument("--dataset", default="synthetic", choices=("synthetic", "matterport", "interiornet", "streetlearn"))
+    for flag in ("no_pos_encoding", "noess", "cross_features", "use_single_softmax", "l1_pos_encoding", "fusion_transformer"):
+        ap.add_argument("--" + flag, action="store_true")
+    ap.add_argument("--fc_hidden_size", type=int, default=512)
+    ap.add_argument("--pool_size", type=int, default=60)
+    ap.add_argument("--transformer_depth", type=int, default=6)
+    return ap
+
+
+if __name__ == "__main__":
+    a = parser().parse_args()
+    a.noess = "1" if a.noess else ""
+    os.makedirs("output/%s" % a.name, exist_ok=True)
+    with open("output/%s/args_%s.txt" % (a.name, datetime.now().strftime("%Y-%m-%d_%H-%M")), "w") as f:
+        for k, v in vars(a).items():
+            f.write("%s  %s\n" % (k, v))
+    run(a)

@@ -190,7 +190,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    roctx = None
+    if os.environ.get("RP_ROCTX"):       # rocprofv3 --selected-regions: profile only the timed steps
+        import ctypes
+        roctx = ctypes.CDLL("librocprofiler-sdk-roctx.so")
     fence()
+    if roctx is not None:
+        roctx.roctxProfilerResume(0)
     timer.enabled = True
     t0 = time.perf_counter()
     last = None
@@ -198,6 +204,8 @@ def main():
         last = step()
     fence()
     el = time.perf_counter() - t0
+    if roctx is not None:
+        roctx.roctxProfilerPause(0)
     timer.enabled = False
     if world > 1:
         tt = torch.tensor([el], device=dev, dtype=torch.float64)

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_kernel(AttnP p) {
   const float* vb = STATS ? nullptr : p.v + (long long)z * NTOK * p.ldv + h * 64;
 
   float qreg[32];
-  load_owner(qb + (long long)(q0 + l31) * p.ldq, hi, p.scale, qreg);
+  load_owner(qb + (long long)(q0 + l31) * p.ldq, hi, p.scale * RP_LOG2E, qreg);   // scores in log2 units
 
   f32x16 o0 = zero16(), o1 = zero16();
   float m = -INFINITY, l = 0.f;
@@ -131,12 +131,12 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_kernel(AttnP p) {
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float mn = fmaxf(m, mx);
-    const float alpha = expf(m - mn);
+    const float alpha = fast_exp2(m - mn);
     m = mn;
     float ps = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      s[r] = expf(s[r] - mn);
+      s[r] = fast_exp2(s[r] - mn);
       ps += s[r];
     }
     l = l * alpha + ps;
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_kernel(AttnP p) {
   }
   const float lt = l + __shfl_xor(l, 32, 64);
   if (!STATS) store_ownerT(p.o + ((long long)z * NTOK + q0 + l31) * p.ldo + h * 64, hi, o0, o1, 1.0f / lt);
-  if (hi == 0) p.lse[((long long)z * p.H + h) * NTOK + q0 + l31] = m + logf(lt);
+  if (hi == 0) p.lse[((long long)z * p.H + h) * NTOK + q0 + l31] = m * RP_LN2 + logf(lt);   // natural-log lse
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dkdv_kernel(AttnBwdP p)
   const float* delb = p.delta + ((long long)z * p.H + h) * NTOK;
 
   float kreg[32], vreg[32];
-  load_owner(p.k + ((long long)z * NTOK + k0 + l31) * p.ldk + h * 64, hi, p.scale, kreg);   // scale folded into K here
+  load_owner(p.k + ((long long)z * NTOK + k0 + l31) * p.ldk + h * 64, hi, p.scale * RP_LOG2E, kreg);   // scale*log2e folded into K
   load_owner(p.v + ((long long)z * NTOK + k0 + l31) * p.ldv + h * 64, hi, 1.0f, vreg);
 
   f32x16 dv0 = zero16(), dv1 = zero16(), dk0 = zero16(), dk1 = zero16();
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dkdv_kernel(AttnBwdP p)
   float lpre = 0.f;
   tile_gload<NT>(qb, p.ldq, tid, qpre);
   tile_gload<NT>(dob, p.lddo, tid, dpre);
-  if (tid < 64) lpre = tid < 32 ? lseb[tid] : delb[tid - 32];
+  if (tid < 64) lpre = tid < 32 ? lseb[tid] * RP_LOG2E : delb[tid - 32];
   tile_sstore<NT, KST>(Qs[0], tid, qpre);
   tile_sstore<NT, KST>(Ds[0], tid, dpre);
   if (tid < 64) Ls[0][tid] = lpre;
@@ -212,14 +212,14 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dkdv_kernel(AttnBwdP p)
     if (t + 1 < NTILE) {
       tile_gload<NT>(qb + (long long)(t + 1) * 32 * p.ldq, p.ldq, tid, qpre);
       tile_gload<NT>(dob + (long long)(t + 1) * 32 * p.lddo, p.lddo, tid, dpre);
-      if (tid < 64) lpre = tid < 32 ? lseb[(t + 1) * 32 + tid] : delb[(t + 1) * 32 + tid - 32];
+      if (tid < 64) lpre = tid < 32 ? lseb[(t + 1) * 32 + tid] * RP_LOG2E : delb[(t + 1) * 32 + tid - 32];
     }
     f32x16 s = score_tile(Qs[cur], l31, hi, kreg);     // rows = queries acc_row(r,hi), lane = key
     f32x16 dp = score_tile(Ds[cur], l31, hi, vreg);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int qi = acc_row(r, hi);
-      const float pr = expf(s[r] - Ls[cur][qi]);
+      const float pr = fast_exp2(s[r] - Ls[cur][qi]);
       s[r] = pr;
       dp[r] = pr * (dp[r] - Ls[cur][32 + qi]);
     }
@@ -249,9 +249,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dq_kernel(AttnBwdP p) {
   const float* vb = p.v + (long long)z * NTOK * p.ldv + h * 64;
 
   float qreg[32], dreg[32];
-  load_owner(p.q + ((long long)z * NTOK + q0 + l31) * p.ldq + h * 64, hi, p.scale, qreg);
+  load_owner(p.q + ((long long)z * NTOK + q0 + l31) * p.ldq + h * 64, hi, p.scale * RP_LOG2E, qreg);
   load_owner(p.dout + ((long long)z * NTOK + q0 + l31) * p.lddo + h * 64, hi, 1.0f, dreg);
-  const float lse = p.lse[((long long)z * p.H + h) * NTOK + q0 + l31];
+  const float lse = p.lse[((long long)z * p.H + h) * NTOK + q0 + l31] * RP_LOG2E;
   const float del = p.delta[((long long)z * p.H + h) * NTOK + q0 + l31];
 
   f32x16 dq0 = zero16(), dq1 = zero16();
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dq_kernel(AttnBwdP p) {
     f32x16 s = score_tile(Ks[cur], l31, hi, qreg);     // S^T: rows = keys, lane = query
     f32x16 dp = score_tile(Vs[cur], l31, hi, dreg);    // dP^T
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dp[r] = expf(s[r] - lse) * (dp[r] - del);
+    for (int r = 0; r < 16; ++r) dp[r] = fast_exp2(s[r] - lse) * (dp[r] - del);
     accum_tile<KST>(Ks[cur], l31, hi, dp, dq0, dq1);    // dQ^T += K^T dS^T
     if (t + 1 < NTILE) {
       tile_sstore<NT, KST>(Ks[cur ^ 1], tid, kpre);
@@ -302,21 +302,24 @@ extern "C" int rp_attn_fwd(const float* q, const float* k, const float* v, float
   return RP_OK;
 }
 
+template <int NW>
+static int launch_bwd(const AttnBwdP& p, int Z, int H, hipStream_t st) {
+  dim3 grid(NTILE / NW, H, Z);
+  hipLaunchKernelGGL((attn_bwd_dkdv_kernel<NW, 2>), grid, dim3(NW * 64), 0, st, p);
+  RP_CHECK_LAUNCH();
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<NW, 2>), grid, dim3(NW * 64), 0, st, p);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
 extern "C" int rp_attn_bwd(const float* q, const float* k, const float* v, const float* dout, const float* lse,
                            const float* delta, float* dq, float* dk, float* dv, int Z, int H, int ldq, int ldk, int ldv,
                            int lddo, int lddq, int lddk, int lddv, float scale, void* stream) {
   if (Z <= 0 || H <= 0) return RP_EBADSHAPE;
   if ((ldq | ldk | ldv | lddo | lddq | lddk | lddv) & 3) return RP_EALIGN;
   AttnBwdP p{q, k, v, dout, lse, delta, dq, dk, dv, H, ldq, ldk, ldv, lddo, lddq, lddk, lddv, scale};
-  constexpr int NW = 3;
-  dim3 grid(NTILE / NW, H, Z);
-  const char* ov = getenv("RP_ATTN_WPS");
-  const int wk = ov ? ov[2] - '0' : 2, wq = ov ? ov[4] - '0' : 2;
-  if (wk == 2) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<NW, 2>), grid, dim3(NW * 64), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL((attn_bwd_dkdv_kernel<NW, 1>), grid, dim3(NW * 64), 0, (hipStream_t)stream, p);
-  RP_CHECK_LAUNCH();
-  if (wq == 3) hipLaunchKernelGGL((attn_bwd_dq_kernel<NW, 3>), grid, dim3(NW * 64), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL((attn_bwd_dq_kernel<NW, 2>), grid, dim3(NW * 64), 0, (hipStream_t)stream, p);
-  RP_CHECK_LAUNCH();
-  return RP_OK;
+  // both passes need ~190-240 VGPRs (2 waves/SIMD = 8 wave slots per CU): 2-wave workgroups pack 4 per CU, 3-wave ones only 2
+  const char* ov = getenv("RP_ATTN_NW");
+  if (ov && ov[0] == '3') return launch_bwd<3>(p, Z, H, (hipStream_t)stream);
+  return launch_bwd<2>(p, Z, H, (hipStream_t)stream);
 }

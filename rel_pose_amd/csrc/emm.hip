@@ -92,8 +92,8 @@ __global__ __launch_bounds__(NT) void emm_apply_kernel(EmmP p) {
   const float* xb = p.x + zh * NTOK * XW;
 
   float oreg[32];
-  load_owner(p.qkv + ((long long)own_img * NTOK + o0 + l31) * p.ld + own_col, hi, p.scale, oreg);
-  const float ls_o = own_lse[o0 + l31];
+  load_owner(p.qkv + ((long long)own_img * NTOK + o0 + l31) * p.ld + own_col, hi, p.scale * RP_LOG2E, oreg);
+  const float ls_o = own_lse[o0 + l31] * RP_LOG2E;
 
   f32x16 tacc[3] = {zero16(), zero16(), zero16()};
   float4 kpre[3], xpre[4];
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(NT) void emm_apply_kernel(EmmP p) {
   };
   kv_gload(lb, p.ld, tid, kpre);
   x_gload(0);
-  if (tid < 32) cpre = loop_lse[tid];
+  if (tid < 32) cpre = loop_lse[tid] * RP_LOG2E;
   kv_sstore(Ks, tid, kpre);
   x_sstore(Xs);
   if (tid < 32) Cl[tid] = cpre;
@@ -119,13 +119,13 @@ __global__ __launch_bounds__(NT) void emm_apply_kernel(EmmP p) {
     if (t + 1 < NTILE) {
       kv_gload(lb + (long long)(t + 1) * 32 * p.ld, p.ld, tid, kpre);
       x_gload(t + 1);
-      if (tid < 32) cpre = loop_lse[(t + 1) * 32 + tid];
+      if (tid < 32) cpre = loop_lse[(t + 1) * 32 + tid] * RP_LOG2E;
     }
     f32x16 s = score_tile(Ks + cur * 32 * KST, l31, hi, oreg);   // S^T[loop][owner]
     const float* cl = Cl + cur * 32;
     const float* xs = Xs + cur * 32 * XW;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = expf(2.0f * s[r] - ls_o - cl[acc_row(r, hi)]);
+    for (int r = 0; r < 16; ++r) s[r] = fast_exp2(2.0f * s[r] - ls_o - cl[acc_row(r, hi)]);
     // T[owner][c] += sum_loop A[owner][loop] X[loop][c] : A operand = s (lane = owner), B operand = X rows
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(NT) void emm_grad_kernel(EmmP p) {
   const float* xb = p.x + zh * NTOK * XW;
 
   float oreg[32], wreg[36];
-  load_owner(p.qkv + ((long long)own_img * NTOK + o0 + l31) * p.ld + own_col, hi, p.scale, oreg);
+  load_owner(p.qkv + ((long long)own_img * NTOK + o0 + l31) * p.ld + own_col, hi, p.scale * RP_LOG2E, oreg);
   {
     const float* wr = p.w + (zh * NTOK + o0 + l31) * XW + 36 * hi;
 #pragma unroll
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(NT) void emm_grad_kernel(EmmP p) {
       wreg[4 * c] = v.x; wreg[4 * c + 1] = v.y; wreg[4 * c + 2] = v.z; wreg[4 * c + 3] = v.w;
     }
   }
-  const float ls_o = own_lse[o0 + l31], g_o = own_g[o0 + l31];
+  const float ls_o = own_lse[o0 + l31] * RP_LOG2E, g_o = own_g[o0 + l31];
 
   f32x16 d0 = zero16(), d1 = zero16();
   float4 kpre[3], xpre[3];
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(NT) void emm_grad_kernel(EmmP p) {
   };
   kv_gload(lb, p.ld, tid, kpre);
   x_gload(0);
-  if (tid < 64) lpre = tid < 32 ? loop_lse[tid] : loop_g[tid - 32];
+  if (tid < 64) lpre = tid < 32 ? loop_lse[tid] * RP_LOG2E : loop_g[tid - 32];
   kv_sstore(Ks[0], tid, kpre);
   x_sstore(Xs[0]);
   if (tid < 64) Ll[0][tid] = lpre;
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(NT) void emm_grad_kernel(EmmP p) {
     if (t + 1 < NTILE) {
       kv_gload(lb + (long long)(t + 1) * 32 * p.ld, p.ld, tid, kpre);
       x_gload(t + 1);
-      if (tid < 64) lpre = tid < 32 ? loop_lse[(t + 1) * 32 + tid] : loop_g[(t + 1) * 32 + tid - 32];
+      if (tid < 64) lpre = tid < 32 ? loop_lse[(t + 1) * 32 + tid] * RP_LOG2E : loop_g[(t + 1) * 32 + tid - 32];
     }
     f32x16 s = score_tile(Ks[cur], l31, hi, oreg);      // S^T[loop][owner]
     f32x16 da = zero16();                                // dA^T[loop][owner] = sum_c X[loop][c] W[owner][c]
@@ -257,8 +257,8 @@ __global__ __launch_bounds__(NT) void emm_grad_kernel(EmmP p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int li = acc_row(r, hi);
-      const float eo = expf(s[r] - ls_o);                // owner-side softmax factor
-      const float el = expf(s[r] - Ll[cur][li]);         // loop-side softmax factor
+      const float eo = fast_exp2(s[r] - ls_o);           // owner-side softmax factor
+      const float el = fast_exp2(s[r] - Ll[cur][li]);    // loop-side softmax factor
       s[r] = 2.0f * eo * el * da[r] - eo * g_o - el * Ll[cur][32 + li];
     }
     // d owner^T[d][owner] += sum_loop other[loop][d] dS^T[loop][owner]

@@ -61,13 +61,15 @@ def gemm_tile(M, N, a_layout, b_layout, reads_mn=False):
     return 2, 1
 
 
-def pick_split_k(M, N, K, a_layout=0, b_layout=0, target_wgs=288, min_ktiles=8):
+def pick_split_k(M, N, K, a_layout=0, b_layout=0, target_wgs=768, min_ktiles=8, max_split=128):
     tm, tn = gemm_tile(M, N, a_layout, b_layout)
     tiles = -(-M // (64 * tm)) * -(-N // (64 * tn))
     ktiles = -(-K // 32)
     if tiles >= 256 or ktiles < 2 * min_ktiles:
         return 1
-    return max(1, min(ktiles // min_ktiles, -(-target_wgs // tiles)))
+    # ~3 workgroups per CU keeps >=2 waves per SIMD resident (measured: 0.76 waves/SIMD at 288 WGs left the MFMA pipe
+    # 44 % busy); more than 128 partial slabs makes the reduce pass visible
+    return max(1, min(ktiles // min_ktiles, -(-target_wgs // tiles), max_split))
 
 
 class KernelTimer:

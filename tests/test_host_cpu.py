@@ -93,7 +93,7 @@ def test_gemm_tile_and_splitk_selection():
     assert ops.gemm_instance(64, 512, 0, 0) == (0, 0, 1, 2)
     assert ops.pick_split_k(73728, 768, 192) == 1               # plenty of tiles
     sk = ops.pick_split_k(576, 192, 73728, 1, 1)                # weight gradient: 9 tiles, 2304 k-tiles
-    assert 16 <= sk <= 64
+    assert 64 <= sk <= 128
     assert ops.pick_split_k(64, 512, 26880) > 32                # regressor layer 0 at batch 64
     assert ops.pick_split_k(64, 26880, 512) <= 2
 

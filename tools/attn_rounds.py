@@ -3,7 +3,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from rel_pose_amd import ops, _lib
 _lib.load()
-Z = 128; M = Z * 576
 def timeit(fn, n=10, warm=3):
     for _ in range(warm): fn()
     torch.cuda.synchronize()
@@ -12,9 +11,8 @@ def timeit(fn, n=10, warm=3):
     for _ in range(n): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n * 1e3
-qkv = torch.randn(M, 576, device="cuda"); do = torch.randn(M, 192, device="cuda")
-o, lse = ops.attn_fwd(qkv, Z)
-timeit(lambda: ops.attn_fwd(qkv, Z))
-for nw in sys.argv[1:]:
-    os.environ["RP_ATTN_NW"] = nw
-    print("NW", nw, "fwd %.1f us  bwd %.1f us" % (timeit(lambda: ops.attn_fwd(qkv, Z)), timeit(lambda: ops.attn_bwd(qkv, o, lse, do, Z))), flush=True)
+for Z in (14, 28, 56, 57, 64, 86, 114, 128, 170, 228, 256):
+    qkv = torch.randn(Z * 576, 576, device="cuda")
+    t = timeit(lambda: ops.attn_fwd(qkv, Z))
+    fl = 4.0 * Z * 3 * 576 * 576 * 64
+    print("Z=%3d WGs=%5d fwd %.1f us  %.1f TF  (%.2f us per image)" % (Z, 18 * Z, t, fl / t / 1e6, t / Z), flush=True)

@@ -18,6 +18,12 @@ bq = torch.zeros(576, device="cuda")
 for _ in range(3):
     if what == "fc1":
         ops.linear(x, W1, b1, act=1)
+    elif what == "dw":
+        dY = torch.randn(M, 768, device="cuda")
+        ops.linear_dw(dY, x)
+    elif what == "dx":
+        dY = torch.randn(M, 768, device="cuda")
+        ops.linear_dx(dY, W1)
     elif what == "attn":
         qkv = ops.linear(x, Wq, bq)
         ops.attn_fwd(qkv, Z)

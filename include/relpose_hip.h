@@ -89,6 +89,8 @@ int rp_colsum(const float* in, int rows, int cols, int ld, float* out, float* wo
 /* Token layout + learned position embedding: x[z][n][c] = feat[z][c][n] + pos_embed[n][c]
  * (reference src/model.py:136-141,170-171; index part bit-exact).  feat is the CNN map [Z,C,N]. */
 int rp_tokens_fwd(const float* feat, const float* pos_embed, float* x, int Z, int C, int N, void* stream);
+/* same for a channels-last CNN map (memory already [Z,N,C]): x = feat + pos_embed; its backward is the identity */
+int rp_tokens_fwd_nhwc(const float* feat, const float* pos_embed, float* x, int Z, int C, int N, void* stream);
 int rp_tokens_bwd(const float* dx, float* dfeat, int Z, int C, int N, void* stream);
 
 /* Fused softmax attention, N=576 tokens, d=64, heads packed along columns (col = h*64 + e):

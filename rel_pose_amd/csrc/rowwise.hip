@@ -150,6 +150,15 @@ __global__ __launch_bounds__(256) void tokens_fwd_kernel(const float* __restrict
   }
 }
 
+// channels-last CNN map: memory is already [z][n][c]; only the pos_embed add remains (float4)
+__global__ __launch_bounds__(256) void tokens_nhwc_kernel(const float* __restrict__ feat, const float* __restrict__ pe,
+                                                          float* __restrict__ x, long long per_img4, long long total4) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const float4 a = ld4(feat + 4 * i), b = ld4(pe + 4 * (i % per_img4));
+  st4(x + 4 * i, make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w));
+}
+
 __global__ __launch_bounds__(256) void tokens_bwd_kernel(const float* __restrict__ dx, float* __restrict__ dfeat, int C,
                                                          int N) {
   __shared__ float t[32][33];
@@ -389,6 +398,16 @@ extern "C" int rp_tokens_fwd(const float* feat, const float* pos_embed, float* x
   if (Z <= 0 || (C & 31) || (N & 31)) return RP_EBADSHAPE;
   hipLaunchKernelGGL(tokens_fwd_kernel, dim3(N / 32, C / 32, Z), dim3(256), 0, (hipStream_t)stream, feat, pos_embed, x,
                      C, N);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
+extern "C" int rp_tokens_fwd_nhwc(const float* feat, const float* pos_embed, float* x, int Z, int C, int N,
+                                  void* stream) {
+  if (Z <= 0 || (C & 3)) return RP_EBADSHAPE;
+  const long long per4 = (long long)C * N / 4, tot4 = per4 * Z;
+  hipLaunchKernelGGL(tokens_nhwc_kernel, dim3((unsigned)((tot4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, feat,
+                     pos_embed, x, per4, tot4);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }

@@ -54,6 +54,10 @@ class ViTEss(nn.Module):
         self.pose_regressor = nn.Sequential(
             nn.Linear(self.H, self.H2), nn.ReLU(), nn.Linear(self.H2, self.H2), nn.ReLU(),
             nn.Linear(self.H2, self.num_images * self.pose_size), nn.Unflatten(1, (self.num_images, self.pose_size)))
+        # CNN front-end in channels-last: MIOpen's fp32 kernels are NHWC (saves its NCHW<->NHWC transposes, measured
+        # 24.1 -> 20.1 ms fwd+bwd at 128 images) and the [2B,24,24,192] map IS the token layout (src/model.py:136-141)
+        self.resnet.to(memory_format=torch.channels_last)
+        self.extractor_final_conv.to(memory_format=torch.channels_last)
 
     # -- src/model.py:100-109 ---------------------------------------------------------------------
     def update_intrinsics(self, input_shape, intrinsics):
@@ -73,7 +77,7 @@ class ViTEss(nn.Module):
         images = images.sub_(mean[:, None, None]).div_(std[:, None, None])
         if intrinsics is not None:
             intrinsics = self.update_intrinsics(images.shape, intrinsics)
-        x = F.interpolate(self.flatten(images), size=224)
+        x = F.interpolate(self.flatten(images), size=224).contiguous(memory_format=torch.channels_last)
         r = self.resnet
         x = r.maxpool(r.relu(r.bn1(r.conv1(x))))
         x = r.layer2(r.layer1(x))

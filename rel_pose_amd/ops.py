@@ -344,18 +344,25 @@ def emm_backward(qkv, x, t, rlse, clse, df, Z):
 # autograd Functions
 # ------------------------------------------------------------------------------------------------
 class TokensFn(torch.autograd.Function):
-    """x[z][n][c] = feat[z][c][n] + pos_embed[n][c]  (src/model.py:136-141,170-171)."""
+    """x[z][n][c] = feat[z][c][n] + pos_embed[n][c]  (src/model.py:136-141,170-171).  A channels-last CNN map is
+    already laid out [z][n][c] in memory, so the permutation is a view and only the add runs."""
 
     @staticmethod
     def forward(ctx, feat, pos_embed):
         lib = _lib.load()
-        feat = feat.contiguous()
-        _chk(feat, pos_embed)
         Z, C = feat.shape[0], feat.shape[1]
         N = feat.numel() // (Z * C)
-        x = _empty(Z, N, C, like=feat)
-        _lib.check(lib.rp_tokens_fwd(_p(feat), _p(pos_embed), _p(x), Z, C, N, _st()), "rp_tokens_fwd")
-        ctx.shape = tuple(feat.shape)
+        nhwc = feat.dim() == 4 and feat.is_contiguous(memory_format=torch.channels_last) and not feat.is_contiguous()
+        ctx.nhwc, ctx.shape = nhwc, tuple(feat.shape)
+        x = torch.empty(Z, N, C, device=feat.device, dtype=torch.float32)
+        if nhwc:
+            src = feat.permute(0, 2, 3, 1)              # [Z,H,W,C] view, contiguous
+            _chk(src, pos_embed)
+            _lib.check(lib.rp_tokens_fwd_nhwc(_p(src), _p(pos_embed), _p(x), Z, C, N, _st()), "rp_tokens_fwd_nhwc")
+        else:
+            feat = feat.contiguous()
+            _chk(feat, pos_embed)
+            _lib.check(lib.rp_tokens_fwd(_p(feat), _p(pos_embed), _p(x), Z, C, N, _st()), "rp_tokens_fwd")
         return x
 
     @staticmethod
@@ -363,9 +370,12 @@ class TokensFn(torch.autograd.Function):
         lib = _lib.load()
         dx = dx.contiguous()
         Z, N, C = dx.shape
+        dpe = colsum(dx.view(Z, N * C)).view(1, N, C)
+        if ctx.nhwc:
+            _, _, H, W = ctx.shape
+            return dx.view(Z, H, W, C).permute(0, 3, 1, 2), dpe          # channels-last gradient, no copy
         dfeat = _empty(*ctx.shape, like=dx)
         _lib.check(lib.rp_tokens_bwd(_p(dx), _p(dfeat), Z, C, N, _st()), "rp_tokens_bwd")
-        dpe = colsum(dx.view(Z, N * C)).view(1, N, C)
         return dfeat, dpe
 
 

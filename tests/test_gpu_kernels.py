@@ -143,6 +143,12 @@ def test_colsum_tokens_posenc_pose(ops, golden):
     assert torch.equal(tok, feat.reshape(4, 192, 576).permute(0, 2, 1).contiguous())
     tok2 = ops.TokensFn.apply(feat, pe)
     assert torch.equal(tok2, feat.reshape(4, 192, 576).permute(0, 2, 1) + pe)
+    # channels-last map: the permutation is a view; same values, bit-exact
+    fcl = feat.contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    tok3 = ops.TokensFn.apply(fcl, pe)
+    assert torch.equal(tok3, tok2)
+    (tok3 * rnd(4, 576, 192, seed=4)).sum().backward()
+    assert torch.equal(fcl.grad, rnd(4, 576, 192, seed=4).permute(0, 2, 1).reshape(4, 192, 24, 24))
     f2 = feat.clone().requires_grad_(True)
     p2 = pe.clone().requires_grad_(True)
     cot = rnd(4, 576, 192, seed=4)

@@ -122,7 +122,7 @@ def main():
     ap.add_argument("--scope", default="full", choices=("full", "hot"),
                     help="full = images -> CNN -> hot path (the metric); hot = synthetic CNN maps -> hot path only "
                          "(kernel profiling; not the headline number)")
-    ap.add_argument("--timer-instance", default="0,0,2,3", help="gemm_kernel<aL,bL,TM,TN> instance timed for `roofline`")
+    ap.add_argument("--timer-instance", default="0,0,2,1", help="gemm_kernel<aL,bL,TM,TN> instance timed for `roofline`")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -217,6 +217,14 @@ def main():
         n_launch, t_launch, flops = timer.summary()
         achieved = flops / max(n_launch, 1) / max(t_launch, 1e-12) / 1e12
         pairs = world * args.batch * args.steps
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")      # PMC passes cannot run inside the timed process:
+        if os.path.exists(tpath):                                     # tools/pmc_bench.sh measured this command's kernels
+            with open(tpath) as f:
+                tj = json.load(f)
+            ent = tj["kernels"].get("gemm_kernel<%s>" % ", ".join(args.timer_instance.split(",")))
+            if ent:
+                traffic, traffic_src = round(ent["hbm_bytes_per_launch"]), "profiles/r1_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE)"
         rec = {
             "metric": METRIC, "value": round(pairs / el, 2), "unit": "image-pairs/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 3),
@@ -228,7 +236,9 @@ def main():
                        "parallelism": "dp%d" % world, "finite": finite,
                        "hot_path_share": "ViT+EMM+regressor on HIP kernels; ResNet front-end on MIOpen (SURVEY 8f-1)"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch_avg": timer.bytes / max(n_launch, 1),
                          "kernel": "gemm_kernel<%s>" % args.timer_instance, "launches_timed": n_launch,
                          "avg_launch_us": round(t_launch * 1e6, 2),
                          "flops_per_launch_avg": flops / max(n_launch, 1),

@@ -29,23 +29,28 @@ struct AttnP {
   float* o; float* lse;
   int H, ldq, ldk, ldv, ldo, q_xor, k_xor;
   float scale;
+  int ZH;
 };
 
-// cooperative global -> register prefetch of a [32][64] tile (rows 32, 16 float4 each)
+// cooperative global -> register prefetch of a [32][64] tile (32 rows x 16 float4).  No exec-masked guards: when the
+// thread count does not divide 512 the surplus threads of the last round re-load (and later re-store) element 511-ish
+// duplicates -- a guarded load becomes its own basic block and hipcc then drains vmcnt(0) before every one of them.
 template <int NT>
 RP_DEV void tile_gload(const float* base, int ld, int tid, float4 (&r)[(512 + NT - 1) / NT]) {
 #pragma unroll
   for (int j = 0; j < (512 + NT - 1) / NT; ++j) {
-    const int f = tid + NT * j;
-    if (f < 512) r[j] = ld4(base + (long long)(f >> 4) * ld + (f & 15) * 4);
+    int f = tid + NT * j;
+    if (512 % NT != 0) f = min(f, 511);
+    r[j] = ld4(base + (long long)(f >> 4) * ld + (f & 15) * 4);
   }
 }
 template <int NT, int STRIDE>
 RP_DEV void tile_sstore(float* s, int tid, const float4 (&r)[(512 + NT - 1) / NT]) {
 #pragma unroll
   for (int j = 0; j < (512 + NT - 1) / NT; ++j) {
-    const int f = tid + NT * j;
-    if (f < 512) st4(s + (f >> 4) * STRIDE + (f & 15) * 4, r[j]);
+    int f = tid + NT * j;
+    if (512 % NT != 0) f = min(f, 511);
+    st4(s + (f >> 4) * STRIDE + (f & 15) * 4, r[j]);
   }
 }
 
@@ -93,6 +98,14 @@ RP_DEV void load_owner(const float* row_ptr, int hi, float mul, float (&reg)[32]
   }
 }
 
+// Software-pipelined tile loop (one barrier per tile, two LDS buffers).  MFMA operands are fetched from LDS one phase
+// ahead of the MFMAs that consume them, so the matrix pipe never waits on a ds_read (the first version issued each
+// read right before its MFMA and exposed ~2000 cycles of LDS latency per 4096-cycle tile):
+//   top      : global loads of tile t+1 -> VGPRs;  LDS reads: K[t] second half, V[t] rows 0-7
+//   S chain  : 16 MFMAs on K[t] first half (read during the previous tile's last phase) + 16 on the second half
+//   softmax  : VALU;  LDS reads: V[t] rows 8-15
+//   PV part 1: 16 MFMAs;  tile t+1 VGPRs -> LDS[other];  barrier;  LDS reads: K[t+1] first half
+//   PV part 2: 16 MFMAs (cover the K[t+1] read)
 template <int NW, bool STATS, int WPS>
 __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_kernel(AttnP p) {
   constexpr int NT = NW * 64;
@@ -100,8 +113,10 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_kernel(AttnP p) {
   __shared__ __attribute__((aligned(16))) float Ks[2][32 * KST];
   __shared__ __attribute__((aligned(16))) float Vs[STATS ? 1 : 2][STATS ? 4 : 32 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-  const int h = blockIdx.y, z = blockIdx.z;
-  const int q0 = (blockIdx.x * NW + wave) * 32;
+  int zh, qblk;
+  if (!xcd_problem(NTILE / NW, p.ZH, zh, qblk)) return;
+  const int h = zh % p.H, z = zh / p.H;
+  const int q0 = (qblk * NW + wave) * 32;
   const float* qb = p.q + (long long)(z ^ p.q_xor) * NTOK * p.ldq + h * 64;
   const float* kb = p.k + (long long)(z ^ p.k_xor) * NTOK * p.ldk + h * 64;
   const float* vb = STATS ? nullptr : p.v + (long long)z * NTOK * p.ldv + h * 64;
@@ -119,13 +134,46 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_kernel(AttnP p) {
   if (!STATS) tile_sstore<NT, 64>(Vs[0], tid, vpre);
   __syncthreads();
 
+  const int krow = l31 * KST + 32 * hi;          // this lane's K row / column half inside a tile
+  float4 ka[4], kb2[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) ka[c] = ld4(Ks[0] + krow + 4 * c);
+
+  // tile 1 is already in flight while tile 0 is being consumed (global loads are issued right after each barrier, one
+  // full tile of MFMAs ahead of the LDS store that needs them)
+  tile_gload<NT>(kb + (long long)32 * p.ldk, p.ldk, tid, kpre);
+  if (!STATS) tile_gload<NT>(vb + (long long)32 * p.ldv, p.ldv, tid, vpre);
+
   for (int t = 0; t < NTILE; ++t) {
     const int cur = t & 1;
-    if (t + 1 < NTILE) {
-      tile_gload<NT>(kb + (long long)(t + 1) * 32 * p.ldk, p.ldk, tid, kpre);
-      if (!STATS) tile_gload<NT>(vb + (long long)(t + 1) * 32 * p.ldv, p.ldv, tid, vpre);
+    const bool more = t + 1 < NTILE;
+    float va[16], vb_[16];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) kb2[c] = ld4(Ks[cur] + krow + 16 + 4 * c);
+    if (!STATS) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const float* vr = Vs[cur] + acc_row(r, hi) * 64 + l31;
+        va[2 * r] = vr[0];
+        va[2 * r + 1] = vr[32];
+      }
     }
-    f32x16 s = score_tile(Ks[cur], l31, hi, qreg);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 s = zero16();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      s = mfma32(ka[c].x, qreg[4 * c + 0], s);
+      s = mfma32(ka[c].y, qreg[4 * c + 1], s);
+      s = mfma32(ka[c].z, qreg[4 * c + 2], s);
+      s = mfma32(ka[c].w, qreg[4 * c + 3], s);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      s = mfma32(kb2[c].x, qreg[16 + 4 * c + 0], s);
+      s = mfma32(kb2[c].y, qreg[16 + 4 * c + 1], s);
+      s = mfma32(kb2[c].z, qreg[16 + 4 * c + 2], s);
+      s = mfma32(kb2[c].w, qreg[16 + 4 * c + 3], s);
+    }
     float mx = s[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
@@ -142,17 +190,44 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_kernel(AttnP p) {
     l = l * alpha + ps;
     if (!STATS) {
 #pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const float* vr = Vs[cur] + acc_row(8 + r, hi) * 64 + l31;
+        vb_[2 * r] = vr[0];
+        vb_[2 * r + 1] = vr[32];
+      }
+#pragma unroll
       for (int r = 0; r < 16; ++r) {
         o0[r] *= alpha;
         o1[r] *= alpha;
       }
-      accum_tile<64>(Vs[cur], l31, hi, s, o0, o1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        o0 = mfma32(va[2 * r], s[r], o0);
+        o1 = mfma32(va[2 * r + 1], s[r], o1);
+      }
     }
-    if (t + 1 < NTILE) {
+    if (more) {
       tile_sstore<NT, KST>(Ks[cur ^ 1], tid, kpre);
       if (!STATS) tile_sstore<NT, 64>(Vs[cur ^ 1], tid, vpre);
     }
     __syncthreads();
+    if (more) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) ka[c] = ld4(Ks[cur ^ 1] + krow + 4 * c);
+      if (t + 2 < NTILE) {
+        tile_gload<NT>(kb + (long long)(t + 2) * 32 * p.ldk, p.ldk, tid, kpre);
+        if (!STATS) tile_gload<NT>(vb + (long long)(t + 2) * 32 * p.ldv, p.ldv, tid, vpre);
+      }
+    }
+    if (!STATS) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        o0 = mfma32(vb_[2 * r], s[8 + r], o0);
+        o1 = mfma32(vb_[2 * r + 1], s[8 + r], o1);
+      }
+    }
   }
   const float lt = l + __shfl_xor(l, 32, 64);
   if (!STATS) store_ownerT(p.o + ((long long)z * NTOK + q0 + l31) * p.ldo + h * 64, hi, o0, o1, 1.0f / lt);
@@ -175,6 +250,7 @@ struct AttnBwdP {
   float* dq; float* dk; float* dv;
   int H, ldq, ldk, ldv, lddo, lddq, lddk, lddv;
   float scale;
+  int ZH;
 };
 
 template <int NW, int WPS>
@@ -185,8 +261,10 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dkdv_kernel(AttnBwdP p)
   __shared__ __attribute__((aligned(16))) float Ds[2][32 * KST];
   __shared__ __attribute__((aligned(16))) float Ls[2][64];   // [0..31] lse, [32..63] delta of the query tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-  const int h = blockIdx.y, z = blockIdx.z;
-  const int k0 = (blockIdx.x * NW + wave) * 32;
+  int zh, qblk;
+  if (!xcd_problem(NTILE / NW, p.ZH, zh, qblk)) return;
+  const int h = zh % p.H, z = zh / p.H;
+  const int k0 = (qblk * NW + wave) * 32;
   const float* qb = p.q + (long long)z * NTOK * p.ldq + h * 64;
   const float* dob = p.dout + (long long)z * NTOK * p.lddo + h * 64;
   const float* lseb = p.lse + ((long long)z * p.H + h) * NTOK;
@@ -243,8 +321,10 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dq_kernel(AttnBwdP p) {
   __shared__ __attribute__((aligned(16))) float Ks[2][32 * KST];
   __shared__ __attribute__((aligned(16))) float Vs[2][32 * KST];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-  const int h = blockIdx.y, z = blockIdx.z;
-  const int q0 = (blockIdx.x * NW + wave) * 32;
+  int zh, qblk;
+  if (!xcd_problem(NTILE / NW, p.ZH, zh, qblk)) return;
+  const int h = zh % p.H, z = zh / p.H;
+  const int q0 = (qblk * NW + wave) * 32;
   const float* kb = p.k + (long long)z * NTOK * p.ldk + h * 64;
   const float* vb = p.v + (long long)z * NTOK * p.ldv + h * 64;
 
@@ -290,21 +370,21 @@ extern "C" int rp_attn_fwd(const float* q, const float* k, const float* v, float
   if ((q_xor || k_xor) && (Z & 1)) return RP_EBADSHAPE;
   if ((ldq | ldk) & 3) return RP_EALIGN;
   if (!stats_only && ((ldv | ldo) & 3)) return RP_EALIGN;
-  AttnP p{q, k, v, o, lse, H, ldq, ldk, ldv, ldo, q_xor, k_xor, scale};
-  constexpr int NW = 3;
-  dim3 grid(NTILE / NW, H, Z);
-  const char* ov = getenv("RP_ATTN_WPS");   // tuning aid: "f,k,q" waves/SIMD bounds
-  const int wf = ov ? ov[0] - '0' : 2;
-  if (stats_only) hipLaunchKernelGGL((attn_fwd_kernel<NW, true, 2>), grid, dim3(NW * 64), 0, (hipStream_t)stream, p);
-  else if (wf == 3) hipLaunchKernelGGL((attn_fwd_kernel<NW, false, 3>), grid, dim3(NW * 64), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL((attn_fwd_kernel<NW, false, 2>), grid, dim3(NW * 64), 0, (hipStream_t)stream, p);
+  AttnP p{q, k, v, o, lse, H, ldq, ldk, ldv, ldo, q_xor, k_xor, scale, Z * H};
+  hipStream_t st = (hipStream_t)stream;
+  const char* ov = getenv("RP_ATTN_FWD");   // tuning aid: "<NW><WPS>", e.g. "32"
+  const int nw = ov ? ov[0] - '0' : 2, wps = ov ? ov[1] - '0' : 2;
+  if (stats_only) hipLaunchKernelGGL((attn_fwd_kernel<3, true, 2>), dim3(xcd_grid(NTILE / 3, Z * H)), dim3(192), 0, st, p);
+  else if (nw == 2) hipLaunchKernelGGL((attn_fwd_kernel<2, false, 2>), dim3(xcd_grid(NTILE / 2, Z * H)), dim3(128), 0, st, p);
+  else if (wps == 3) hipLaunchKernelGGL((attn_fwd_kernel<3, false, 3>), dim3(xcd_grid(NTILE / 3, Z * H)), dim3(192), 0, st, p);
+  else hipLaunchKernelGGL((attn_fwd_kernel<3, false, 2>), dim3(xcd_grid(NTILE / 3, Z * H)), dim3(192), 0, st, p);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }
 
 template <int NW>
 static int launch_bwd(const AttnBwdP& p, int Z, int H, hipStream_t st) {
-  dim3 grid(NTILE / NW, H, Z);
+  dim3 grid(xcd_grid(NTILE / NW, Z * H));
   hipLaunchKernelGGL((attn_bwd_dkdv_kernel<NW, 2>), grid, dim3(NW * 64), 0, st, p);
   RP_CHECK_LAUNCH();
   hipLaunchKernelGGL((attn_bwd_dq_kernel<NW, 2>), grid, dim3(NW * 64), 0, st, p);
@@ -317,7 +397,7 @@ extern "C" int rp_attn_bwd(const float* q, const float* k, const float* v, const
                            int lddo, int lddq, int lddk, int lddv, float scale, void* stream) {
   if (Z <= 0 || H <= 0) return RP_EBADSHAPE;
   if ((ldq | ldk | ldv | lddo | lddq | lddk | lddv) & 3) return RP_EALIGN;
-  AttnBwdP p{q, k, v, dout, lse, delta, dq, dk, dv, H, ldq, ldk, ldv, lddo, lddq, lddk, lddv, scale};
+  AttnBwdP p{q, k, v, dout, lse, delta, dq, dk, dv, H, ldq, ldk, ldv, lddo, lddq, lddk, lddv, scale, Z * H};
   // both passes need ~190-240 VGPRs (2 waves/SIMD = 8 wave slots per CU): 2-wave workgroups pack 4 per CU, 3-wave ones only 2
   const char* ov = getenv("RP_ATTN_NW");
   if (ov && ov[0] == '3') return launch_bwd<3>(p, Z, H, (hipStream_t)stream);

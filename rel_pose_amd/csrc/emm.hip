@@ -31,21 +31,21 @@ struct EmmP {
   const float* x; const float* w;
   const float* rlse; const float* clse; const float* rho; const float* gamma;
   float* t_out; float* f_part; float* dqkv;
-  int H; float scale; int swap;
+  int H; float scale; int swap; int ZH;
 };
 
 RP_DEV void kv_gload(const float* base, int ld, int tid, float4 (&r)[3]) {
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-    const int f = tid + NT * j;
-    if (f < 512) r[j] = ld4(base + (long long)(f >> 4) * ld + (f & 15) * 4);
+    const int f = min(tid + NT * j, 511);     // surplus threads duplicate the last element (no exec-masked guard)
+    r[j] = ld4(base + (long long)(f >> 4) * ld + (f & 15) * 4);
   }
 }
 RP_DEV void kv_sstore(float* s, int tid, const float4 (&r)[3]) {
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-    const int f = tid + NT * j;
-    if (f < 512) st4(s + (f >> 4) * KST + (f & 15) * 4, r[j]);
+    const int f = min(tid + NT * j, 511);
+    st4(s + (f >> 4) * KST + (f & 15) * 4, r[j]);
   }
 }
 
@@ -80,8 +80,10 @@ __global__ __launch_bounds__(NT) void emm_apply_kernel(EmmP p) {
   float* Xs = lds + 2 * 32 * KST;
   float* Cl = Xs + 2 * 32 * XW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-  const int h = blockIdx.y, z = blockIdx.z;
-  const int wg0 = blockIdx.x * (NW * 32);
+  int zh_, wgi;
+  if (!xcd_problem(NTILE / NW, p.ZH, zh_, wgi)) return;
+  const int h = zh_ % p.H, z = zh_ / p.H;
+  const int wg0 = wgi * (NW * 32);
   const int o0 = wg0 + wave * 32;
   const int own_img = p.swap ? z : (z ^ 1), own_col = (p.swap ? 192 : 0) + h * 64;
   const int loop_img = p.swap ? (z ^ 1) : z, loop_col = (p.swap ? 0 : 192) + h * 64;
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(NT) void emm_apply_kernel(EmmP p) {
     facc[1] = mfma32(av, tr[32], facc[1]);
     facc[2] = mfma32(av, tr[64], facc[2]);
   }
-  float* fb = p.f_part + ((zh * (NTOK / (NW * 32)) + blockIdx.x) * XW + 32 * wave) * XW;
+  float* fb = p.f_part + ((zh * (NTOK / (NW * 32)) + wgi) * XW + 32 * wave) * XW;
 #pragma unroll
   for (int nb = 0; nb < 3; ++nb)
 #pragma unroll
@@ -185,8 +187,10 @@ __global__ __launch_bounds__(NT) void emm_grad_kernel(EmmP p) {
   __shared__ __attribute__((aligned(16))) float Xs[2][32 * XGS];
   __shared__ float Ll[2][64];   // loop-side lse [0..31] and rho/gamma [32..63]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-  const int h = blockIdx.y, z = blockIdx.z;
-  const int o0 = (blockIdx.x * NW + wave) * 32;
+  int zh_, wgi;
+  if (!xcd_problem(NTILE / NW, p.ZH, zh_, wgi)) return;
+  const int h = zh_ % p.H, z = zh_ / p.H;
+  const int o0 = (wgi * NW + wave) * 32;
   const int own_img = p.swap ? z : (z ^ 1), own_col = (p.swap ? 192 : 0) + h * 64;
   const int loop_img = p.swap ? (z ^ 1) : z, loop_col = (p.swap ? 0 : 192) + h * 64;
   const long long zh = (long long)z * p.H + h;
@@ -291,8 +295,8 @@ extern "C" int rp_emm_apply(const float* qkv, int ldqkv, const float* x, const f
   if (swap && f_part) return RP_EUNSUPPORTED;
   EmmP p{};
   p.qkv = qkv; p.ld = ldqkv; p.x = x; p.rlse = rlse; p.clse = clse; p.t_out = t_out; p.f_part = f_part;
-  p.H = H; p.scale = scale; p.swap = swap ? 1 : 0;
-  hipLaunchKernelGGL(emm_apply_kernel, dim3(NTILE / NW, H, Z), dim3(NT), 0, (hipStream_t)stream, p);
+  p.H = H; p.scale = scale; p.swap = swap ? 1 : 0; p.ZH = Z * H;
+  hipLaunchKernelGGL(emm_apply_kernel, dim3(xcd_grid(NTILE / NW, Z * H)), dim3(NT), 0, (hipStream_t)stream, p);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }
@@ -303,8 +307,8 @@ extern "C" int rp_emm_grad(const float* qkv, int ldqkv, const float* x, const fl
   if (Z <= 0 || (Z & 1) || H <= 0 || (ldqkv & 3)) return RP_EBADSHAPE;
   EmmP p{};
   p.qkv = qkv; p.ld = ldqkv; p.x = x; p.w = w; p.rlse = rlse; p.clse = clse; p.rho = rho; p.gamma = gamma;
-  p.dqkv = dqkv; p.H = H; p.scale = scale; p.swap = swap ? 1 : 0;
-  hipLaunchKernelGGL(emm_grad_kernel, dim3(NTILE / NW, H, Z), dim3(NT), 0, (hipStream_t)stream, p);
+  p.dqkv = dqkv; p.H = H; p.scale = scale; p.swap = swap ? 1 : 0; p.ZH = Z * H;
+  hipLaunchKernelGGL(emm_grad_kernel, dim3(xcd_grid(NTILE / NW, Z * H)), dim3(NT), 0, (hipStream_t)stream, p);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }

@@ -80,10 +80,11 @@ class KernelTimer:
         self.instance = tuple(instance)
         self.events = []
         self.flops = 0.0
+        self.bytes = 0.0          # compulsory bytes: A + B + C (+ [M,N] epilogue operands), each once
         self.enabled = False
 
     def reset(self):
-        self.events, self.flops = [], 0.0
+        self.events, self.flops, self.bytes = [], 0.0, 0.0
 
     def summary(self):
         """-> (launches, mean seconds per launch, total algorithmic flops); call after a device sync."""
@@ -142,6 +143,7 @@ def gemm(A, B, M, N, K, *, a_layout=0, b_layout=0, lda=None, ldb=None, out=None,
         e1.record()
         tm.events.append((e0, e1))
         tm.flops += 2.0 * M * N * K * batch
+        tm.bytes += 4.0 * batch * (M * K + N * K + M * N * (1 + (aux is not None) + (residual is not None) + (pre_out is not None)))
         return out
     _lib.check(lib.rp_gemm(ctypes.byref(g), _st()), "rp_gemm")
     return out

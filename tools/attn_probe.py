@@ -16,5 +16,5 @@ qkv = torch.randn(M, 576, device="cuda"); do = torch.randn(M, 192, device="cuda"
 o, lse = ops.attn_fwd(qkv, Z)
 timeit(lambda: ops.attn_fwd(qkv, Z))
 for nw in sys.argv[1:]:
-    os.environ["RP_ATTN_NW"] = nw
+    os.environ["RP_ATTN_FWD"] = nw
     print("NW", nw, "fwd %.1f us  bwd %.1f us" % (timeit(lambda: ops.attn_fwd(qkv, Z)), timeit(lambda: ops.attn_bwd(qkv, o, lse, do, Z))), flush=True)

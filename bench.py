@@ -119,6 +119,9 @@ def main():
     ap.add_argument("--hw", type=int, default=384)
     ap.add_argument("--mode", default="train", choices=("train", "fwd"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step from captured HIP graphs (rel_pose_amd/graph.py) instead of launching eagerly; "
+                         "measured neutral at N=1 once the step had no host syncs left, so eager + DDP is the default")
     ap.add_argument("--scope", default="full", choices=("full", "hot"),
                     help="full = images -> CNN -> hot path (the metric); hot = synthetic CNN maps -> hot path only "
                          "(kernel profiling; not the headline number)")
@@ -149,9 +152,16 @@ def main():
     train = args.mode == "train"
     model.train(train)
     net = model
-    if world > 1 and train:
+    if world > 1 and train and not args.graph:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], find_unused_parameters=False)
-    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=5e-4, weight_decay=1e-5)
+    elif world > 1:
+        for t in list(model.parameters()) + list(model.buffers()):      # what DDP's constructor does: rank 0's replica everywhere
+            dist.broadcast(t.data, 0)
+    graphed = train and args.graph
+    if graphed:
+        net = model                                                    # the graphs do their own single flat all-reduce
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=5e-4, weight_decay=1e-5,
+                           capturable=graphed)
     images, poses, intr = synthetic_batch(args.batch, args.hw, dev, 1234 + rank)
     Ps = SE3(poses)
     Gs = SE3.IdentityLike(Ps)
@@ -181,6 +191,12 @@ def main():
 
     timer = ops.KernelTimer([int(v) for v in args.timer_instance.split(",")])
     ops.TIMER = timer
+    eager_step = step
+    if graphed:
+        from rel_pose_amd.graph import GraphedTrainStep
+        fwd = (lambda im, G, it: net(im, G, intrinsics=it))
+        gs = GraphedTrainStep(model, opt, images, poses, intr, forward_fn=fwd).capture(warmup=max(args.warmup, 3))
+        step = gs.step
     for _ in range(args.warmup):
         step()
 
@@ -213,6 +229,17 @@ def main():
         el = float(tt.item())
     finite = bool(torch.isfinite(last).all())
 
+    if graphed:
+        # per-kernel HIP events cannot be recorded inside a graph replay: time the roofline kernel over eager steps of the
+        # SAME step function, same resident batch, right after the timed region (rocprofv3 over this command sees both)
+        fence()
+        timer.enabled = True
+        for _ in range(max(2, min(5, args.steps))):
+            gs._fwd_bwd()
+            gs._exchange()
+            gs._update()
+        fence()
+        timer.enabled = False
     if rank == 0:
         n_launch, t_launch, flops = timer.summary()
         achieved = flops / max(n_launch, 1) / max(t_launch, 1e-12) / 1e12
@@ -234,6 +261,7 @@ def main():
                                    ", synthetic %dx%d pairs" % (args.hw, args.hw),
                        "scope": args.scope, "pairs_per_gpu": args.batch, "global_batch_pairs": world * args.batch,
                        "parallelism": "dp%d" % world, "finite": finite,
+                       "launch": "HIP graph replay (fwd+loss+bwd | flat grad all-reduce | clip+Adam)" if graphed else "eager",
                        "hot_path_share": "ViT+EMM+regressor on HIP kernels; ResNet front-end on MIOpen (SURVEY 8f-1)"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,

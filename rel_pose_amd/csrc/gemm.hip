@@ -36,6 +36,8 @@ struct GemmP {
   const float* residual;
   int epi_mode;
   int trans_c;
+  int abl;   // tuning aid (RP_GEMM_ABL bitmask): 1 = skip global loads + LDS stores after the first tile, 2 = skip barriers,
+             // 4 = skip LDS operand reads (reuse registers), 8 = skip the C store.  Results are garbage; timing only.
 };
 
 RP_DEV float epilogue(float v, int m, int n, const GemmP& p) {
@@ -68,6 +70,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   // panels mt = x (mod 8) and walks all N tiles of one panel back to back, so an A panel is pulled from
   // HBM/MALL into ONE L2 once and the weight panel stays L2-resident everywhere.
   const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
+  // persistent walk (large-M, non-split launches): a workgroup processes tiles xs, xs + stride, ... of its XCD's queue, so
+  // the C stores of one tile drain under the MFMAs of the next and no workgroup slot idles between dispatches
+  const bool walk = p.split_k == 1 && ntm >= 16;
+  const int xs_end = walk ? ntn * ((ntm + 7) / 8) : 1, xs_step = walk ? (int)(gridDim.x >> 3) : 1;
+  for (int xs = walk ? (int)(blockIdx.x >> 3) : 0; xs < xs_end; xs += xs_step) {
   int mt, nt;
   int zid = blockIdx.z;
   if (p.split_k > 1) {
@@ -81,10 +88,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     mt = t / ntn;
     nt = t % ntn;
   } else if (ntm >= 16) {
-    const int xs = blockIdx.x >> 3;
     mt = (xs / ntn) * 8 + (blockIdx.x & 7);
     nt = xs % ntn;
-    if (mt >= ntm) return;
+    if (mt >= ntm) continue;
   } else {                       // few row panels: plain order (the remap would park whole XCDs)
     mt = blockIdx.x / ntn;
     nt = blockIdx.x % ntn;
@@ -170,11 +176,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     sstore();
   }
   __syncthreads();
+  const int abl = p.abl;
+  float a[TM][8], b[TN][8];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) a[i][t] = 1.f;
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) b[j][t] = 1.f;
   for (int kt = 0; kt < nkt; ++kt) {
-    if (kt + 1 < nkt) gload(kt + 1);
+    if (kt + 1 < nkt && !(abl & 1)) gload(kt + 1);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-      float a[TM][8], b[TN][8];
+      if (!(abl & 4)) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         if (ALAY == 0) {
@@ -199,6 +215,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
           for (int t = 0; t < 8; ++t) b[j][t] = Bs[(16 * hi + 8 * half + t) * BN + wn0 + 32 * j + l31];
         }
       }
+      }
 #pragma unroll
       for (int t = 0; t < 8; ++t)
 #pragma unroll
@@ -206,10 +223,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 #pragma unroll
           for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(a[i][t], b[j][t], acc[i][j]);
     }
-    __syncthreads();
-    if (kt + 1 < nkt) {
+    if (!(abl & 2)) __syncthreads();
+    if (kt + 1 < nkt && !(abl & 1)) {
       sstore();
-      __syncthreads();
+      if (!(abl & 2)) __syncthreads();
     }
   }
 
@@ -231,7 +248,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     const int n = n0 + wn0 + 32 * j + l31;                                             \
     _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                   \
       const int m = m0 + wm0 + 32 * i + acc_row(r, hi);                                \
-      if (interior || (m < p.M && n < p.N)) {                                          \
+      if ((interior || (m < p.M && n < p.N)) && !(abl & 8)) {                          \
         const long long off = (long long)m * ldc + n;                                  \
         float v = acc[i][j][r];                                                        \
         BODY;                                                                          \
@@ -255,6 +272,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
       RP_EPI_LOOP(v = epilogue(v, m, n, q))
     }
   }
+  }  // persistent tile walk
 #undef RP_EPI_LOOP
 }
 
@@ -280,7 +298,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, const float
 template <int ALAY, int BLAY, int TM, int TN>
 int launch(const GemmP& p, int nz, hipStream_t st) {
   const int ntn = (p.N + 64 * TN - 1) / (64 * TN), ntm = (p.M + 64 * TM - 1) / (64 * TM);
-  dim3 grid(ntm >= 16 ? ntn * ((ntm + 7) / 8) * 8 : ntn * ntm, 1, nz);
+  int gx = ntm >= 16 ? ntn * ((ntm + 7) / 8) * 8 : ntn * ntm;
+  if (ntm >= 16 && p.split_k == 1) {
+    int per_cu = 6;                                     // resident workgroups per CU to aim for (tuning aid below)
+    if (const char* ov = getenv("RP_GEMM_WGS_PER_CU")) per_cu = atoi(ov);
+    if (per_cu > 0) gx = min(gx, 256 * per_cu);
+    gx = (gx + 7) / 8 * 8;
+  }
+  dim3 grid(gx, 1, nz);
   if (p.split_k > 1) grid = dim3(ntn * ntm * ((p.split_k + 7) / 8) * 8, 1, 1);
   hipLaunchKernelGGL((gemm_kernel<ALAY, BLAY, TM, TN>), grid, dim3(256), 0, st, p);
   return 0;
@@ -341,6 +366,8 @@ extern "C" int rp_gemm(const RpGemm* g, void* stream) {
     p.epi_mode = m;
   }
   p.trans_c = g->trans_c;
+  p.abl = 0;
+  if (const char* ab = getenv("RP_GEMM_ABL")) p.abl = atoi(ab);
   if (g->trans_c && (split == 1 || g->bias || g->pre_out || g->aux || g->residual)) return RP_EUNSUPPORTED;
   // tile shape (TM,TN) = wave tile in 32x32 units; measured on MI355X (tools/gemm_tiles.py): with fp32 MFMA (64
   // cycles per 32x32x2) operand reuse is cheap and occupancy wins -- 128x64 / 64x192 tiles beat 128x192.

@@ -1,25 +1,28 @@
 """Geodesic pose loss (reference src/geom/losses.py:3-21), over rel_pose_amd.se3.SE3.  Parity with lietorch's
-arithmetic is unpinned (see se3.py)."""
+arithmetic is unpinned (see se3.py).
+
+The reference indexes with ii=[0,1], jj=[1,0] (tensor indices -> host-to-device copies every call); here the same
+selection is ``flip(1)``, which keeps the step free of host syncs and capturable in a HIP graph."""
 import torch
 
+from .se3 import SE3
 
-def geodesic_loss(Ps, Gs, train_val="train"):
-    ii, jj = torch.tensor([0, 1]), torch.tensor([1, 0])
-    dP = Ps[:, jj] * Ps[:, ii].inv()
-    dG = Gs[0][:, jj] * Gs[0][:, ii].inv()
-    d = (dG * dP.inv()).log()
-    tau, phi = d.split([3, 3], dim=-1)
-    loss_tr = tau.norm(dim=-1).mean()
-    loss_rot = phi.norm(dim=-1).mean()
-    metrics = {train_val + "_geo_loss_tr": loss_tr.detach().item(),
-               train_val + "_geo_loss_rot": loss_rot.detach().item()}
-    return loss_tr, loss_rot, metrics
+
+def _pair_swap(G):
+    """G[:, [1, 0]]"""
+    return SE3(G.data.flip(1))
 
 
 def geodesic_loss_tensors(Ps, Gs):
-    """Same without the .item() host syncs (bench / graph-friendly)."""
-    ii, jj = [0, 1], [1, 0]
-    dP = Ps[:, jj] * Ps[:, ii].inv()
-    dG = Gs[0][:, jj] * Gs[0][:, ii].inv()
+    """(translation, rotation) geodesic losses as device scalars -- no .item(), no host sync."""
+    dP = _pair_swap(Ps) * Ps.inv()
+    dG = _pair_swap(Gs[0]) * Gs[0].inv()
     tau, phi = (dG * dP.inv()).log().split([3, 3], dim=-1)
     return tau.norm(dim=-1).mean(), phi.norm(dim=-1).mean()
+
+
+def geodesic_loss(Ps, Gs, train_val="train"):
+    loss_tr, loss_rot = geodesic_loss_tensors(Ps, Gs)
+    metrics = {train_val + "_geo_loss_tr": loss_tr.detach().item(),
+               train_val + "_geo_loss_rot": loss_rot.detach().item()}
+    return loss_tr, loss_rot, metrics

@@ -58,23 +58,28 @@ class ViTEss(nn.Module):
         # 24.1 -> 20.1 ms fwd+bwd at 128 images) and the [2B,24,24,192] map IS the token layout (src/model.py:136-141)
         self.resnet.to(memory_format=torch.channels_last)
         self.extractor_final_conv.to(memory_format=torch.channels_last)
+        # ImageNet statistics as (non-persistent) buffers: no per-call host-to-device copies, state_dict unchanged
+        self.register_buffer("_mean", torch.tensor([0.485, 0.456, 0.406]).view(3, 1, 1), persistent=False)
+        self.register_buffer("_std", torch.tensor([0.229, 0.224, 0.225]).view(3, 1, 1), persistent=False)
+        self._intr_scale = {}
 
     # -- src/model.py:100-109 ---------------------------------------------------------------------
     def update_intrinsics(self, input_shape, intrinsics):
         sizey, sizex = self.feature_resolution
-        scalex = sizex / input_shape[-1]
-        scaley = sizey / input_shape[-2]
-        intrinsics[:, :, [0, 2]] = scalex * intrinsics[:, :, [0, 2]]
-        intrinsics[:, :, [1, 3]] = scaley * intrinsics[:, :, [1, 3]]
+        key = (int(input_shape[-2]), int(input_shape[-1]), str(intrinsics.device), intrinsics.dtype)
+        sc = self._intr_scale.get(key)
+        if sc is None:          # (sx, sy, sx, sy): same fp32 products as the reference's two index_put_ lines, no index tensors
+            scalex, scaley = sizex / input_shape[-1], sizey / input_shape[-2]
+            sc = torch.tensor([scalex, scaley, scalex, scaley], dtype=intrinsics.dtype, device=intrinsics.device)
+            self._intr_scale[key] = sc
+        intrinsics.mul_(sc)     # in place on the CALLER's tensor, like the reference
         return intrinsics
 
     # -- src/model.py:111-143 ---------------------------------------------------------------------
     def cnn_map(self, images, intrinsics=None):
         """preprocessing + CNN front-end -> [2B,192,24,24] (PyTorch-ROCm / MIOpen: 'next' row 8f-1)."""
-        images = images[:, :, [2, 1, 0]] / 255.0
-        mean = torch.as_tensor([0.485, 0.456, 0.406], device=images.device)
-        std = torch.as_tensor([0.229, 0.224, 0.225], device=images.device)
-        images = images.sub_(mean[:, None, None]).div_(std[:, None, None])
+        images = images.flip(2) / 255.0                      # BGR -> RGB == images[:, :, [2, 1, 0]]
+        images = images.sub_(self._mean).div_(self._std)
         if intrinsics is not None:
             intrinsics = self.update_intrinsics(images.shape, intrinsics)
         x = F.interpolate(self.flatten(images), size=224).contiguous(memory_format=torch.channels_last)

@@ -36,8 +36,6 @@ struct GemmP {
   const float* residual;
   int epi_mode;
   int trans_c;
-  int abl;   // tuning aid (RP_GEMM_ABL bitmask): 1 = skip global loads + LDS stores after the first tile, 2 = skip barriers,
-             // 4 = skip LDS operand reads (reuse registers), 8 = skip the C store.  Results are garbage; timing only.
 };
 
 RP_DEV float epilogue(float v, int m, int n, const GemmP& p) {
@@ -59,7 +57,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   constexpr int A_FLOATS = ALAY == 0 ? BM * KST : BK * BM;
   constexpr int B_FLOATS = BLAY == 0 ? BN * KST : BK * BN;
   constexpr int NA = BM / 32, NB = BN / 32;         // float4 per thread per k-tile
-  __shared__ __attribute__((aligned(16))) float lds[A_FLOATS + B_FLOATS];
+  constexpr int STAGE = A_FLOATS + B_FLOATS;
+  constexpr int CST = 32 * TN + 4;                  // row stride of a wave's C tile staged in LDS for the epilogue
+  constexpr int C_FLOATS = 4 * 32 * TM * CST;
+  // the weight-gradient layout writes small split-K slabs: staging them would only cost LDS (51 KB vs 32 KB -> 3 instead
+  // of 5 workgroups per CU, measured 199 -> 278 us), so it keeps the direct dword epilogue
+  constexpr bool STAGED = !(ALAY == 1 && BLAY == 1);
+  constexpr int LDS_FLOATS = (STAGED && C_FLOATS > STAGE) ? C_FLOATS : STAGE;
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
   float* As = lds;
   float* Bs = lds + A_FLOATS;
 
@@ -70,11 +75,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   // panels mt = x (mod 8) and walks all N tiles of one panel back to back, so an A panel is pulled from
   // HBM/MALL into ONE L2 once and the weight panel stays L2-resident everywhere.
   const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
-  // persistent walk (large-M, non-split launches): a workgroup processes tiles xs, xs + stride, ... of its XCD's queue, so
-  // the C stores of one tile drain under the MFMAs of the next and no workgroup slot idles between dispatches
-  const bool walk = p.split_k == 1 && ntm >= 16;
-  const int xs_end = walk ? ntn * ((ntm + 7) / 8) : 1, xs_step = walk ? (int)(gridDim.x >> 3) : 1;
-  for (int xs = walk ? (int)(blockIdx.x >> 3) : 0; xs < xs_end; xs += xs_step) {
   int mt, nt;
   int zid = blockIdx.z;
   if (p.split_k > 1) {
@@ -88,9 +88,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     mt = t / ntn;
     nt = t % ntn;
   } else if (ntm >= 16) {
+    const int xs = blockIdx.x >> 3;
     mt = (xs / ntn) * 8 + (blockIdx.x & 7);
     nt = xs % ntn;
-    if (mt >= ntm) continue;
+    if (mt >= ntm) return;
   } else {                       // few row panels: plain order (the remap would park whole XCDs)
     mt = blockIdx.x / ntn;
     nt = blockIdx.x % ntn;
@@ -150,18 +151,49 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
       rb[j] = v;
     }
   };
-  auto sstore = [&]() {
+  auto sstore = [&](int stage = 0) {
+    float* as = As + stage * STAGE;
+    float* bs = Bs + stage * STAGE;
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
       const int f = tid + 256 * j;
-      if (ALAY == 0) st4(As + (f >> 3) * KST + (f & 7) * 4, ra[j]);
-      else st4(As + (f / (BM / 4)) * BM + (f % (BM / 4)) * 4, ra[j]);
+      if (ALAY == 0) st4(as + (f >> 3) * KST + (f & 7) * 4, ra[j]);
+      else st4(as + (f / (BM / 4)) * BM + (f % (BM / 4)) * 4, ra[j]);
     }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int f = tid + 256 * j;
-      if (BLAY == 0) st4(Bs + (f >> 3) * KST + (f & 7) * 4, rb[j]);
-      else st4(Bs + (f / (BN / 4)) * BN + (f % (BN / 4)) * 4, rb[j]);
+      if (BLAY == 0) st4(bs + (f >> 3) * KST + (f & 7) * 4, rb[j]);
+      else st4(bs + (f / (BN / 4)) * BN + (f % (BN / 4)) * 4, rb[j]);
+    }
+  };
+  // MFMA operand fragments of one half k-tile (8 k-steps) from LDS stage `stage`
+  auto fload = [&](int stage, int half, float (&a)[TM][8], float (&b)[TN][8]) {
+    const float* as = As + stage * STAGE;
+    const float* bs = Bs + stage * STAGE;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      if (ALAY == 0) {
+        const float* s_ = as + (wm0 + 32 * i + l31) * KST + 16 * hi + 8 * half;
+        const float4 x = ld4(s_), y = ld4(s_ + 4);
+        a[i][0] = x.x; a[i][1] = x.y; a[i][2] = x.z; a[i][3] = x.w;
+        a[i][4] = y.x; a[i][5] = y.y; a[i][6] = y.z; a[i][7] = y.w;
+      } else {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) a[i][t] = as[(16 * hi + 8 * half + t) * BM + wm0 + 32 * i + l31];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      if (BLAY == 0) {
+        const float* s_ = bs + (wn0 + 32 * j + l31) * KST + 16 * hi + 8 * half;
+        const float4 x = ld4(s_), y = ld4(s_ + 4);
+        b[j][0] = x.x; b[j][1] = x.y; b[j][2] = x.z; b[j][3] = x.w;
+        b[j][4] = y.x; b[j][5] = y.y; b[j][6] = y.z; b[j][7] = y.w;
+      } else {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) b[j][t] = bs[(16 * hi + 8 * half + t) * BN + wn0 + 32 * j + l31];
+      }
     }
   };
 
@@ -176,46 +208,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     sstore();
   }
   __syncthreads();
-  const int abl = p.abl;
-  float a[TM][8], b[TN][8];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int t = 0; t < 8; ++t) a[i][t] = 1.f;
-#pragma unroll
-  for (int j = 0; j < TN; ++j)
-#pragma unroll
-    for (int t = 0; t < 8; ++t) b[j][t] = 1.f;
   for (int kt = 0; kt < nkt; ++kt) {
-    if (kt + 1 < nkt && !(abl & 1)) gload(kt + 1);
+    if (kt + 1 < nkt) gload(kt + 1);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-      if (!(abl & 4)) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        if (ALAY == 0) {
-          const float* s = As + (wm0 + 32 * i + l31) * KST + 16 * hi + 8 * half;
-          const float4 x = ld4(s), y = ld4(s + 4);
-          a[i][0] = x.x; a[i][1] = x.y; a[i][2] = x.z; a[i][3] = x.w;
-          a[i][4] = y.x; a[i][5] = y.y; a[i][6] = y.z; a[i][7] = y.w;
-        } else {
-#pragma unroll
-          for (int t = 0; t < 8; ++t) a[i][t] = As[(16 * hi + 8 * half + t) * BM + wm0 + 32 * i + l31];
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        if (BLAY == 0) {
-          const float* s = Bs + (wn0 + 32 * j + l31) * KST + 16 * hi + 8 * half;
-          const float4 x = ld4(s), y = ld4(s + 4);
-          b[j][0] = x.x; b[j][1] = x.y; b[j][2] = x.z; b[j][3] = x.w;
-          b[j][4] = y.x; b[j][5] = y.y; b[j][6] = y.z; b[j][7] = y.w;
-        } else {
-#pragma unroll
-          for (int t = 0; t < 8; ++t) b[j][t] = Bs[(16 * hi + 8 * half + t) * BN + wn0 + 32 * j + l31];
-        }
-      }
-      }
+      float a[TM][8], b[TN][8];
+      fload(0, half, a, b);
 #pragma unroll
       for (int t = 0; t < 8; ++t)
 #pragma unroll
@@ -223,10 +221,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 #pragma unroll
           for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(a[i][t], b[j][t], acc[i][j]);
     }
-    if (!(abl & 2)) __syncthreads();
-    if (kt + 1 < nkt && !(abl & 1)) {
+    __syncthreads();
+    if (kt + 1 < nkt) {
       sstore();
-      if (!(abl & 2)) __syncthreads();
+      __syncthreads();
     }
   }
 
@@ -242,13 +240,60 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   const int mode = partial ? EPI_RAW : p.epi_mode;
   const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N);
 
+  if (STAGED && (p.N & 3) == 0 && mode != EPI_GENERIC) {
+    // LDS-staged epilogue: the accumulators (lane = column, register = row) are transposed through the wave's own LDS
+    // region so that every global access of the epilogue -- C, bias, residual, GELU'/ReLU' aux, pre-activation copy -- is a
+    // 16-byte row segment per lane (global_load/store_dwordx4) instead of 16*TM*TN dword accesses per lane.  Ablation:
+    // the dword store tail alone was 11 % of the kernel; dword aux/residual loads serialised at 96 per lane.
+    float* cs = lds + wave * (32 * TM * CST);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cs[(32 * i + acc_row(r, hi)) * CST + 32 * j + l31] = acc[i][j][r];
+    __syncthreads();
+    constexpr int C4 = 8 * TN;             // float4 per staged row
+#pragma unroll
+    for (int it = 0; it < (32 * TM * C4) / 64; ++it) {
+      const int idx = lane + 64 * it;
+      const int row = idx / C4, c4 = idx % C4;
+      const int m = m0 + wm0 + row, n = n0 + wn0 + 4 * c4;
+      if ((interior || (m < p.M && n < p.N))) {
+        float4 v = ld4(cs + row * CST + 4 * c4);
+        const long long off = (long long)m * ldc + n;
+        if (mode == EPI_BIAS || mode == EPI_BIAS_RES || mode == EPI_BIAS_GELU || mode == EPI_BIAS_GELU_PRE ||
+            mode == EPI_BIAS_RELU) {
+          const float4 b4 = ld4(bias + n);
+          v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+        }
+        if (mode == EPI_BIAS_GELU_PRE) st4(pre_out + off, v);
+        if (mode == EPI_BIAS_GELU || mode == EPI_BIAS_GELU_PRE) {
+          v.x = gelu_exact(v.x); v.y = gelu_exact(v.y); v.z = gelu_exact(v.z); v.w = gelu_exact(v.w);
+        } else if (mode == EPI_BIAS_RELU) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        } else if (mode == EPI_DGELU) {
+          const float4 a4 = ld4(aux + off);
+          v.x *= gelu_grad(a4.x); v.y *= gelu_grad(a4.y); v.z *= gelu_grad(a4.z); v.w *= gelu_grad(a4.w);
+        } else if (mode == EPI_DRELU) {
+          const float4 a4 = ld4(aux + off);
+          v.x = a4.x > 0.f ? v.x : 0.f; v.y = a4.y > 0.f ? v.y : 0.f; v.z = a4.z > 0.f ? v.z : 0.f; v.w = a4.w > 0.f ? v.w : 0.f;
+        }
+        if (mode == EPI_BIAS_RES || mode == EPI_RES) {
+          const float4 r4 = ld4(res + off);
+          v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+        }
+        st4(C + off, v);
+      }
+    }
+  } else {
 #define RP_EPI_LOOP(BODY)                                                              \
   _Pragma("unroll") for (int i = 0; i < TM; ++i)                                       \
   _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                     \
     const int n = n0 + wn0 + 32 * j + l31;                                             \
     _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                   \
       const int m = m0 + wm0 + 32 * i + acc_row(r, hi);                                \
-      if ((interior || (m < p.M && n < p.N)) && !(abl & 8)) {                          \
+      if ((interior || (m < p.M && n < p.N))) {                          \
         const long long off = (long long)m * ldc + n;                                  \
         float v = acc[i][j][r];                                                        \
         BODY;                                                                          \
@@ -256,23 +301,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
       }                                                                                \
     }                                                                                  \
   }
-  switch (mode) {
-    case EPI_RAW: RP_EPI_LOOP((void)0) break;
-    case EPI_BIAS: RP_EPI_LOOP(v += bias[n]) break;
-    case EPI_BIAS_RES: RP_EPI_LOOP(v += bias[n] + res[off]) break;
-    case EPI_RES: RP_EPI_LOOP(v += res[off]) break;
-    case EPI_BIAS_GELU: RP_EPI_LOOP(v = gelu_exact(v + bias[n])) break;
-    case EPI_BIAS_GELU_PRE: RP_EPI_LOOP(v += bias[n]; pre_out[off] = v; v = gelu_exact(v)) break;
-    case EPI_BIAS_RELU: RP_EPI_LOOP(v = fmaxf(v + bias[n], 0.f)) break;
-    case EPI_DGELU: RP_EPI_LOOP(v *= gelu_grad(aux[off])) break;
-    case EPI_DRELU: RP_EPI_LOOP(v = aux[off] > 0.f ? v : 0.f) break;
-    default: {
-      GemmP q = p;
-      q.pre_out = pre_out; q.aux = aux; q.residual = res;
-      RP_EPI_LOOP(v = epilogue(v, m, n, q))
-    }
+  if (mode == EPI_RAW) {
+    RP_EPI_LOOP((void)0)
+  } else {
+    GemmP q = p;
+    q.pre_out = pre_out; q.aux = aux; q.residual = res;
+    RP_EPI_LOOP(v = epilogue(v, m, n, q))
   }
-  }  // persistent tile walk
+  }
 #undef RP_EPI_LOOP
 }
 
@@ -298,14 +334,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, const float
 template <int ALAY, int BLAY, int TM, int TN>
 int launch(const GemmP& p, int nz, hipStream_t st) {
   const int ntn = (p.N + 64 * TN - 1) / (64 * TN), ntm = (p.M + 64 * TM - 1) / (64 * TM);
-  int gx = ntm >= 16 ? ntn * ((ntm + 7) / 8) * 8 : ntn * ntm;
-  if (ntm >= 16 && p.split_k == 1) {
-    int per_cu = 6;                                     // resident workgroups per CU to aim for (tuning aid below)
-    if (const char* ov = getenv("RP_GEMM_WGS_PER_CU")) per_cu = atoi(ov);
-    if (per_cu > 0) gx = min(gx, 256 * per_cu);
-    gx = (gx + 7) / 8 * 8;
-  }
-  dim3 grid(gx, 1, nz);
+  dim3 grid(ntm >= 16 ? ntn * ((ntm + 7) / 8) * 8 : ntn * ntm, 1, nz);
   if (p.split_k > 1) grid = dim3(ntn * ntm * ((p.split_k + 7) / 8) * 8, 1, 1);
   hipLaunchKernelGGL((gemm_kernel<ALAY, BLAY, TM, TN>), grid, dim3(256), 0, st, p);
   return 0;
@@ -366,8 +395,6 @@ extern "C" int rp_gemm(const RpGemm* g, void* stream) {
     p.epi_mode = m;
   }
   p.trans_c = g->trans_c;
-  p.abl = 0;
-  if (const char* ab = getenv("RP_GEMM_ABL")) p.abl = atoi(ab);
   if (g->trans_c && (split == 1 || g->bias || g->pre_out || g->aux || g->residual)) return RP_EUNSUPPORTED;
   // tile shape (TM,TN) = wave tile in 32x32 units; measured on MI355X (tools/gemm_tiles.py): with fp32 MFMA (64
   // cycles per 32x32x2) operand reuse is cheap and occupancy wins -- 128x64 / 64x192 tiles beat 128x192.

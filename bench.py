@@ -133,11 +133,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node N" % (args.gpus, world))
+    if os.environ.get("RP_BENCH_SHARE_GPU"):      # functional test of the N>1 path on a 1-GPU box (gloo, all ranks on cuda:0)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank)
+        dist.init_process_group(backend=os.environ.get("RP_DIST_BACKEND", "nccl"), init_method="env://",
+                                world_size=world, rank=rank)
 
     from rel_pose_amd import _lib, ops
     from rel_pose_amd.losses import geodesic_loss_tensors
@@ -154,6 +157,7 @@ def main():
     net = model
     if world > 1 and train and not args.graph:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], find_unused_parameters=False)
+        # (reference train.py:66-67; bucketed all-reduce of the 19.26 M trainable grads overlaps the backward)
     elif world > 1:
         for t in list(model.parameters()) + list(model.buffers()):      # what DDP's constructor does: rank 0's replica everywhere
             dist.broadcast(t.data, 0)

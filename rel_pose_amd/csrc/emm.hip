@@ -34,17 +34,19 @@ struct EmmP {
   int H; float scale; int swap; int ZH;
 };
 
-RP_DEV void kv_gload(const float* base, int ld, int tid, float4 (&r)[3]) {
+template <int NTH>
+RP_DEV void kv_gload(const float* base, int ld, int tid, float4 (&r)[(512 + NTH - 1) / NTH]) {
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const int f = min(tid + NT * j, 511);     // surplus threads duplicate the last element (no exec-masked guard)
+  for (int j = 0; j < (512 + NTH - 1) / NTH; ++j) {
+    const int f = min(tid + NTH * j, 511);     // surplus threads duplicate the last element (no exec-masked guard)
     r[j] = ld4(base + (long long)(f >> 4) * ld + (f & 15) * 4);
   }
 }
-RP_DEV void kv_sstore(float* s, int tid, const float4 (&r)[3]) {
+template <int NTH>
+RP_DEV void kv_sstore(float* s, int tid, const float4 (&r)[(512 + NTH - 1) / NTH]) {
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const int f = min(tid + NT * j, 511);
+  for (int j = 0; j < (512 + NTH - 1) / NTH; ++j) {
+    const int f = min(tid + NTH * j, 511);
     st4(s + (f >> 4) * KST + (f & 15) * 4, r[j]);
   }
 }
@@ -72,7 +74,7 @@ RP_DEV void load_owner(const float* row_ptr, int hi, float mul, float (&reg)[32]
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void emm_apply_kernel(EmmP p) {
+__global__ __launch_bounds__(NT, 3) void emm_apply_kernel(EmmP p) {
   // LDS carve: loop phase  Ks[2][32*68] | Xs[2][32*96] | Cl[2][32]   (10560 floats)
   //            F phase     Ts[96][96]                                   ( 9216 floats, aliases the above)
   __shared__ __attribute__((aligned(16))) float lds[2 * 32 * KST + 2 * 32 * XW + 64];
@@ -108,10 +110,10 @@ __global__ __launch_bounds__(NT) void emm_apply_kernel(EmmP p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) st4(s + (tid + NT * j) * 4, xpre[j]);
   };
-  kv_gload(lb, p.ld, tid, kpre);
+  kv_gload<NT>(lb, p.ld, tid, kpre);
   x_gload(0);
   if (tid < 32) cpre = loop_lse[tid] * RP_LOG2E;
-  kv_sstore(Ks, tid, kpre);
+  kv_sstore<NT>(Ks, tid, kpre);
   x_sstore(Xs);
   if (tid < 32) Cl[tid] = cpre;
   __syncthreads();
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(NT) void emm_apply_kernel(EmmP p) {
   for (int t = 0; t < NTILE; ++t) {
     const int cur = t & 1;
     if (t + 1 < NTILE) {
-      kv_gload(lb + (long long)(t + 1) * 32 * p.ld, p.ld, tid, kpre);
+      kv_gload<NT>(lb + (long long)(t + 1) * 32 * p.ld, p.ld, tid, kpre);
       x_gload(t + 1);
       if (tid < 32) cpre = loop_lse[(t + 1) * 32 + tid] * RP_LOG2E;
     }
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(NT) void emm_apply_kernel(EmmP p) {
       tacc[2] = mfma32(s[r], xr[64], tacc[2]);
     }
     if (t + 1 < NTILE) {
-      kv_sstore(Ks + (cur ^ 1) * 32 * KST, tid, kpre);
+      kv_sstore<NT>(Ks + (cur ^ 1) * 32 * KST, tid, kpre);
       x_sstore(Xs + (cur ^ 1) * 32 * XW);
       if (tid < 32) Cl[(cur ^ 1) * 32 + tid] = cpre;
     }
@@ -182,15 +184,17 @@ __global__ __launch_bounds__(NT) void emm_apply_kernel(EmmP p) {
 constexpr int XG = 72;       // live columns of X / W used by the dA contraction (70 rounded up to even, x4)
 constexpr int XGS = 76;      // LDS row stride for the X tile read along c with ds_read_b128
 
-__global__ __launch_bounds__(NT) void emm_grad_kernel(EmmP p) {
+// 2-wave workgroups: the kernel needs ~250 VGPRs (2 waves/SIMD = 8 wave slots per CU); 4 x 2 waves fill them, 2 x 3 do not
+constexpr int GW = 2, GT = GW * 64;
+__global__ __launch_bounds__(GT, 2) void emm_grad_kernel(EmmP p) {
   __shared__ __attribute__((aligned(16))) float Ks[2][32 * KST];
   __shared__ __attribute__((aligned(16))) float Xs[2][32 * XGS];
   __shared__ float Ll[2][64];   // loop-side lse [0..31] and rho/gamma [32..63]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   int zh_, wgi;
-  if (!xcd_problem(NTILE / NW, p.ZH, zh_, wgi)) return;
+  if (!xcd_problem(NTILE / GW, p.ZH, zh_, wgi)) return;
   const int h = zh_ % p.H, z = zh_ / p.H;
-  const int o0 = (wgi * NW + wave) * 32;
+  const int o0 = (wgi * GW + wave) * 32;
   const int own_img = p.swap ? z : (z ^ 1), own_col = (p.swap ? 192 : 0) + h * 64;
   const int loop_img = p.swap ? (z ^ 1) : z, loop_col = (p.swap ? 0 : 192) + h * 64;
   const long long zh = (long long)z * p.H + h;
@@ -214,26 +218,26 @@ __global__ __launch_bounds__(NT) void emm_grad_kernel(EmmP p) {
   const float ls_o = own_lse[o0 + l31] * RP_LOG2E, g_o = own_g[o0 + l31];
 
   f32x16 d0 = zero16(), d1 = zero16();
-  float4 kpre[3], xpre[3];
+  float4 kpre[(512 + GT - 1) / GT], xpre[(576 + GT - 1) / GT];
   float lpre = 0.f;
   auto x_gload = [&](int t) {   // 32 rows x 18 float4 (72 cols) = 576 float4 -> 3 per thread
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int f = tid + NT * j;
+    for (int j = 0; j < (576 + GT - 1) / GT; ++j) {
+      const int f = min(tid + GT * j, 575);
       xpre[j] = ld4(xb + ((long long)t * 32 + f / 18) * XW + (f % 18) * 4);
     }
   };
   auto x_sstore = [&](float* s) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int f = tid + NT * j;
+    for (int j = 0; j < (576 + GT - 1) / GT; ++j) {
+      const int f = min(tid + GT * j, 575);
       st4(s + (f / 18) * XGS + (f % 18) * 4, xpre[j]);
     }
   };
-  kv_gload(lb, p.ld, tid, kpre);
+  kv_gload<GT>(lb, p.ld, tid, kpre);
   x_gload(0);
   if (tid < 64) lpre = tid < 32 ? loop_lse[tid] * RP_LOG2E : loop_g[tid - 32];
-  kv_sstore(Ks[0], tid, kpre);
+  kv_sstore<GT>(Ks[0], tid, kpre);
   x_sstore(Xs[0]);
   if (tid < 64) Ll[0][tid] = lpre;
   __syncthreads();
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(NT) void emm_grad_kernel(EmmP p) {
   for (int t = 0; t < NTILE; ++t) {
     const int cur = t & 1;
     if (t + 1 < NTILE) {
-      kv_gload(lb + (long long)(t + 1) * 32 * p.ld, p.ld, tid, kpre);
+      kv_gload<GT>(lb + (long long)(t + 1) * 32 * p.ld, p.ld, tid, kpre);
       x_gload(t + 1);
       if (tid < 64) lpre = tid < 32 ? loop_lse[(t + 1) * 32 + tid] * RP_LOG2E : loop_g[(t + 1) * 32 + tid - 32];
     }
@@ -273,7 +277,7 @@ __global__ __launch_bounds__(NT) void emm_grad_kernel(EmmP p) {
       d1 = mfma32(kr[32], s[r], d1);
     }
     if (t + 1 < NTILE) {
-      kv_sstore(Ks[cur ^ 1], tid, kpre);
+      kv_sstore<GT>(Ks[cur ^ 1], tid, kpre);
       x_sstore(Xs[cur ^ 1]);
       if (tid < 64) Ll[cur ^ 1][tid] = lpre;
     }
@@ -308,7 +312,7 @@ extern "C" int rp_emm_grad(const float* qkv, int ldqkv, const float* x, const fl
   EmmP p{};
   p.qkv = qkv; p.ld = ldqkv; p.x = x; p.w = w; p.rlse = rlse; p.clse = clse; p.rho = rho; p.gamma = gamma;
   p.dqkv = dqkv; p.H = H; p.scale = scale; p.swap = swap ? 1 : 0; p.ZH = Z * H;
-  hipLaunchKernelGGL(emm_grad_kernel, dim3(xcd_grid(NTILE / NW, Z * H)), dim3(NT), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(emm_grad_kernel, dim3(xcd_grid(NTILE / GW, Z * H)), dim3(GT), 0, (hipStream_t)stream, p);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }

@@ -106,6 +106,12 @@ int rp_attn_bwd_delta(const float* dout, const float* o, float* delta, int Z, in
 int rp_attn_bwd(const float* q, const float* k, const float* v, const float* dout, const float* lse, const float* delta,
                 float* dq, float* dk, float* dv, int Z, int H, int ldq, int ldk, int ldv, int lddo, int lddq, int lddk,
                 int lddv, float scale, void* stream);
+/* the two passes of rp_attn_bwd separately (they are independent; the host overlaps them on two HIP streams) */
+int rp_attn_bwd_dkdv(const float* q, const float* k, const float* v, const float* dout, const float* lse,
+                     const float* delta, float* dk, float* dv, int Z, int H, int ldq, int ldk, int ldv, int lddo, int lddk,
+                     int lddv, float scale, void* stream);
+int rp_attn_bwd_dq(const float* q, const float* k, const float* v, const float* dout, const float* lse, const float* delta,
+                   float* dq, int Z, int H, int ldq, int ldk, int ldv, int lddo, int lddq, float scale, void* stream);
 
 /* Quadratic positional features (closed form of get_positional_encodings, vision_transformer.py:90-158):
  * pos[b][n] = (p3^2, p4^2, p3 p4, p3, p4, 1), p3 = lin[n%24]*iy_b, p4 = lin[n/24]*ix_b,

@@ -42,6 +42,8 @@ _SIGS = {
     "rp_attn_fwd": (c_int, [P, P, P, P, P, I, I, I, I, I, I, I, I, F, I, P]),
     "rp_attn_bwd_delta": (c_int, [P, P, P, I, I, I, P]),
     "rp_attn_bwd": (c_int, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, P]),
+    "rp_attn_bwd_dkdv": (c_int, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, F, P]),
+    "rp_attn_bwd_dq": (c_int, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, F, P]),
     "rp_posenc": (c_int, [P, P, P, I, P]),
     "rp_emm_build_x": (c_int, [P, P, P, I, I, I, P]),
     "rp_emm_build_x_bwd": (c_int, [P, P, I, I, I, P]),

@@ -382,24 +382,45 @@ extern "C" int rp_attn_fwd(const float* q, const float* k, const float* v, float
   return RP_OK;
 }
 
+// which: 1 = dK,dV pass, 2 = dQ pass, 3 = both (the passes are independent: callers may put them on different streams)
 template <int NW>
-static int launch_bwd(const AttnBwdP& p, int Z, int H, hipStream_t st) {
+static int launch_bwd(const AttnBwdP& p, int Z, int H, int which, hipStream_t st) {
   dim3 grid(xcd_grid(NTILE / NW, Z * H));
-  hipLaunchKernelGGL((attn_bwd_dkdv_kernel<NW, 2>), grid, dim3(NW * 64), 0, st, p);
-  RP_CHECK_LAUNCH();
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<NW, 2>), grid, dim3(NW * 64), 0, st, p);
-  RP_CHECK_LAUNCH();
+  if (which & 1) {
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<NW, 2>), grid, dim3(NW * 64), 0, st, p);
+    RP_CHECK_LAUNCH();
+  }
+  if (which & 2) {
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<NW, 2>), grid, dim3(NW * 64), 0, st, p);
+    RP_CHECK_LAUNCH();
+  }
   return RP_OK;
 }
 
-extern "C" int rp_attn_bwd(const float* q, const float* k, const float* v, const float* dout, const float* lse,
-                           const float* delta, float* dq, float* dk, float* dv, int Z, int H, int ldq, int ldk, int ldv,
-                           int lddo, int lddq, int lddk, int lddv, float scale, void* stream) {
+static int attn_bwd_impl(const float* q, const float* k, const float* v, const float* dout, const float* lse,
+                         const float* delta, float* dq, float* dk, float* dv, int Z, int H, int ldq, int ldk, int ldv,
+                         int lddo, int lddq, int lddk, int lddv, float scale, int which, void* stream) {
   if (Z <= 0 || H <= 0) return RP_EBADSHAPE;
   if ((ldq | ldk | ldv | lddo | lddq | lddk | lddv) & 3) return RP_EALIGN;
   AttnBwdP p{q, k, v, dout, lse, delta, dq, dk, dv, H, ldq, ldk, ldv, lddo, lddq, lddk, lddv, scale, Z * H};
   // both passes need ~190-240 VGPRs (2 waves/SIMD = 8 wave slots per CU): 2-wave workgroups pack 4 per CU, 3-wave ones only 2
   const char* ov = getenv("RP_ATTN_NW");
-  if (ov && ov[0] == '3') return launch_bwd<3>(p, Z, H, (hipStream_t)stream);
-  return launch_bwd<2>(p, Z, H, (hipStream_t)stream);
+  if (ov && ov[0] == '3') return launch_bwd<3>(p, Z, H, which, (hipStream_t)stream);
+  return launch_bwd<2>(p, Z, H, which, (hipStream_t)stream);
+}
+
+extern "C" int rp_attn_bwd(const float* q, const float* k, const float* v, const float* dout, const float* lse,
+                           const float* delta, float* dq, float* dk, float* dv, int Z, int H, int ldq, int ldk, int ldv,
+                           int lddo, int lddq, int lddk, int lddv, float scale, void* stream) {
+  return attn_bwd_impl(q, k, v, dout, lse, delta, dq, dk, dv, Z, H, ldq, ldk, ldv, lddo, lddq, lddk, lddv, scale, 3, stream);
+}
+extern "C" int rp_attn_bwd_dkdv(const float* q, const float* k, const float* v, const float* dout, const float* lse,
+                                const float* delta, float* dk, float* dv, int Z, int H, int ldq, int ldk, int ldv, int lddo,
+                                int lddk, int lddv, float scale, void* stream) {
+  return attn_bwd_impl(q, k, v, dout, lse, delta, nullptr, dk, dv, Z, H, ldq, ldk, ldv, lddo, 4, lddk, lddv, scale, 1, stream);
+}
+extern "C" int rp_attn_bwd_dq(const float* q, const float* k, const float* v, const float* dout, const float* lse,
+                              const float* delta, float* dq, int Z, int H, int ldq, int ldk, int ldv, int lddo, int lddq,
+                              float scale, void* stream) {
+  return attn_bwd_impl(q, k, v, dout, lse, delta, dq, nullptr, nullptr, Z, H, ldq, ldk, ldv, lddo, lddq, 4, 4, scale, 2, stream);
 }

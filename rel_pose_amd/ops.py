@@ -12,6 +12,7 @@ All tensors are fp32, contiguous, on the GPU; anything else raises (there is no 
 """
 import ctypes
 import math
+import os
 
 import torch
 
@@ -59,6 +60,44 @@ def gemm_tile(M, N, a_layout, b_layout, reads_mn=False):
     if N % 192 == 0 and not reads_mn:
         return 1, 3
     return 2, 1
+
+
+# ------------------------------------------------------------------------------------------------
+# two-stream backward: for every Linear the input gradient (dX, on the critical path) and the parameter gradients
+# (dW split-K GEMM, bias column sums) are independent, as are the two passes of the attention backward.  Issuing the
+# off-critical-path work on a second HIP stream lets its kernels fill the ramp-up / tail of the critical-path kernels
+# (each ~150 us GEMM otherwise spends ~10 % of its time with a partly empty chip) and hides the small column-sum / reduce
+# launches entirely.  Fork = side waits for main; join = main waits for side (always before a backward returns).
+# ------------------------------------------------------------------------------------------------
+_SIDE = {}
+USE_SIDE_STREAM = os.environ.get("RP_SIDE_STREAM", "1") != "0"
+
+
+class _Fork:
+    def __init__(self, device):
+        self.enabled = USE_SIDE_STREAM
+        if self.enabled:
+            key = str(device)
+            if key not in _SIDE:
+                _SIDE[key] = torch.cuda.Stream(device=device)
+            self.side = _SIDE[key]
+            self.main = torch.cuda.current_stream(device)
+
+    def sync_side(self):
+        """side stream waits for everything issued so far on the main stream"""
+        if self.enabled:
+            self.side.wait_stream(self.main)
+
+    def on_side(self, fn, *a, **k):
+        if not self.enabled:
+            return fn(*a, **k)
+        with torch.cuda.stream(self.side):
+            return fn(*a, **k)
+
+    def sync_main(self):
+        """main stream waits for the side stream (required before the results are consumed / the backward returns)"""
+        if self.enabled:
+            self.main.wait_stream(self.side)
 
 
 def pick_split_k(M, N, K, a_layout=0, b_layout=0, target_wgs=768, min_ktiles=8, max_split=128):
@@ -229,7 +268,9 @@ def attn_fwd(qkv, Z, stats_only=False, q_off=0, k_off=DIM, v_off=2 * DIM, q_xor=
     return o, lse
 
 
-def attn_bwd(qkv, o, lse, do, Z):
+def attn_bwd(qkv, o, lse, do, Z, fork=None):
+    """dqkv of the fused attention.  With a _Fork the dQ pass runs on the side stream next to the dK/dV pass (they write
+    disjoint column blocks of dqkv); the caller must fork.sync_main() before reading dqkv."""
     lib = _lib.load()
     _chk(qkv, o, lse, do)
     ld = qkv.shape[1]
@@ -238,9 +279,19 @@ def attn_bwd(qkv, o, lse, do, Z):
     dqkv = torch.empty_like(qkv)
     P = ctypes.c_void_p
     b, d = qkv.data_ptr(), dqkv.data_ptr()
-    _lib.check(lib.rp_attn_bwd(P(b), P(b + 4 * DIM), P(b + 8 * DIM), _p(do), _p(lse), _p(delta), P(d), P(d + 4 * DIM),
-                               P(d + 8 * DIM), Z, HEADS, ld, ld, ld, DIM, ld, ld, ld, (DIM // HEADS) ** -0.5, _st()),
-               "rp_attn_bwd")
+    sc = (DIM // HEADS) ** -0.5
+    if fork is None or not fork.enabled:
+        _lib.check(lib.rp_attn_bwd(P(b), P(b + 4 * DIM), P(b + 8 * DIM), _p(do), _p(lse), _p(delta), P(d), P(d + 4 * DIM),
+                                   P(d + 8 * DIM), Z, HEADS, ld, ld, ld, DIM, ld, ld, ld, sc, _st()), "rp_attn_bwd")
+        return dqkv
+    fork.sync_side()                                   # delta (and do, dqkv allocation) visible to the side stream
+
+    def dq_pass():
+        _lib.check(lib.rp_attn_bwd_dq(P(b), P(b + 4 * DIM), P(b + 8 * DIM), _p(do), _p(lse), _p(delta), P(d), Z, HEADS,
+                                      ld, ld, ld, DIM, ld, sc, _st()), "rp_attn_bwd_dq")
+    fork.on_side(dq_pass)
+    _lib.check(lib.rp_attn_bwd_dkdv(P(b), P(b + 4 * DIM), P(b + 8 * DIM), _p(do), _p(lse), _p(delta), P(d + 4 * DIM),
+                                    P(d + 8 * DIM), Z, HEADS, ld, ld, ld, DIM, ld, ld, sc, _st()), "rp_attn_bwd_dkdv")
     return dqkv
 
 
@@ -390,11 +441,18 @@ def _mlp_fwd(xn, w1, b1, w2, b2, residual, train):
     return y, h, hpre
 
 
-def _mlp_bwd(dy, xn, h, hpre, w1, w2):
+def _param_grads(fork, dy, x):
+    """(dW, db) of a Linear on the side stream (caller has made dy visible with fork.sync_side())."""
+    return fork.on_side(lambda: (linear_dw(dy, x), colsum(dy)))
+
+
+def _mlp_bwd(fork, dy, xn, h, hpre, w1, w2):
+    fork.sync_side()
+    dw2, db2 = _param_grads(fork, dy, h)
     dh = linear_dx(dy, w2, dact=1, aux=hpre)          # grad wrt fc1 pre-activation (GELU' fused)
-    dw2, db2 = linear_dw(dy, h), colsum(dy)
+    fork.sync_side()
+    dw1, db1 = _param_grads(fork, dh, xn)
     dxn = linear_dx(dh, w1)
-    dw1, db1 = linear_dw(dh, xn), colsum(dh)
     return dxn, dw1, db1, dw2, db2
 
 
@@ -425,14 +483,19 @@ class BlockFn(torch.autograd.Function):
          fc2_w) = ctx.saved_tensors
         Z = ctx.Z
         dy = dy.contiguous().view(Z * N_TOK, DIM)
-        dxn2, dfc1w, dfc1b, dfc2w, dfc2b = _mlp_bwd(dy, xn2, h, hpre, fc1_w, fc2_w)
+        fork = _Fork(dy.device)
+        dxn2, dfc1w, dfc1b, dfc2w, dfc2b = _mlp_bwd(fork, dy, xn2, h, hpre, fc1_w, fc2_w)
         dx1, dn2w, dn2b = layernorm_bwd(dxn2, x1, n2w, m2, r2, add=dy)
+        fork.sync_side()
+        dprojw, dprojb = _param_grads(fork, dx1, o)
         do = linear_dx(dx1, proj_w)
-        dprojw, dprojb = linear_dw(dx1, o), colsum(dx1)
-        dqkv = attn_bwd(qkv, o, lse, do, Z)
+        dqkv = attn_bwd(qkv, o, lse, do, Z, fork)
+        fork.sync_main()                                  # dQ pass (side) done before dqkv is consumed
+        fork.sync_side()
+        dqkvw, dqkvb = _param_grads(fork, dqkv, xn1)
         dxn1 = linear_dx(dqkv, qkv_w)
-        dqkvw, dqkvb = linear_dw(dqkv, xn1), colsum(dqkv)
         dx, dn1w, dn1b = layernorm_bwd(dxn1, x2, n1w, m1, r1, add=dx1)
+        fork.sync_main()
         return (dx.view(Z, N_TOK, DIM), dn1w, dn1b, dqkvw, dqkvb, dprojw, dprojb, dn2w, dn2b, dfc1w, dfc1b, dfc2w,
                 dfc2b)
 
@@ -469,16 +532,20 @@ class CrossBlockFn(torch.autograd.Function):
          fc2_w) = ctx.saved_tensors
         Z = ctx.Z
         dy = dy.contiguous().view(Z * 70, DIM)
-        dfn, dfc1w, dfc1b, dfc2w, dfc2b = _mlp_bwd(dy, fn, h, hpre, fc1_w, fc2_w)
+        fork = _Fork(dy.device)
+        dfn, dfc1w, dfc1b, dfc2w, dfc2b = _mlp_bwd(fork, dy, fn, h, hpre, fc1_w, fc2_w)
         df_, dn2w, dn2b = layernorm_bwd(dfn, f, n2w, m2, r2, add=dy)
+        fork.sync_side()
+        dpfw_full, dpfb = _param_grads(fork, df_, g)
         dg = linear_dx(df_, pf_wp)                                      # [Z*70, 224]
-        dpfw = linear_dw(df_, g)[:, :ctx.pf_cols].contiguous()
-        dpfb = colsum(df_)
         dF = emm_finalize_bwd(dg, Z)
         dqkv = emm_backward(qkv, xa, t, rlse, clse, dF, Z)
+        fork.sync_side()
+        dqkvw, dqkvb = _param_grads(fork, dqkv, xn)
         dxn = linear_dx(dqkv, qkv_w)
-        dqkvw, dqkvb = linear_dw(dqkv, xn), colsum(dqkv)
         dx, dn1w, dn1b = layernorm_bwd(dxn, x2, n1w, m1, r1)
+        fork.sync_main()
+        dpfw = dpfw_full[:, :ctx.pf_cols].contiguous()
         return (dx.view(Z, N_TOK, DIM), None, dn1w, dn1b, dqkvw, dqkvb, dpfw, dpfb, dn2w, dn2b, dfc1w, dfc1b, dfc2w,
                 dfc2b)
 

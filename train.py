@@ -90,10 +90,17 @@ def run(args):
             sd = OrderedDict((k.replace("module.", ""), v) for k, v in sd.items())
         net.load_state_dict(sd, strict=not args.ckpt)
         opt.load_state_dict(ck["optimizer"])
+        resumed_step = 0
         if "scheduler" in ck and not args.ckpt:
-            sched.load_state_dict(ck["scheduler"])
+            # keep THIS run's schedule (--steps may have grown) but continue from the saved position.  (The reference
+            # restores the scheduler wholesale and restarts its step counter at 0, train.py:97-104,111.)
+            st = sched.state_dict()
+            for k in ("last_epoch", "_step_count"):
+                st[k] = ck["scheduler"][k]
+            sched.load_state_dict(st)
+            resumed_step = int(sched.last_epoch)
         if rank == 0:
-            print("resumed from", resume)
+            print("resumed from", resume, "at step", resumed_step)
 
     if args.dataset != "synthetic":
         raise SystemExit("dataset readers are out of scope here (no datasets in this environment): use --dataset synthetic")
@@ -102,7 +109,7 @@ def run(args):
     loader = torch.utils.data.DataLoader(db, batch_size=args.batch, sampler=sampler, shuffle=sampler is None,
                                          num_workers=args.num_workers, pin_memory=True, drop_last=True)
     os.makedirs("output/%s/checkpoints" % args.name, exist_ok=True)
-    step, t0 = 0, time.time()
+    step, t0 = (resumed_step if resume else 0), time.time()
     while step < args.steps:
         if sampler is not None:
             sampler.set_epoch(step)
@@ -119,7 +126,7 @@ def run(args):
             sched.step()
             step += 1
             if rank == 0 and step % 20 == 0:
-                print("step %6d  %s  %.1f pairs/s" % (step, metrics, step * args.batch * world / (time.time() - t0)), flush=True)
+                print("step %6d  %s" % (step, metrics), flush=True)
             if rank == 0 and (step % 10000 == 0 or step >= args.steps):
                 torch.save({"model": net.state_dict(), "optimizer": opt.state_dict(), "scheduler": sched.state_dict()},
                            "output/%s/checkpoints/%06d.pth" % (args.name, step))

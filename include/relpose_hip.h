@@ -116,7 +116,8 @@ int rp_attn_bwd_dq(const float* q, const float* k, const float* v, const float* 
 /* Quadratic positional features (closed form of get_positional_encodings, vision_transformer.py:90-158):
  * pos[b][n] = (p3^2, p4^2, p3 p4, p3, p4, 1), p3 = lin[n%24]*iy_b, p4 = lin[n/24]*ix_b,
  * ix = 1/((fx/(2cx))*2), iy = 1/((fy/(2cy))*2) from intrinsics[b][0] (fx,fy,cx,cy); intrinsics == NULL -> ix=iy=1. */
-int rp_posenc(const float* intrinsics, const float* lin24, float* pos, int B, void* stream);
+/* l1 != 0: get_l1_positional_encodings (vision_transformer.py:37-87): (1, 1, 1, p3, p4, 1) */
+int rp_posenc(const float* intrinsics, const float* lin24, float* pos, int B, int l1, void* stream);
 
 /* Essential Matrix Module (CrossAttention ess branch, vision_transformer.py:198-223), per image z, head h:
  *   S = scale * q_{z^1} k_z^T ; A = rowsoftmax(S) o colsoftmax(S) = exp(2S - rlse_i - clse_j)
@@ -129,8 +130,11 @@ int rp_posenc(const float* intrinsics, const float* lin24, float* pos, int B, vo
  */
 int rp_emm_build_x(const float* qkv, const float* pos, float* x, int Z, int H, int ldqkv, void* stream);
 int rp_emm_build_x_bwd(const float* dx, float* dqkv, int Z, int H, int ldqkv, void* stream); /* dqkv[:, 384+h*64+e] = dx[..][e] */
-int rp_emm_apply(const float* qkv, int ldqkv, const float* x, const float* rlse, const float* clse, float* t_out,
-                 float* f_part, int Z, int H, float scale, int swap, void* stream);
+/* ablation flags of the reference that are runnable there:
+ *   single != 0 : use_single_softmax (:201-203), A = softmax(S,-1) (clse unused);
+ *   x_left != 0 : cross_features (:218-220), F_z = X_left[z^1]^T A_z X_z  (x_left indexed like x). */
+int rp_emm_apply(const float* qkv, int ldqkv, const float* x, const float* x_left, const float* rlse, const float* clse,
+                 float* t_out, float* f_part, int Z, int H, float scale, int swap, int single, void* stream);
 int rp_emm_finalize(const float* f_part, float* g, int Z, int H, int ldg, void* stream);
 int rp_emm_finalize_bwd(const float* dg, float* df, int Z, int H, int ldg, void* stream); /* df[z][h][96][96] */
 /* rowdot: out[r] = sum_c a[r][c]*b[r][c], C = 96 */
@@ -139,7 +143,8 @@ int rp_rowdot96(const float* a, const float* b, float* out, long long rows, void
  *   dS = 2 A dA - R rho_i - C gamma_j,  dA = W X^T (swap==0: W rows i) ;  d(owner operand) = scale * dS * other
  * writes dqkv q-columns of image z^1 (swap==0) or k-columns of image z (swap!=0). */
 int rp_emm_grad(const float* qkv, int ldqkv, const float* x, const float* w, const float* rlse, const float* clse,
-                const float* rho, const float* gamma, float* dqkv, int Z, int H, float scale, int swap, void* stream);
+                const float* rho, const float* gamma, float* dqkv, int Z, int H, float scale, int swap, int single,
+                void* stream);
 
 /* q / max(|q|, 0.01), slot 0 <- Gs  (normalize_preds, src/model.py:145-159) */
 int rp_pose_normalize_fwd(const float* pred, const float* gs, float* out, int B, void* stream);

@@ -331,7 +331,7 @@ def positional_encodings_loop(B, intrinsics=None):
     return positional
 
 
-def positional_encodings(B, intrinsics=None, dtype=torch.float32):
+def positional_encodings(B, intrinsics=None, dtype=torch.float32, l1=False):
     """Closed form of the above: token n -> p3 = ys[n%24]*cy/fy,
     p4 = xs[n//24]*cx/fx (normalised principal point is identically 0).  The normalised focal
     lengths are formed in fp32 exactly as the reference does ((f/(2c))*2, then 1/x)."""
@@ -345,12 +345,18 @@ def positional_encodings(B, intrinsics=None, dtype=torch.float32):
         ify = 1.0 / ((fy / (cy * 2)) * 2)
         p3 = p3 * ify[:, None]
         p4 = p4 * ifx[:, None]
-    pos = torch.stack([p3 * p3, p4 * p4, p3 * p4, p3, p4, torch.ones_like(p3)], dim=2)
+    one = torch.ones_like(p3)
+    if l1:      # get_l1_positional_encodings (vision_transformer.py:37-87): (1, 1, 1, p3, p4, 1)
+        pos = torch.stack([one, one, one, p3, p4, one], dim=2)
+    else:
+        pos = torch.stack([p3 * p3, p4 * p4, p3 * p4, p3, p4, one], dim=2)
     return pos.to(dtype)
 
 
-def cross_attention(sd, p, x1, x2, intrinsics=None, heads=HEADS, pos=None, return_parts=False):
-    """CrossAttention.forward, ess branch, default flags (vision_transformer.py:188-238)."""
+def cross_attention(sd, p, x1, x2, intrinsics=None, heads=HEADS, pos=None, return_parts=False, cross_features=False,
+                    use_single_softmax=False, l1_pos_encoding=False):
+    """CrossAttention.forward, ess branch (vision_transformer.py:188-238) incl. the runnable ablation flags
+    (:201-203 single softmax, :208-209 L1 positional features, :218-220 cross features)."""
     B, N, C = x1.shape
     d = C // heads
     scale = d ** -0.5
@@ -358,15 +364,22 @@ def cross_attention(sd, p, x1, x2, intrinsics=None, heads=HEADS, pos=None, retur
     q2, k2, v2 = split_heads(F.linear(x2, sd[p + "qkv.weight"], sd[p + "qkv.bias"]), heads)
     s1 = (q2 @ k1.transpose(-2, -1)) * scale
     s2 = (q1 @ k2.transpose(-2, -1)) * scale
-    a1 = s1.softmax(dim=-1) * s1.softmax(dim=-2)
-    a2 = s2.softmax(dim=-1) * s2.softmax(dim=-2)
+    if use_single_softmax:
+        a1, a2 = s1.softmax(dim=-1), s2.softmax(dim=-1)
+    else:
+        a1 = s1.softmax(dim=-1) * s1.softmax(dim=-2)
+        a2 = s2.softmax(dim=-1) * s2.softmax(dim=-2)
     if pos is None:
-        pos = positional_encodings(B, intrinsics, x1.dtype)
+        pos = positional_encodings(B, intrinsics, x1.dtype, l1=l1_pos_encoding)
     pe = pos.to(x1.dtype).unsqueeze(1).repeat(1, heads, 1, 1)
     v1 = torch.cat([v1, pe], dim=3)
     v2 = torch.cat([v2, pe], dim=3)
-    f1 = (v1.transpose(-2, -1) @ a1) @ v1           # [B,H,70,70]
-    f2 = (v2.transpose(-2, -1) @ a2) @ v2
+    if cross_features:
+        f1 = (v2.transpose(-2, -1) @ a1) @ v1       # [B,H,70,70]
+        f2 = (v1.transpose(-2, -1) @ a2) @ v2
+    else:
+        f1 = (v1.transpose(-2, -1) @ a1) @ v1
+        f2 = (v2.transpose(-2, -1) @ a2) @ v2
     Ca = C + POS_FEATS * heads
     g1 = f1.reshape(B, Ca, Ca // heads).transpose(-2, -1)   # [B,70,210]: out[b,c,h*70+a] = F[b,h,a,c]
     g2 = f2.reshape(B, Ca, Ca // heads).transpose(-2, -1)
@@ -377,23 +390,23 @@ def cross_attention(sd, p, x1, x2, intrinsics=None, heads=HEADS, pos=None, retur
     return o2, o1                                    # flipped, vision_transformer.py:236-238
 
 
-def cross_block(sd, p, x, intrinsics=None, heads=HEADS, pos=None):
+def cross_block(sd, p, x, intrinsics=None, heads=HEADS, pos=None, **variant):
     """CrossBlock.forward, ess branch (vision_transformer.py:285-296): no residual from x."""
     b_s, h_w, nf = x.shape
     xp = x.reshape(-1, 2, h_w, nf)
     n1w, n1b = sd[p + "norm1.weight"], sd[p + "norm1.bias"]
     fa, fb = cross_attention(sd, p + "cross_attn.", layernorm(xp[:, 0], n1w, n1b), layernorm(xp[:, 1], n1w, n1b),
-                             intrinsics, heads, pos)
+                             intrinsics, heads, pos, **variant)
     f = torch.cat([fa.unsqueeze(1), fb.unsqueeze(1)], dim=1).reshape(b_s, -1, nf)
     return f + mlp(sd, p + "mlp.", layernorm(f, sd[p + "norm2.weight"], sd[p + "norm2.bias"]))
 
 
-def vit_features(sd, tokens, intrinsics=None, depth=6, heads=HEADS, pos=None):
+def vit_features(sd, tokens, intrinsics=None, depth=6, heads=HEADS, pos=None, **variant):
     """src/model.py:169-178: +pos_embed, depth-1 Blocks, CrossBlock, final norm -> [2B,70,192]."""
     x = tokens + sd["fusion_transformer.pos_embed"]
     for l in range(depth - 1):
         x = block(sd, "fusion_transformer.blocks.%d." % l, x, heads)
-    x = cross_block(sd, "fusion_transformer.blocks.%d." % (depth - 1), x, intrinsics, heads, pos)
+    x = cross_block(sd, "fusion_transformer.blocks.%d." % (depth - 1), x, intrinsics, heads, pos, **variant)
     return layernorm(x, sd["fusion_transformer.norm.weight"], sd["fusion_transformer.norm.bias"])
 
 

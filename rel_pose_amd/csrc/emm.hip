@@ -32,6 +32,8 @@ struct EmmP {
   const float* rlse; const float* clse; const float* rho; const float* gamma;
   float* t_out; float* f_part; float* dqkv;
   int H; float scale; int swap; int ZH;
+  int single;            // use_single_softmax (vision_transformer.py:201-203): A = softmax(S, -1) only
+  const float* x_left;   // cross_features (:218-220): left operand of F = X_L^T A X comes from the partner image
 };
 
 template <int NTH>
@@ -129,7 +131,11 @@ __global__ __launch_bounds__(NT, 3) void emm_apply_kernel(EmmP p) {
     const float* cl = Cl + cur * 32;
     const float* xs = Xs + cur * 32 * XW;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = fast_exp2(2.0f * s[r] - ls_o - cl[acc_row(r, hi)]);
+    for (int r = 0; r < 16; ++r) {
+      const float ll = cl[acc_row(r, hi)];
+      // dual softmax: exp(2S - rlse_i - clse_j); single: exp(S - rlse_i) with i = owner (swap == 0) or loop row (swap != 0)
+      s[r] = p.single ? fast_exp2(s[r] - (p.swap ? ll : ls_o)) : fast_exp2(2.0f * s[r] - ls_o - ll);
+    }
     // T[owner][c] += sum_loop A[owner][loop] X[loop][c] : A operand = s (lane = owner), B operand = X rows
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -163,7 +169,8 @@ __global__ __launch_bounds__(NT, 3) void emm_apply_kernel(EmmP p) {
     for (int r = 0; r < 16; ++r) Ts[(wave * 32 + acc_row(r, hi)) * XW + 32 * nb + l31] = tacc[nb][r];
   __syncthreads();
   f32x16 facc[3] = {zero16(), zero16(), zero16()};
-  const float* xa = xb + (long long)wg0 * XW + 32 * wave + l31;   // column a = 32*wave + l31 of X rows
+  const float* xlb = p.x_left ? p.x_left + ((long long)(z ^ 1) * p.H + h) * NTOK * XW : xb;
+  const float* xa = xlb + (long long)wg0 * XW + 32 * wave + l31;   // column a = 32*wave + l31 of the LEFT operand's rows
 #pragma unroll 4
   for (int t = 0; t < 48; ++t) {
     const int i = 48 * hi + t;
@@ -267,7 +274,12 @@ __global__ __launch_bounds__(GT, 2) void emm_grad_kernel(EmmP p) {
       const int li = acc_row(r, hi);
       const float eo = fast_exp2(s[r] - ls_o);           // owner-side softmax factor
       const float el = fast_exp2(s[r] - Ll[cur][li]);    // loop-side softmax factor
-      s[r] = 2.0f * eo * el * da[r] - eo * g_o - el * Ll[cur][32 + li];
+      if (p.single) {      // dS = A dA - A rho_row,  A = row softmax; the row side is the owner (swap == 0) or the loop tile
+        const float a_ = p.swap ? el : eo;
+        s[r] = a_ * (da[r] - (p.swap ? Ll[cur][32 + li] : g_o));
+      } else {
+        s[r] = 2.0f * eo * el * da[r] - eo * g_o - el * Ll[cur][32 + li];
+      }
     }
     // d owner^T[d][owner] += sum_loop other[loop][d] dS^T[loop][owner]
 #pragma unroll
@@ -293,13 +305,14 @@ __global__ __launch_bounds__(GT, 2) void emm_grad_kernel(EmmP p) {
 
 }  // namespace
 
-extern "C" int rp_emm_apply(const float* qkv, int ldqkv, const float* x, const float* rlse, const float* clse,
-                            float* t_out, float* f_part, int Z, int H, float scale, int swap, void* stream) {
+extern "C" int rp_emm_apply(const float* qkv, int ldqkv, const float* x, const float* x_left, const float* rlse,
+                            const float* clse, float* t_out, float* f_part, int Z, int H, float scale, int swap,
+                            int single, void* stream) {
   if (Z <= 0 || (Z & 1) || H <= 0 || (ldqkv & 3)) return RP_EBADSHAPE;
   if (swap && f_part) return RP_EUNSUPPORTED;
   EmmP p{};
   p.qkv = qkv; p.ld = ldqkv; p.x = x; p.rlse = rlse; p.clse = clse; p.t_out = t_out; p.f_part = f_part;
-  p.H = H; p.scale = scale; p.swap = swap ? 1 : 0; p.ZH = Z * H;
+  p.H = H; p.scale = scale; p.swap = swap ? 1 : 0; p.ZH = Z * H; p.single = single ? 1 : 0; p.x_left = x_left;
   hipLaunchKernelGGL(emm_apply_kernel, dim3(xcd_grid(NTILE / NW, Z * H)), dim3(NT), 0, (hipStream_t)stream, p);
   RP_CHECK_LAUNCH();
   return RP_OK;
@@ -307,11 +320,11 @@ extern "C" int rp_emm_apply(const float* qkv, int ldqkv, const float* x, const f
 
 extern "C" int rp_emm_grad(const float* qkv, int ldqkv, const float* x, const float* w, const float* rlse,
                            const float* clse, const float* rho, const float* gamma, float* dqkv, int Z, int H,
-                           float scale, int swap, void* stream) {
+                           float scale, int swap, int single, void* stream) {
   if (Z <= 0 || (Z & 1) || H <= 0 || (ldqkv & 3)) return RP_EBADSHAPE;
   EmmP p{};
   p.qkv = qkv; p.ld = ldqkv; p.x = x; p.w = w; p.rlse = rlse; p.clse = clse; p.rho = rho; p.gamma = gamma;
-  p.dqkv = dqkv; p.H = H; p.scale = scale; p.swap = swap ? 1 : 0; p.ZH = Z * H;
+  p.dqkv = dqkv; p.H = H; p.scale = scale; p.swap = swap ? 1 : 0; p.ZH = Z * H; p.single = single ? 1 : 0;
   hipLaunchKernelGGL(emm_grad_kernel, dim3(xcd_grid(NTILE / GW, Z * H)), dim3(GT), 0, (hipStream_t)stream, p);
   RP_CHECK_LAUNCH();
   return RP_OK;

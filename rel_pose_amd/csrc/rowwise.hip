@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void tokens_bwd_kernel(const float* __restrict
 }
 
 __global__ __launch_bounds__(256) void posenc_kernel(const float* __restrict__ intr, const float* __restrict__ lin,
-                                                     float* __restrict__ pos, int B) {
+                                                     float* __restrict__ pos, int B, int l1) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= B * 576) return;
   const int b = idx / 576, n = idx % 576;
@@ -194,9 +194,9 @@ __global__ __launch_bounds__(256) void posenc_kernel(const float* __restrict__ i
     p4 = p4 * ix;
   }
   float* o = pos + (long long)idx * 6;
-  o[0] = p3 * p3;
-  o[1] = p4 * p4;
-  o[2] = p3 * p4;
+  o[0] = l1 ? 1.0f : p3 * p3;     // l1: get_l1_positional_encodings (vision_transformer.py:37-87) = (1,1,1,p3,p4,1)
+  o[1] = l1 ? 1.0f : p4 * p4;
+  o[2] = l1 ? 1.0f : p3 * p4;
   o[3] = p3;
   o[4] = p4;
   o[5] = 1.0f;
@@ -419,10 +419,10 @@ extern "C" int rp_tokens_bwd(const float* dx, float* dfeat, int Z, int C, int N,
   return RP_OK;
 }
 
-extern "C" int rp_posenc(const float* intrinsics, const float* lin24, float* pos, int B, void* stream) {
+extern "C" int rp_posenc(const float* intrinsics, const float* lin24, float* pos, int B, int l1, void* stream) {
   if (B <= 0) return RP_EBADSHAPE;
   hipLaunchKernelGGL(posenc_kernel, dim3((B * 576 + 255) / 256), dim3(256), 0, (hipStream_t)stream, intrinsics, lin24,
-                     pos, B);
+                     pos, B, l1);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }

@@ -4,9 +4,9 @@ Same class names, constructor arguments, attribute names (=> identical ``state_d
 signatures as reference src/modules/vision_transformer.py (Attention :307-333, Block :336-354,
 CrossAttention :160-238, CrossBlock :265-296, VisionTransformer :357-443) and vit_layers/mlp.py:8-26,
 but the modules hold parameters only: the arithmetic of a whole Block / CrossBlock runs as one autograd
-Function over hand-written gfx950 kernels (rel_pose_amd/ops.py).  Non-default ablation flags
-(cross_features, use_single_softmax, no_pos_encoding, noess, l1_pos_encoding) are
-rejected loudly rather than silently approximated.
+Function over hand-written gfx950 kernels (rel_pose_amd/ops.py).  Ablation flags: cross_features, use_single_softmax and l1_pos_encoding are implemented
+(forward and backward, pinned against the reference); noess (a different head) and no_pos_encoding (crashes in the
+reference itself) are rejected loudly.
 """
 import torch
 import torch.nn as nn
@@ -65,9 +65,12 @@ class CrossAttention(nn.Module):
     def __init__(self, dim, num_heads=8, qkv_bias=False, attn_drop=0., proj_drop=0., cross_features=False,
                  use_single_softmax=False, no_pos_encoding=False, noess=False, l1_pos_encoding=False):
         super().__init__()
-        if cross_features or use_single_softmax or no_pos_encoding or noess or l1_pos_encoding:
-            raise NotImplementedError("only the default Essential-Matrix-Module variant is implemented "
-                                      "(every scripts/*.sh of the reference uses it)")
+        if noess:
+            raise NotImplementedError("--noess (plain cross attention + conv pooling head) is out of scope (SURVEY.md 8a a14)")
+        if no_pos_encoding:
+            raise NotImplementedError("--no_pos_encoding cannot run in the reference either: proj_fundamental is always "
+                                      "Linear(210,192) (vision_transformer.py:179) but the flag feeds it 192 columns (:225-227)")
+        self.cross_features, self.use_single_softmax, self.l1_pos_encoding = cross_features, use_single_softmax, l1_pos_encoding
         self.num_heads = num_heads
         self.scale = (dim // num_heads) ** -0.5
         self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
@@ -100,11 +103,12 @@ class CrossBlock(nn.Module):
             if self.strict_intrinsics:   # the reference's host-side asserts (vision_transformer.py:117,124); sync!
                 assert bool(torch.all(intrinsics[:, 0] == intrinsics[:, 1])), "intrinsics differ within a pair"
                 assert float(intrinsics[0, 0, 2] * intrinsics[0, 0, 3]) != 0.0, "principal point at the origin"
-        pos = ops.posenc(intrinsics, B, x.device)
         a, m = self.cross_attn, self.mlp
+        pos = ops.posenc(intrinsics, B, x.device, l1=a.l1_pos_encoding)
         return ops.CrossBlockFn.apply(x, pos, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias,
                                       a.proj_fundamental.weight, a.proj_fundamental.bias, self.norm2.weight,
-                                      self.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias)
+                                      self.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias,
+                                      a.use_single_softmax, a.cross_features)
 
 
 class VisionTransformer(nn.Module):

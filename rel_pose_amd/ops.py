@@ -306,11 +306,11 @@ def lin24(device):
     return _LIN24[key]
 
 
-def posenc(intrinsics, B, device):
+def posenc(intrinsics, B, device, l1=False):
     lib = _lib.load()
     _chk(intrinsics)
     pos = torch.empty(B, N_TOK, 6, device=device, dtype=torch.float32)
-    _lib.check(lib.rp_posenc(_p(intrinsics), _p(lin24(device)), _p(pos), B, _st()), "rp_posenc")
+    _lib.check(lib.rp_posenc(_p(intrinsics), _p(lin24(device)), _p(pos), B, 1 if l1 else 0, _st()), "rp_posenc")
     return pos
 
 
@@ -322,20 +322,27 @@ def emm_build_x(qkv, pos, Z):
     return x
 
 
-def emm_stats(qkv, Z):
-    """row / column log-sum-exp of S_z = scale q_{z^1} k_z^T."""
+def emm_stats(qkv, Z, single=False):
+    """row / column log-sum-exp of S_z = scale q_{z^1} k_z^T (single softmax: rows only)."""
     _, rlse = attn_fwd(qkv, Z, stats_only=True, q_off=0, k_off=DIM, q_xor=1, k_xor=0)
+    if single:
+        return rlse, rlse
     _, clse = attn_fwd(qkv, Z, stats_only=True, q_off=DIM, k_off=0, q_xor=0, k_xor=1)
     return rlse, clse
 
 
-def emm_apply(qkv, x, rlse, clse, Z, swap=False, want_t=True, want_f=True):
+def pair_swap(x):
+    """x[z] -> x[z ^ 1] for a tensor whose leading dim is the image index (images 2b, 2b+1 form pair b)."""
+    return x.view(x.shape[0] // 2, 2, *x.shape[1:]).flip(1).reshape(x.shape).contiguous()
+
+
+def emm_apply(qkv, x, rlse, clse, Z, swap=False, want_t=True, want_f=True, single=False, x_left=None):
     lib = _lib.load()
-    _chk(qkv, x, rlse, clse)
+    _chk(qkv, x, rlse, clse, x_left)
     t = _empty(Z, HEADS, N_TOK, XW, like=qkv) if want_t else None
     f = _empty(Z, HEADS, NWG, XW, XW, like=qkv) if (want_f and not swap) else None
-    _lib.check(lib.rp_emm_apply(_p(qkv), qkv.shape[1], _p(x), _p(rlse), _p(clse), _p(t), _p(f), Z, HEADS,
-                                (DIM // HEADS) ** -0.5, 1 if swap else 0, _st()), "rp_emm_apply")
+    _lib.check(lib.rp_emm_apply(_p(qkv), qkv.shape[1], _p(x), _p(x_left), _p(rlse), _p(clse), _p(t), _p(f), Z, HEADS,
+                                (DIM // HEADS) ** -0.5, 1 if swap else 0, 1 if single else 0, _st()), "rp_emm_apply")
     return t, f
 
 
@@ -372,23 +379,26 @@ def _bmm96(X, D, transpose_d, residual=None):
     return out
 
 
-def emm_backward(qkv, x, t, rlse, clse, df, Z):
-    """Gradient of F = X^T A X wrt qkv (q, k through A; v through X).  df: [Z,H,96,96] zero-padded."""
+def emm_backward(qkv, x, t, rlse, clse, df, Z, single=False, cross=False):
+    """Gradient of F = X_L^T A X wrt qkv (q, k through A; v through X_L and X).  df: [Z,H,96,96] zero-padded.
+    cross (cross_features): X_L[z] = X[z^1]; otherwise X_L = X."""
     lib = _lib.load()
     scale = (DIM // HEADS) ** -0.5
-    w = _bmm96(x, df, False)        # W  = X dF      (rows i)
+    sg = 1 if single else 0
+    xl = pair_swap(x) if cross else x   # left operand, indexed by the problem z
+    w = _bmm96(xl, df, False)       # W  = X_L dF    (rows i)
     wp = _bmm96(x, df, True)        # W' = X dF^T    (rows j)
-    u, _ = emm_apply(qkv, x, rlse, clse, Z, swap=True, want_f=False)     # U = A^T X
+    u, _ = emm_apply(qkv, xl, rlse, clse, Z, swap=True, want_f=False, single=single)     # U = A^T X_L
     rho = rowdot96(w, t)            # rho_i   = sum_j A_ij dA_ij
-    gam = rowdot96(wp, u)           # gamma_j = sum_i A_ij dA_ij
-    dx = _bmm96(t, df, True)
-    dx = _bmm96(u, df, False, residual=dx)                     # dX = T dF^T + U dF
+    gam = rho if single else rowdot96(wp, u)           # gamma_j = sum_i A_ij dA_ij (unused by the single softmax)
+    dxl = _bmm96(t, df, True)                                   # d X_L = T dF^T  (belongs to image z^1 when cross)
+    dx = _bmm96(u, df, False, residual=pair_swap(dxl) if cross else dxl)      # + d X = U dF
     dqkv = torch.empty_like(qkv)
     ld = qkv.shape[1]
     _lib.check(lib.rp_emm_grad(_p(qkv), ld, _p(x), _p(w), _p(rlse), _p(clse), _p(rho), _p(gam), _p(dqkv), Z, HEADS,
-                               scale, 0, _st()), "rp_emm_grad(q)")
-    _lib.check(lib.rp_emm_grad(_p(qkv), ld, _p(x), _p(wp), _p(rlse), _p(clse), _p(rho), _p(gam), _p(dqkv), Z, HEADS,
-                               scale, 1, _st()), "rp_emm_grad(k)")
+                               scale, 0, sg, _st()), "rp_emm_grad(q)")
+    _lib.check(lib.rp_emm_grad(_p(qkv), ld, _p(xl), _p(wp), _p(rlse), _p(clse), _p(rho), _p(gam), _p(dqkv), Z, HEADS,
+                               scale, 1, sg, _st()), "rp_emm_grad(k)")
     _lib.check(lib.rp_emm_build_x_bwd(_p(dx), _p(dqkv), Z, HEADS, ld, _st()), "rp_emm_build_x_bwd")
     return dqkv
 
@@ -504,16 +514,19 @@ class CrossBlockFn(torch.autograd.Function):
     """CrossBlock.forward, ess branch (vision_transformer.py:285-296): x [2B,576,192] -> [2B,70,192]."""
 
     @staticmethod
-    def forward(ctx, x, pos, n1w, n1b, qkv_w, qkv_b, pf_w, pf_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b):
+    def forward(ctx, x, pos, n1w, n1b, qkv_w, qkv_b, pf_w, pf_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b, single=False,
+                cross=False):
         train = any(ctx.needs_input_grad)   # (grad mode is off inside Function.forward)
         x = x.contiguous()
         Z = x.shape[0]
         x2 = x.view(Z * N_TOK, DIM)
         xn, m1, r1 = layernorm_fwd(x2, n1w, n1b)
         qkv = linear(xn, qkv_w, qkv_b)
-        rlse, clse = emm_stats(qkv, Z)
+        rlse, clse = emm_stats(qkv, Z, single)
         xa = emm_build_x(qkv, pos, Z)
-        t, fpart = emm_apply(qkv, xa, rlse, clse, Z, swap=False, want_t=train)
+        t, fpart = emm_apply(qkv, xa, rlse, clse, Z, swap=False, want_t=train, single=single,
+                             x_left=xa if cross else None)
+        ctx.single, ctx.cross = single, cross
         g = emm_finalize(fpart, Z)                                     # [Z*70, 224]
         pf_wp = torch.nn.functional.pad(pf_w, (0, GW - pf_w.shape[1])).contiguous()
         f = linear(g, pf_wp, pf_b)                                     # [Z*70, 192]
@@ -539,7 +552,7 @@ class CrossBlockFn(torch.autograd.Function):
         dpfw_full, dpfb = _param_grads(fork, df_, g)
         dg = linear_dx(df_, pf_wp)                                      # [Z*70, 224]
         dF = emm_finalize_bwd(dg, Z)
-        dqkv = emm_backward(qkv, xa, t, rlse, clse, dF, Z)
+        dqkv = emm_backward(qkv, xa, t, rlse, clse, dF, Z, single=ctx.single, cross=ctx.cross)
         fork.sync_side()
         dqkvw, dqkvb = _param_grads(fork, dqkv, xn)
         dxn = linear_dx(dqkv, qkv_w)
@@ -547,7 +560,7 @@ class CrossBlockFn(torch.autograd.Function):
         fork.sync_main()
         dpfw = dpfw_full[:, :ctx.pf_cols].contiguous()
         return (dx.view(Z, N_TOK, DIM), None, dn1w, dn1b, dqkvw, dqkvb, dpfw, dpfb, dn2w, dn2b, dfc1w, dfc1b, dfc2w,
-                dfc2b)
+                dfc2b, None, None)
 
 
 class HeadFn(torch.autograd.Function):

@@ -51,9 +51,16 @@ lt = types.ModuleType("lietorch")
 lt.SE3 = SE3
 sys.modules["lietorch"] = lt
 
+# this repo ships drop-in aliases under the same package name `src` (a regular package, which would shadow the reference's
+# namespace package): take the repo root off sys.path while the reference is imported, and check what was imported
+sys.path = [p_ for p_ in sys.path if os.path.abspath(p_ or ".") not in (ROOT, HERE)]
 sys.path.insert(0, REF)
+for _m in [k for k in sys.modules if k == "src" or k.startswith("src.")]:
+    del sys.modules[_m]
 from src.model import ViTEss                              # noqa: E402  (reference)
 from src.modules import vision_transformer as RVT         # noqa: E402  (reference)
+assert os.path.abspath(RVT.__file__).startswith(os.path.abspath(REF)), RVT.__file__
+assert os.path.abspath(sys.modules["src.model"].__file__).startswith(os.path.abspath(REF))
 
 torch.set_num_threads(8)
 torch.manual_seed(0)
@@ -157,6 +164,22 @@ def main():
     out["grad_param_summaries_f64"] = np.stack(gsum)
     with open(os.path.join(HERE, "grad_param_names.json"), "w") as f:
         json.dump(gnames, f)
+
+    # ---- a14: the ablation flags that actually run in the reference (no_pos_encoding crashes there: proj_fundamental is
+    # always Linear(210,192), vision_transformer.py:179 vs :225-227).  fp64 features + token gradients per variant. ----
+    for tag, kw in {"l1": dict(l1_pos_encoding=True), "single": dict(use_single_softmax=True),
+                    "cross": dict(cross_features=True),
+                    "all3": dict(l1_pos_encoding=True, use_single_softmax=True, cross_features=True)}.items():
+        mv = ViTEss(ref_args(**kw)).eval()
+        mv.load_state_dict(sd32, strict=False)
+        mv = mv.double()
+        mv.load_state_dict({k: v for k, v in sd64.items()}, strict=False)
+        tv = O.synthetic_tokens(2 * B, dtype=torch.float64).requires_grad_(True)
+        fv, _ = run_stack(mv.fusion_transformer, tv, intr.clone().double())
+        out["variant_%s_feat_sub_f64" % tag] = subsample(fv, 5)
+        (fv * cot).sum().backward()
+        out["variant_%s_grad_tokens_sub_f64" % tag] = subsample(tv.grad)
+        out["variant_%s_grad_qkv_sum_f64" % tag] = summarize(mv.fusion_transformer.blocks[5].cross_attn.qkv.weight.grad)
 
     # ---- regressor + normalise on the stack output (fp32, fp64) --------------------------------
     Gs = torch.tensor([0, 0, 0, 0, 0, 0, 1.0]).repeat(B, 2, 1)

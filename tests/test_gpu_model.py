@@ -221,3 +221,37 @@ def test_pairs_are_independent_at_full_batch(model):
     assert rel(full, small[src]) < 1e-5
     for b in range(B):
         assert torch.equal(full[b], full[int((src == src[b]).nonzero()[0])])      # identical pairs -> identical bits
+
+
+VARIANTS = {"l1": dict(l1_pos_encoding=True), "single": dict(use_single_softmax=True), "cross": dict(cross_features=True),
+            "all3": dict(l1_pos_encoding=True, use_single_softmax=True, cross_features=True)}
+
+
+@pytest.mark.parametrize("tag", list(VARIANTS))
+def test_ablation_variants_fwd_bwd_vs_reference(states, golden, tag):
+    """cross_features / use_single_softmax / l1_pos_encoding, forward and backward, against the REAL
+    reference's fp64 outputs and autograd (golden)."""
+    from rel_pose_amd import ops
+    from rel_pose_amd.model import ViTEss
+    a = make_args()
+    a.__dict__.update(VARIANTS[tag])
+    m = ViTEss(a)
+    m.load_state_dict(states[0], strict=True)
+    m = m.cuda().train()
+    ft = m.fusion_transformer
+    tok = O.synthetic_tokens(4)
+    fmap = tok.permute(0, 2, 1).contiguous().view(4, 192, 24, 24).cuda().requires_grad_(True)
+    x = ops.TokensFn.apply(fmap, ft.pos_embed[0])
+    for l in range(6):
+        x = ft.blocks[l](x, intrinsics=intr24().cuda())
+    feats = torch.nn.functional.layer_norm(x, (192,), ft.norm.weight, ft.norm.bias, 1e-6)
+    e_f = rel(feats.reshape(-1)[::5], golden["variant_%s_feat_sub_f64" % tag])
+    cot = O.closed_form((4, 70, 192), 991, 1.0, dtype=torch.float64).float().cuda()
+    (feats * cot).sum().backward()
+    e_g = rel(fmap.grad.view(4, 192, 576).permute(0, 2, 1).reshape(-1)[::37], golden["variant_%s_grad_tokens_sub_f64" % tag])
+    g = ft.blocks[5].cross_attn.qkv.weight.grad.double().reshape(-1).cpu()
+    ref = golden["variant_%s_grad_qkv_sum_f64" % tag]
+    e_w = float(np.abs(g[:16].numpy() - ref[3:]).max() / np.abs(ref[3:]).max())
+    e_l1 = abs(float(g.abs().sum()) - ref[1]) / ref[1]
+    report("variant_" + tag, feats=e_f, grad_tokens=e_g, grad_qkv16=e_w, grad_qkv_l1=e_l1)
+    assert e_f < 1e-3 and e_g < 1e-3 and e_w < 2e-3 and e_l1 < 1e-3

@@ -59,8 +59,7 @@ def test_state_dict_contract_and_dropin_alias():
 
 def test_unsupported_variants_are_rejected_loudly():
     from rel_pose_amd.model import ViTEss
-    for kw in (dict(noess="1"), dict(cross_features=True), dict(use_single_softmax=True), dict(no_pos_encoding=True),
-               dict(l1_pos_encoding=True), dict(fusion_transformer=False)):
+    for kw in (dict(noess="1"), dict(no_pos_encoding=True), dict(fusion_transformer=False)):
         with pytest.raises(NotImplementedError):
             ViTEss(make_args(**kw))
 

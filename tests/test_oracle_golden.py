@@ -136,3 +136,19 @@ def test_index_ops_bit_exact(golden):
     assert np.array_equal(tk[1, ::97, ::31].numpy().astype(np.int64), golden["token_layout_probe"])
     # token n = row*24+col of the CNN map, channel-last
     assert float(tk[1, 5 * 24 + 7, 33]) == float(x[1, 33, 5, 7])
+
+
+VARIANTS = {"l1": dict(l1_pos_encoding=True), "single": dict(use_single_softmax=True), "cross": dict(cross_features=True),
+            "all3": dict(l1_pos_encoding=True, use_single_softmax=True, cross_features=True)}
+
+
+@pytest.mark.parametrize("tag", list(VARIANTS))
+def test_ablation_variants_fp64(golden, states, tag):
+    """the three ablation flags that run in the reference (no_pos_encoding crashes there)."""
+    _, sd64 = states
+    tok = O.synthetic_tokens(4, dtype=torch.float64).requires_grad_(True)
+    f = O.vit_features(sd64, tok, intr24(torch.float64), **VARIANTS[tag])
+    assert rel(f.reshape(-1)[::5], golden["variant_%s_feat_sub_f64" % tag]) < 1e-7
+    cot = O.closed_form(tuple(f.shape), 991, 1.0, dtype=torch.float64)
+    (f * cot).sum().backward()
+    assert rel(tok.grad.reshape(-1)[::37], golden["variant_%s_grad_tokens_sub_f64" % tag]) < 1e-7

@@ -255,3 +255,28 @@ def test_ablation_variants_fwd_bwd_vs_reference(states, golden, tag):
     e_l1 = abs(float(g.abs().sum()) - ref[1]) / ref[1]
     report("variant_" + tag, feats=e_f, grad_tokens=e_g, grad_qkv16=e_w, grad_qkv_l1=e_l1)
     assert e_f < 1e-3 and e_g < 1e-3 and e_w < 2e-3 and e_l1 < 1e-3
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_odd_batch_sizes_fwd_bwd(model, states, B):
+    """Guards / padding paths: B=1 (demo) and B=3 (Z*H = 18 problems: not a multiple of the 8 XCD groups, M tiles ragged)."""
+    _, sd64 = states
+    model.train()
+    try:
+        tok = O.synthetic_tokens(2 * B, key=300 + B)
+        Gs = torch.tensor([0, 0, 0, 0, 0, 0, 1.0]).repeat(B, 2, 1)
+        intr = torch.tensor([[30.0, 26.0, 12.0, 11.0]]).repeat(B, 2, 1).contiguous()
+        cot = O.closed_form((B, 2, 7), 77, 1.0, dtype=torch.float64)
+        sd, gtok, ref = _oracle_grads(sd64, tok.double(), intr.double(), cot, True, Gs.double())
+        fmap = tok.permute(0, 2, 1).contiguous().view(2 * B, 192, 24, 24).cuda().requires_grad_(True)
+        for p in model.parameters():
+            p.grad = None
+        out = model.forward_tokens(fmap, Gs.cuda(), intr.cuda())
+        (out * cot.float().cuda()).sum().backward()
+        t_err, q_err, ang = O.pose_errors(out.detach().cpu(), ref.detach())
+        e_tok = rel(fmap.grad.view(2 * B, 192, 576).permute(0, 2, 1), gtok)
+        e_w = rel(model.pose_regressor[0].weight.grad, sd["pose_regressor.0.weight"].grad)
+        report("odd_batch_%d" % B, t=t_err, q=q_err, grad_tokens=e_tok, grad_reg0=e_w)
+        assert max(t_err, q_err) < 1e-4 and e_tok < 1e-3 and e_w < 1e-3
+    finally:
+        model.eval()

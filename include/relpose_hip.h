@@ -72,6 +72,10 @@ typedef struct RpGemm {
 } RpGemm;
 int rp_gemm(const RpGemm* g, void* stream);
 size_t rp_gemm_workspace_bytes(int M, int N, int split_k);
+/* EXPERIMENTAL, not on the default path: C = act(A B^T + bias) (+ residual), fp32 in/out, products on the bf16 MFMA pipe
+ * with the 3xBF16 split (a_hi b_hi + a_hi b_lo + a_lo b_hi, fp32 accumulate).  A [M,K], B [N,K], K-contiguous. */
+int rp_gemm_nt_bf16x3(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                      const float* bias, const float* residual, float* pre_out, int act, void* stream);
 
 /* LayerNorm over the last dim C (multiple of 64, <= 512), eps as given (reference uses 1e-6,
  * vision_transformer.py:396).  Saves mean / rstd per row for the backward. */

@@ -31,6 +31,7 @@ _SIGS = {
     "rp_target_arch": (c_char_p, []),
     "rp_gemm": (c_int, [POINTER(RpGemm), P]),
     "rp_gemm_workspace_bytes": (c_size_t, [I, I, I]),
+    "rp_gemm_nt_bf16x3": (c_int, [P, P, P, I, I, I, I, I, I, P, P, P, I, P]),
     "rp_layernorm_fwd": (c_int, [P, P, P, P, P, P, I, I, F, P]),
     "rp_layernorm_bwd_blocks": (c_int, [I]),
     "rp_layernorm_bwd": (c_int, [P, P, P, P, P, P, P, P, P, I, I, P]),

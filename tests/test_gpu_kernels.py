@@ -273,3 +273,17 @@ def test_emm_backward(ops):
     e = [rel(dqkv[:, i * 192:(i + 1) * 192], q64.grad[:, i * 192:(i + 1) * 192]) for i in range(3)]
     report("emm_bwd", dq=e[0], dk=e[1], dv=e[2])
     assert max(e) < 5e-5
+
+
+def test_experimental_bf16x3_gemm(ops):
+    """The 3xBF16-split GEMM (not on the default path): fp32-class accuracy (<= 2e-5 of max|ref|) on the bf16 MFMA pipe."""
+    from rel_pose_amd import _lib
+    lib = _lib.load()
+    M, N, K = 1152, 192, 768
+    A, W, b, R = rnd(M, K, seed=21), rnd(N, K, seed=22, scale=K ** -0.5), rnd(N, seed=23), rnd(M, N, seed=24)
+    C = torch.empty(M, N, device="cuda")
+    _lib.check(lib.rp_gemm_nt_bf16x3(ops._p(A), ops._p(W), ops._p(C), M, N, K, K, K, N, ops._p(b), ops._p(R), None, 0,
+                                     ops._st()), "rp_gemm_nt_bf16x3")
+    e = rel(C, A.double() @ W.double().t() + b.double() + R.double())
+    report("gemm_bf16x3", rel=e)
+    assert e < 2e-5

@@ -90,6 +90,10 @@ int rp_layernorm_bwd(const float* dy, const float* x, const float* gamma, const 
 size_t rp_colsum_workspace_bytes(int rows, int cols);
 int rp_colsum(const float* in, int rows, int cols, int ld, float* out, float* workspace, size_t workspace_bytes, void* stream);
 
+/* Image preprocessing (reference src/model.py:115-118,124-125; bit-exact): BGR->RGB, /255, ImageNet mean/std, nearest
+ * resize to 224x224.  images [Z,3,H,W] fp32 0..255 -> out: channels-last memory [Z,224,224,3] of a [Z,3,224,224] tensor. */
+int rp_preprocess(const float* images, float* out, int Z, int H, int W, void* stream);
+
 /* Token layout + learned position embedding: x[z][n][c] = feat[z][c][n] + pos_embed[n][c]
  * (reference src/model.py:136-141,170-171; index part bit-exact).  feat is the CNN map [Z,C,N]. */
 int rp_tokens_fwd(const float* feat, const float* pos_embed, float* x, int Z, int C, int N, void* stream);

@@ -37,6 +37,7 @@ _SIGS = {
     "rp_layernorm_bwd": (c_int, [P, P, P, P, P, P, P, P, P, I, I, P]),
     "rp_colsum_workspace_bytes": (c_size_t, [I, I]),
     "rp_colsum": (c_int, [P, I, I, I, P, P, c_size_t, P]),
+    "rp_preprocess": (c_int, [P, P, I, I, I, P]),
     "rp_tokens_fwd": (c_int, [P, P, P, I, I, I, P]),
     "rp_tokens_fwd_nhwc": (c_int, [P, P, P, I, I, I, P]),
     "rp_tokens_bwd": (c_int, [P, P, I, I, I, P]),

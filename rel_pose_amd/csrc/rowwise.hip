@@ -284,6 +284,25 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict
   }
 }
 
+// images [Z,3,H,W] BGR 0..255  ->  out [Z,224,224,3] (channels-last memory of a [Z,3,224,224] tensor), RGB, normalised.
+// Same fp32 operation order as the reference (src/model.py:115-118,124-125): v/255, -mean, /std; nearest source index
+// floor(dst * (in/out)) in fp32 (PyTorch "nearest").  Resize and normalisation commute exactly (both are per-pixel), so
+// gathering first touches 224^2 of the H*W pixels.
+__global__ __launch_bounds__(256) void preprocess_kernel(const float* __restrict__ img, float* __restrict__ out, int H, int W,
+                                                         float sy, float sx, long long total) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;   // over Z*224*224 output pixels
+  if (idx >= total) return;
+  const int x = (int)(idx % 224), y = (int)((idx / 224) % 224);
+  const long long z = idx / (224 * 224);
+  const int iy = min((int)floorf((float)y * sy), H - 1), ix = min((int)floorf((float)x * sx), W - 1);
+  const float* p = img + (z * 3) * (long long)H * W + (long long)iy * W + ix;
+  const float b = p[0], g = p[(long long)H * W], r = p[2 * (long long)H * W];
+  float* o = out + idx * 3;
+  o[0] = (r / 255.0f - 0.485f) / 0.229f;
+  o[1] = (g / 255.0f - 0.456f) / 0.224f;
+  o[2] = (b / 255.0f - 0.406f) / 0.225f;
+}
+
 __global__ void pose_norm_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ gs,
                                      float* __restrict__ out, int B) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -469,6 +488,15 @@ extern "C" int rp_attn_bwd_delta(const float* dout, const float* o, float* delta
   const long long total = (long long)Z * 576 * H;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dout, o,
                      delta, H, ld, total);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
+extern "C" int rp_preprocess(const float* images, float* out, int Z, int H, int W, void* stream) {
+  if (Z <= 0 || H <= 0 || W <= 0) return RP_EBADSHAPE;
+  const long long total = (long long)Z * 224 * 224;
+  hipLaunchKernelGGL(preprocess_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, images,
+                     out, H, W, (float)H / 224.0f, (float)W / 224.0f, total);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }

@@ -78,11 +78,9 @@ class ViTEss(nn.Module):
     # -- src/model.py:111-143 ---------------------------------------------------------------------
     def cnn_map(self, images, intrinsics=None):
         """preprocessing + CNN front-end -> [2B,192,24,24] (PyTorch-ROCm / MIOpen: 'next' row 8f-1)."""
-        images = images.flip(2) / 255.0                      # BGR -> RGB == images[:, :, [2, 1, 0]]
-        images = images.sub_(self._mean).div_(self._std)
         if intrinsics is not None:
             intrinsics = self.update_intrinsics(images.shape, intrinsics)
-        x = F.interpolate(self.flatten(images), size=224).contiguous(memory_format=torch.channels_last)
+        x = ops.preprocess(images)       # BGR->RGB, /255, mean/std, nearest 224: one bit-exact HIP kernel, channels-last out
         r = self.resnet
         x = r.maxpool(r.relu(r.bn1(r.conv1(x))))
         x = r.layer2(r.layer1(x))

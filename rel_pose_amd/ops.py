@@ -296,6 +296,18 @@ def attn_bwd(qkv, o, lse, do, Z, fork=None):
     return dqkv
 
 
+def preprocess(images):
+    """[B,2,3,H,W] BGR 0..255 -> [2B,3,224,224] RGB normalised, channels-last (src/model.py:115-118,124-125)."""
+    lib = _lib.load()
+    images = images.contiguous()
+    _chk(images)
+    B, two, C, H, W = images.shape
+    Z = B * two
+    out = torch.empty(Z, 224, 224, 3, device=images.device, dtype=torch.float32)
+    _lib.check(lib.rp_preprocess(_p(images), _p(out), Z, H, W, _st()), "rp_preprocess")
+    return out.permute(0, 3, 1, 2)          # [Z,3,224,224] view with channels-last strides
+
+
 _LIN24 = {}
 
 

@@ -287,3 +287,15 @@ def test_experimental_bf16x3_gemm(ops):
     e = rel(C, A.double() @ W.double().t() + b.double() + R.double())
     report("gemm_bf16x3", rel=e)
     assert e < 2e-5
+
+
+@pytest.mark.parametrize("H,W", [(384, 384), (256, 320), (384, 512), (480, 640)])
+def test_preprocess_bit_exact(ops, H, W):
+    """channel flip, /255, mean/std, nearest resize to 224 -- bit-exact vs the oracle (which is pinned to
+    the reference's F.interpolate index maps)."""
+    from oracle import relpose_oracle as O
+    imgs = O.synthetic_images(2, H, W, key=31)
+    ref = O.preprocess(imgs)                                   # [4,3,224,224] CPU
+    got = ops.preprocess(imgs.cuda())
+    assert got.shape == (4, 3, 224, 224) and got.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(got.cpu(), ref)

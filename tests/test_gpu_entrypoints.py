@@ -50,3 +50,40 @@ def test_demo_runs_on_png_pair(tmp_path):
     r = run([os.path.join(ROOT, "demo.py"), "--img1", str(tmp_path / "a.png"), "--img2", str(tmp_path / "b.png")], str(tmp_path))
     assert r.returncode == 0, r.stderr[-2000:]
     assert "predicted R&t" in r.stdout
+
+
+def test_overfits_a_fixed_batch():
+    """End-to-end sanity of forward + loss + backward + optimiser on the HIP path: a fixed batch of 4 pairs is memorised."""
+    import types
+    import torch
+    from rel_pose_amd.losses import geodesic_loss_tensors
+    from rel_pose_amd.model import ViTEss
+    from rel_pose_amd.se3 import SE3
+    torch.manual_seed(0)
+    a = types.SimpleNamespace(noess="", pool_size=60, fc_hidden_size=512, fusion_transformer=True, transformer_depth=6,
+                              cross_features=False, use_single_softmax=False, no_pos_encoding=False, l1_pos_encoding=False)
+    model = ViTEss(a).cuda().train()
+    opt = torch.optim.Adam(model.parameters(), lr=2e-4)
+    g = torch.Generator().manual_seed(1)
+    images = torch.floor(torch.rand(4, 2, 3, 256, 256, generator=g) * 255).cuda()
+    q = torch.randn(4, 4, generator=g)
+    q = q / q.norm(dim=-1, keepdim=True) * torch.where(q[:, 3:] < 0, -1.0, 1.0)
+    poses = torch.zeros(4, 2, 7)
+    poses[:, :, 6] = 1
+    poses[:, 1] = torch.cat([torch.rand(4, 3, generator=g) - 0.5, q], -1)
+    poses = poses.cuda()
+    intr = torch.tensor([[200.0, 200.0, 128.0, 128.0]]).repeat(4, 2, 1).cuda()
+    Ps = SE3(poses)
+    Gs = SE3.IdentityLike(Ps)
+    losses = []
+    for _ in range(80):
+        opt.zero_grad(set_to_none=True)
+        est = model(images, Gs, intrinsics=intr.clone())
+        ltr, lrot = geodesic_loss_tensors(Ps, est)
+        loss = 10 * ltr + 10 * lrot
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 2.5)
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert all(l == l for l in losses), "NaN in the loss"
+    assert min(losses[-10:]) < 0.35 * losses[0], (losses[0], losses[-10:])

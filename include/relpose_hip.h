@@ -81,7 +81,8 @@ int rp_gemm_nt_bf16x3(const float* A, const float* B, float* C, int M, int N, in
  * vision_transformer.py:396).  Saves mean / rstd per row for the backward. */
 int rp_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                      int rows, int C, float eps, void* stream);
-/* dx = LN'(dy) (+ add if non-null); dgamma_part/dbeta_part: [nblk][C] partial sums, nblk = rp_layernorm_bwd_blocks(rows) */
+/* dx = LN'(dy) (+ add if non-null); partial sums are written to dgamma_part as [nblk][2][C] (dgamma row, dbeta row per
+ * block; dbeta_part is ignored), nblk = rp_layernorm_bwd_blocks(rows) <= 2048: one rp_colsum over [nblk, 2C] finishes both */
 int rp_layernorm_bwd_blocks(int rows);
 int rp_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                      const float* add, float* dx, float* dgamma_part, float* dbeta_part, int rows, int C, void* stream);

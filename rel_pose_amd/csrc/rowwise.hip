@@ -67,7 +67,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     dg[j] = 0.f;
     db[j] = 0.f;
   }
-  const int r0 = blockIdx.x * LNB_ROWS + wave * (LNB_ROWS / 4);
+  for (int chunk = blockIdx.x; chunk * LNB_ROWS < rows; chunk += gridDim.x) {
+  const int r0 = chunk * LNB_ROWS + wave * (LNB_ROWS / 4);
   for (int rr = 0; rr < LNB_ROWS / 4; ++rr) {
     const int row = r0 + rr;
     if (row >= rows) break;
@@ -94,6 +95,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
       dx[o] = v;
     }
   }
+  }
 #pragma unroll
   for (int j = 0; j < J; ++j) {
     red[0][wave][lane + 64 * j] = dg[j];
@@ -101,8 +103,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) {
-    dgp[(long long)blockIdx.x * C + c] = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
-    dbp[(long long)blockIdx.x * C + c] = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+    // partials interleaved as [block][2][C] so ONE column-sum launch finishes both dgamma and dbeta
+    dgp[(long long)blockIdx.x * 2 * C + c] = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+    dgp[(long long)blockIdx.x * 2 * C + C + c] = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
   }
 }
 
@@ -360,7 +363,9 @@ extern "C" int rp_layernorm_fwd(const float* x, const float* gamma, const float*
   return RP_OK;
 }
 
-extern "C" int rp_layernorm_bwd_blocks(int rows) { return (rows + LNB_ROWS - 1) / LNB_ROWS; }
+// enough workgroups to saturate HBM (a 256-block grid left 4 waves per CU and ran ~2x slower), few enough that the
+// interleaved [nblk][2][C] partials are finished by one two-stage column sum
+extern "C" int rp_layernorm_bwd_blocks(int rows) { return min((rows + LNB_ROWS - 1) / LNB_ROWS, 2048); }
 
 extern "C" int rp_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                                 const float* rstd, const float* add, float* dx, float* dgamma_part, float* dbeta_part,

@@ -248,10 +248,11 @@ def layernorm_bwd(dy, x2d, gamma, mean, rstd, add=None):
     rows, C = x2d.shape
     nblk = lib.rp_layernorm_bwd_blocks(rows)
     dx = torch.empty_like(x2d)
-    part = _empty(2, nblk, C, like=x2d)
-    _lib.check(lib.rp_layernorm_bwd(_p(dy), _p(x2d), _p(gamma), _p(mean), _p(rstd), _p(add), _p(dx), _p(part[0]),
-                                    _p(part[1]), rows, C, _st()), "rp_layernorm_bwd")
-    return dx, colsum(part[0]), colsum(part[1])
+    part = _empty(nblk, 2 * C, like=x2d)
+    _lib.check(lib.rp_layernorm_bwd(_p(dy), _p(x2d), _p(gamma), _p(mean), _p(rstd), _p(add), _p(dx), _p(part),
+                                    None, rows, C, _st()), "rp_layernorm_bwd")
+    dgb = colsum(part)                                  # one launch: [dgamma | dbeta]
+    return dx, dgb[:C], dgb[C:]
 
 
 def attn_fwd(qkv, Z, stats_only=False, q_off=0, k_off=DIM, v_off=2 * DIM, q_xor=0, k_xor=0):
@@ -464,9 +465,15 @@ def _mlp_fwd(xn, w1, b1, w2, b2, residual, train):
     return y, h, hpre
 
 
+def linear_dw_db(dy, x):
+    """(dW, db) of a Linear.  (Fusing the bias column sums into the weight-gradient GEMM was measured: the extra per-thread
+    accumulators cost that kernel 20 %, more than the saved pass over dy -- kept as two kernels.)"""
+    return linear_dw(dy, x), colsum(dy)
+
+
 def _param_grads(fork, dy, x):
     """(dW, db) of a Linear on the side stream (caller has made dy visible with fork.sync_side())."""
-    return fork.on_side(lambda: (linear_dw(dy, x), colsum(dy)))
+    return fork.on_side(lambda: linear_dw_db(dy, x))
 
 
 def _mlp_bwd(fork, dy, xn, h, hpre, w1, w2):

@@ -95,6 +95,11 @@ def test_gemm_epilogues_splitk_batch(ops):
     e = rel(dw, dY.double().t() @ X.double())
     report("gemm_dw", rel=e)
     assert e < 2e-6
+    dw2, db2 = ops.linear_dw_db(dY, X)                    # bias gradient fused into the weight-gradient GEMM
+    assert torch.equal(dw2, dw) and rel(db2, dY.double().sum(0)) < 2e-6
+    dYs, Xs = rnd(300, 16, seed=15), rnd(300, 512, seed=16)      # small-M path (regressor): no split
+    dws, dbs = ops.linear_dw_db(dYs, Xs)
+    assert rel(dws, dYs.double().t() @ Xs.double()) < 2e-6 and rel(dbs, dYs.double().sum(0)) < 2e-6
     dx = ops.linear_dx(dY, rnd(192, 768, seed=10))
     assert rel(dx, dY.double() @ rnd(192, 768, seed=10).double()) < 2e-6
     # batched 576x96 @ 96x96 (EMM backward shapes)

@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
     typed = _lib.load()
     assert typed.rp_abi_version() == 1 and typed.rp_target_arch() == b"gfx950"
     assert typed.rp_gemm_workspace_bytes(576, 192, 103) == 103 * 576 * 192 * 4
-    assert typed.rp_layernorm_bwd_blocks(73728) == 1152
+    assert typed.rp_layernorm_bwd_blocks(73728) == 1152 and typed.rp_layernorm_bwd_blocks(100) == 2
 
 
 def test_state_dict_contract_and_dropin_alias():

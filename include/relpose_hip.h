@@ -104,7 +104,9 @@ int rp_tokens_bwd(const float* dx, float* dfeat, int Z, int C, int N, void* stre
 
 /* Fused softmax attention, N=576 tokens, d=64, heads packed along columns (col = h*64 + e):
  *   O[z][i][h*64+:] = softmax_j(scale * q_i . k_j) v_j        (vision_transformer.py:325-329)
- * q/k/v rows for image z: base + (z ^ xor)*576*ld + i*ld.  lse[z][h][i] = log sum_j exp(s_ij) saved
+ * q/k/v rows for image z: base + (z ^ xor)*576*ld + i*ld, with xor = q_xor for q, bit 0 of k_xor for k and bit 1
+ * of k_xor for v (k_xor = 3: keys AND values from the partner image of the pair = the --noess cross attention,
+ * vision_transformer.py:239-262; k_xor = 1 with stats_only: the EMM's S = q k_partner^T).  lse[z][h][i] = log sum_j exp(s_ij) saved
  * for the backward.  stats_only != 0: only lse is produced (v, o ignored) -- used for the row and
  * column normalisers of the dual softmax (vision_transformer.py:205-206). */
 int rp_attn_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int Z, int H, int ldq, int ldk,
@@ -115,6 +117,11 @@ int rp_attn_bwd_delta(const float* dout, const float* o, float* delta, int Z, in
 int rp_attn_bwd(const float* q, const float* k, const float* v, const float* dout, const float* lse, const float* delta,
                 float* dq, float* dk, float* dv, int Z, int H, int ldq, int ldk, int ldv, int lddo, int lddq, int lddk,
                 int lddv, float scale, void* stream);
+/* same with the keys/values of problem z taken from image z ^ kv_xor (dk, dv are written at the rows of the image the
+ * keys/values came from): backward of rp_attn_fwd(..., q_xor=0, k_xor=3, ...) when kv_xor = 1 */
+int rp_attn_bwd_cross(const float* q, const float* k, const float* v, const float* dout, const float* lse,
+                      const float* delta, float* dq, float* dk, float* dv, int Z, int H, int ldq, int ldk, int ldv, int lddo,
+                      int lddq, int lddk, int lddv, float scale, int kv_xor, void* stream);
 /* the two passes of rp_attn_bwd separately (they are independent; the host overlaps them on two HIP streams) */
 int rp_attn_bwd_dkdv(const float* q, const float* k, const float* v, const float* dout, const float* lse,
                      const float* delta, float* dk, float* dv, int Z, int H, int ldq, int ldk, int ldv, int lddo, int lddk,

@@ -67,8 +67,9 @@ def _key(name):
     return h % (1 << 31)
 
 
-def vit_param_shapes(dim=DIM, heads=HEADS, depth=6, mlp_ratio=4, fc_hidden=512):
-    """state_dict keys/shapes of fusion_transformer.* and pose_regressor.* (SURVEY.md 8b)."""
+def vit_param_shapes(dim=DIM, heads=HEADS, depth=6, mlp_ratio=4, fc_hidden=512, noess=False):
+    """state_dict keys/shapes of fusion_transformer.* and pose_regressor.* (SURVEY.md 8b); noess adds pool_attn.*
+    and swaps cross_attn.proj_fundamental for cross_attn.proj (src/model.py:73-82, vision_transformer.py:176-179)."""
     hd = dim // heads
     hid = dim * mlp_ratio
     s = {"fusion_transformer.pos_embed": (1, N_TOK, dim)}
@@ -80,7 +81,7 @@ def vit_param_shapes(dim=DIM, heads=HEADS, depth=6, mlp_ratio=4, fc_hidden=512):
         a = "cross_attn." if l == depth - 1 else "attn."
         s[p + a + "qkv.weight"] = (3 * dim, dim)
         s[p + a + "qkv.bias"] = (3 * dim,)
-        if l == depth - 1:
+        if l == depth - 1 and not noess:
             s[p + a + "proj_fundamental.weight"] = (dim, dim + POS_FEATS * heads)
             s[p + a + "proj_fundamental.bias"] = (dim,)
         else:
@@ -93,6 +94,18 @@ def vit_param_shapes(dim=DIM, heads=HEADS, depth=6, mlp_ratio=4, fc_hidden=512):
     s["fusion_transformer.norm.weight"] = (dim,)
     s["fusion_transformer.norm.bias"] = (dim,)
     H = heads * 2 * (hd + POS_FEATS) * hd          # src/model.py:61
+    if noess:                                      # src/model.py:73-82
+        H = N_TOK * 43
+        s["pool_attn.0.weight"] = (96, 2 * dim, 1, 1)
+        s["pool_attn.0.bias"] = (96,)
+        s["pool_attn.3.weight"] = (43, 96, 1, 1)
+        s["pool_attn.3.bias"] = (43,)
+        for i_, c_ in ((1, 96), (4, 43)):
+            s["pool_attn.%d.weight" % i_] = (c_,)
+            s["pool_attn.%d.bias" % i_] = (c_,)
+            s["pool_attn.%d.running_mean" % i_] = (c_,)
+            s["pool_attn.%d.running_var" % i_] = (c_,)
+            s["pool_attn.%d.num_batches_tracked" % i_] = ()
     s["pose_regressor.0.weight"] = (fc_hidden, H)
     s["pose_regressor.0.bias"] = (fc_hidden,)
     s["pose_regressor.2.weight"] = (fc_hidden, fc_hidden)
@@ -150,7 +163,8 @@ def make_state(shapes, dtype=torch.float32):
             sd[name] = closed_form(shp, k, 0.1, dtype=dtype)
         elif name.endswith("running_var"):
             sd[name] = closed_form(shp, k, 0.2, 1.0, dtype=dtype)
-        elif "norm" in name or ".bn" in name or name.endswith("downsample.1.weight") or name.endswith("downsample.1.bias"):
+        elif ("norm" in name or ".bn" in name or name.endswith("downsample.1.weight") or name.endswith("downsample.1.bias")
+              or name.startswith("pool_attn.1.") or name.startswith("pool_attn.4.")):
             if name.endswith("weight"):
                 sd[name] = closed_form(shp, k, 0.2, 1.0, dtype=dtype)
             else:
@@ -390,11 +404,30 @@ def cross_attention(sd, p, x1, x2, intrinsics=None, heads=HEADS, pos=None, retur
     return o2, o1                                    # flipped, vision_transformer.py:236-238
 
 
-def cross_block(sd, p, x, intrinsics=None, heads=HEADS, pos=None, **variant):
-    """CrossBlock.forward, ess branch (vision_transformer.py:285-296): no residual from x."""
+def cross_attention_noess(sd, p, x1, x2, heads=HEADS):
+    """CrossAttention.forward, noess branch (vision_transformer.py:239-262): plain softmax attention whose keys/values
+    come from the OTHER image; returns (image-1 slot, image-2 slot) = (attn(q1,k2,v2), attn(q2,k1,v1))."""
+    B, N, C = x1.shape
+    scale = (C // heads) ** -0.5
+    q1, k1, v1 = split_heads(F.linear(x1, sd[p + "qkv.weight"], sd[p + "qkv.bias"]), heads)
+    q2, k2, v2 = split_heads(F.linear(x2, sd[p + "qkv.weight"], sd[p + "qkv.bias"]), heads)
+    o1 = (((q2 @ k1.transpose(-2, -1)) * scale).softmax(dim=-1) @ v1).transpose(1, 2).reshape(B, N, C)
+    o2 = (((q1 @ k2.transpose(-2, -1)) * scale).softmax(dim=-1) @ v2).transpose(1, 2).reshape(B, N, C)
+    o1 = F.linear(o1, sd[p + "proj.weight"], sd[p + "proj.bias"])
+    o2 = F.linear(o2, sd[p + "proj.weight"], sd[p + "proj.bias"])
+    return o2, o1                                    # flipped, vision_transformer.py:260-262
+
+
+def cross_block(sd, p, x, intrinsics=None, heads=HEADS, pos=None, noess=False, **variant):
+    """CrossBlock.forward (vision_transformer.py:285-304).  ess branch: no residual from x; noess branch: a Block."""
     b_s, h_w, nf = x.shape
     xp = x.reshape(-1, 2, h_w, nf)
     n1w, n1b = sd[p + "norm1.weight"], sd[p + "norm1.bias"]
+    if noess:
+        a, b = cross_attention_noess(sd, p + "cross_attn.", layernorm(xp[:, 0], n1w, n1b), layernorm(xp[:, 1], n1w, n1b),
+                                     heads)
+        x = x + torch.cat([a.unsqueeze(1), b.unsqueeze(1)], dim=1).reshape(b_s, h_w, nf)
+        return x + mlp(sd, p + "mlp.", layernorm(x, sd[p + "norm2.weight"], sd[p + "norm2.bias"]))
     fa, fb = cross_attention(sd, p + "cross_attn.", layernorm(xp[:, 0], n1w, n1b), layernorm(xp[:, 1], n1w, n1b),
                              intrinsics, heads, pos, **variant)
     f = torch.cat([fa.unsqueeze(1), fb.unsqueeze(1)], dim=1).reshape(b_s, -1, nf)
@@ -427,20 +460,32 @@ def normalize_preds(Gs_data, pose_preds):
     return torch.cat([Gs_data[:, :1], out[:, 1:]], dim=1)
 
 
-def vit_ess_from_tokens(sd, tokens, Gs_data, intrinsics=None):
+def pool_attn(sd, feats, B, train=False):
+    """--noess head, src/model.py:183-188,73-82: [2B,576,192] -reshape-> [B,24,24,384] -permute-> NCHW, 1x1 conv 384->96,
+    BN, ReLU, 1x1 conv 96->43, BN, flattened c-major to [B,24768]."""
+    f = feats.reshape(B, GRID, GRID, -1).permute(0, 3, 1, 2)
+    f = F.relu(_bn(sd, "pool_attn.1", F.conv2d(f, sd["pool_attn.0.weight"], sd["pool_attn.0.bias"]), train))
+    f = _bn(sd, "pool_attn.4", F.conv2d(f, sd["pool_attn.3.weight"], sd["pool_attn.3.bias"]), train)
+    return f.reshape(B, -1)
+
+
+def vit_ess_from_tokens(sd, tokens, Gs_data, intrinsics=None, train=False, **variant):
     """Hot path only: tokens [2B,576,192] -> poses [B,2,7] (intrinsics already on the 24-grid)."""
     B = tokens.shape[0] // 2
-    return normalize_preds(Gs_data, regress(sd, vit_features(sd, tokens, intrinsics), B))
+    feats = vit_features(sd, tokens, intrinsics, **variant)
+    if variant.get("noess"):
+        feats = pool_attn(sd, feats, B, train)
+    return normalize_preds(Gs_data, regress(sd, feats, B))
 
 
-def vit_ess_forward(sd, images, Gs_data, intrinsics=None, train=False):
+def vit_ess_forward(sd, images, Gs_data, intrinsics=None, train=False, **variant):
     """ViTEss.forward end to end (src/model.py:161-191).  Mutates `intrinsics` like the reference."""
     B = images.shape[0]
     x = preprocess(images)
     if intrinsics is not None:
         intrinsics = update_intrinsics(images.shape[-2:], intrinsics)
     tokens = tokens_from_cnn(cnn_features(sd, x, train))
-    return vit_ess_from_tokens(sd, tokens, Gs_data, intrinsics), tokens
+    return vit_ess_from_tokens(sd, tokens, Gs_data, intrinsics, train, **variant), tokens
 
 
 # --------------------------------------------------------------------------------------------

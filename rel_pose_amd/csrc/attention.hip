@@ -118,8 +118,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_kernel(AttnP p) {
   const int h = zh % p.H, z = zh / p.H;
   const int q0 = (qblk * NW + wave) * 32;
   const float* qb = p.q + (long long)(z ^ p.q_xor) * NTOK * p.ldq + h * 64;
-  const float* kb = p.k + (long long)(z ^ p.k_xor) * NTOK * p.ldk + h * 64;
-  const float* vb = STATS ? nullptr : p.v + (long long)z * NTOK * p.ldv + h * 64;
+  const float* kb = p.k + (long long)(z ^ (p.k_xor & 1)) * NTOK * p.ldk + h * 64;
+  const float* vb = STATS ? nullptr : p.v + (long long)(z ^ (p.k_xor >> 1)) * NTOK * p.ldv + h * 64;
 
   float qreg[32];
   load_owner(qb + (long long)(q0 + l31) * p.ldq, hi, p.scale * RP_LOG2E, qreg);   // scores in log2 units
@@ -251,6 +251,7 @@ struct AttnBwdP {
   int H, ldq, ldk, ldv, lddo, lddq, lddk, lddv;
   float scale;
   int ZH;
+  int kv_xor;   // 1: keys/values (and dK, dV) of problem z live at image z^1 relative to its queries (cross attention)
 };
 
 template <int NW, int WPS>
@@ -265,10 +266,11 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dkdv_kernel(AttnBwdP p)
   if (!xcd_problem(NTILE / NW, p.ZH, zh, qblk)) return;
   const int h = zh % p.H, z = zh / p.H;
   const int k0 = (qblk * NW + wave) * 32;
-  const float* qb = p.q + (long long)z * NTOK * p.ldq + h * 64;
-  const float* dob = p.dout + (long long)z * NTOK * p.lddo + h * 64;
-  const float* lseb = p.lse + ((long long)z * p.H + h) * NTOK;
-  const float* delb = p.delta + ((long long)z * p.H + h) * NTOK;
+  const int zq = z ^ p.kv_xor;                       // z indexes the key/value image
+  const float* qb = p.q + (long long)zq * NTOK * p.ldq + h * 64;
+  const float* dob = p.dout + (long long)zq * NTOK * p.lddo + h * 64;
+  const float* lseb = p.lse + ((long long)zq * p.H + h) * NTOK;
+  const float* delb = p.delta + ((long long)zq * p.H + h) * NTOK;
 
   float kreg[32], vreg[32];
   load_owner(p.k + ((long long)z * NTOK + k0 + l31) * p.ldk + h * 64, hi, p.scale * RP_LOG2E, kreg);   // scale*log2e folded into K
@@ -325,8 +327,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dq_kernel(AttnBwdP p) {
   if (!xcd_problem(NTILE / NW, p.ZH, zh, qblk)) return;
   const int h = zh % p.H, z = zh / p.H;
   const int q0 = (qblk * NW + wave) * 32;
-  const float* kb = p.k + (long long)z * NTOK * p.ldk + h * 64;
-  const float* vb = p.v + (long long)z * NTOK * p.ldv + h * 64;
+  const float* kb = p.k + (long long)(z ^ p.kv_xor) * NTOK * p.ldk + h * 64;   // z indexes the query image
+  const float* vb = p.v + (long long)(z ^ p.kv_xor) * NTOK * p.ldv + h * 64;
 
   float qreg[32], dreg[32];
   load_owner(p.q + ((long long)z * NTOK + q0 + l31) * p.ldq + h * 64, hi, p.scale * RP_LOG2E, qreg);
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dq_kernel(AttnBwdP p) {
 extern "C" int rp_attn_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int Z, int H, int ldq,
                            int ldk, int ldv, int ldo, int q_xor, int k_xor, float scale, int stats_only, void* stream) {
   if (Z <= 0 || H <= 0) return RP_EBADSHAPE;
-  if ((q_xor | k_xor) & ~1) return RP_EBADSHAPE;
+  if ((q_xor & ~1) || (k_xor & ~3)) return RP_EBADSHAPE;   // k_xor: bit 0 = K from the partner image, bit 1 = V
   if ((q_xor || k_xor) && (Z & 1)) return RP_EBADSHAPE;
   if ((ldq | ldk) & 3) return RP_EALIGN;
   if (!stats_only && ((ldv | ldo) & 3)) return RP_EALIGN;
@@ -399,10 +401,10 @@ static int launch_bwd(const AttnBwdP& p, int Z, int H, int which, hipStream_t st
 
 static int attn_bwd_impl(const float* q, const float* k, const float* v, const float* dout, const float* lse,
                          const float* delta, float* dq, float* dk, float* dv, int Z, int H, int ldq, int ldk, int ldv,
-                         int lddo, int lddq, int lddk, int lddv, float scale, int which, void* stream) {
-  if (Z <= 0 || H <= 0) return RP_EBADSHAPE;
+                         int lddo, int lddq, int lddk, int lddv, float scale, int which, void* stream, int kv_xor = 0) {
+  if (Z <= 0 || H <= 0 || (kv_xor & ~1) || (kv_xor && (Z & 1))) return RP_EBADSHAPE;
   if ((ldq | ldk | ldv | lddo | lddq | lddk | lddv) & 3) return RP_EALIGN;
-  AttnBwdP p{q, k, v, dout, lse, delta, dq, dk, dv, H, ldq, ldk, ldv, lddo, lddq, lddk, lddv, scale, Z * H};
+  AttnBwdP p{q, k, v, dout, lse, delta, dq, dk, dv, H, ldq, ldk, ldv, lddo, lddq, lddk, lddv, scale, Z * H, kv_xor};
   // both passes need ~190-240 VGPRs (2 waves/SIMD = 8 wave slots per CU): 2-wave workgroups pack 4 per CU, 3-wave ones only 2
   const char* ov = getenv("RP_ATTN_NW");
   if (ov && ov[0] == '3') return launch_bwd<3>(p, Z, H, which, (hipStream_t)stream);
@@ -413,6 +415,12 @@ extern "C" int rp_attn_bwd(const float* q, const float* k, const float* v, const
                            const float* delta, float* dq, float* dk, float* dv, int Z, int H, int ldq, int ldk, int ldv,
                            int lddo, int lddq, int lddk, int lddv, float scale, void* stream) {
   return attn_bwd_impl(q, k, v, dout, lse, delta, dq, dk, dv, Z, H, ldq, ldk, ldv, lddo, lddq, lddk, lddv, scale, 3, stream);
+}
+extern "C" int rp_attn_bwd_cross(const float* q, const float* k, const float* v, const float* dout, const float* lse,
+                                 const float* delta, float* dq, float* dk, float* dv, int Z, int H, int ldq, int ldk, int ldv,
+                                 int lddo, int lddq, int lddk, int lddv, float scale, int kv_xor, void* stream) {
+  return attn_bwd_impl(q, k, v, dout, lse, delta, dq, dk, dv, Z, H, ldq, ldk, ldv, lddo, lddq, lddk, lddv, scale, 3, stream,
+                       kv_xor);
 }
 extern "C" int rp_attn_bwd_dkdv(const float* q, const float* k, const float* v, const float* dout, const float* lse,
                                 const float* delta, float* dk, float* dv, int Z, int H, int ldq, int ldk, int ldv, int lddo,

@@ -22,12 +22,13 @@ from .se3 import SE3
 class ViTEss(nn.Module):
     def __init__(self, args):
         super().__init__()
-        noess = getattr(args, "noess", None)
-        if noess:
-            raise NotImplementedError("--noess ablation is out of scope (SURVEY.md 8a row a14)")
+        noess = getattr(args, "noess", None) or None            # src/model.py:15-17: '' and absent both mean "off"
         if not getattr(args, "fusion_transformer", False):
-            raise NotImplementedError("only --fusion_transformer models exist in the reference's scripts/*.sh")
-        self.noess = None
+            # the reference's non-transformer head cannot run: pool_transformer_output leaves [2B,60,24,24], reshape([B,-1])
+            # gives 69120 columns for a Linear(34560,.) (src/model.py:63-71,180-189); with noess pool_attn gets 120 of 384
+            raise NotImplementedError("fusion_transformer=False crashes in the reference itself (src/model.py:63-71,189); "
+                                      "every scripts/*.sh passes --fusion_transformer")
+        self.noess = noess
         self.total_num_features = 192
         self.feature_resolution = (24, 24)
         self.num_images = 2
@@ -51,6 +52,14 @@ class ViTEss(nn.Module):
 
         hd = self.total_num_features // self.num_heads
         self.H = int(self.num_heads * 2 * (hd + 6) * hd)               # 26880, src/model.py:61
+        if self.noess:                                                 # src/model.py:73-82
+            self.pool_feat1, self.pool_feat2 = 96, 43
+            self.H = 24 * 24 * self.pool_feat2
+            self.pool_attn = nn.Sequential(
+                nn.Conv2d(self.total_num_features * 2, self.pool_feat1, kernel_size=1, bias=True),
+                nn.BatchNorm2d(self.pool_feat1), nn.ReLU(),
+                nn.Conv2d(self.pool_feat1, self.pool_feat2, kernel_size=1, bias=True), nn.BatchNorm2d(self.pool_feat2))
+            self.pool_attn.to(memory_format=torch.channels_last)
         self.pose_regressor = nn.Sequential(
             nn.Linear(self.H, self.H2), nn.ReLU(), nn.Linear(self.H2, self.H2), nn.ReLU(),
             nn.Linear(self.H2, self.num_images * self.pose_size), nn.Unflatten(1, (self.num_images, self.pose_size)))
@@ -99,6 +108,17 @@ class ViTEss(nn.Module):
         for layer in range(self.transformer_depth):
             x = ft.blocks[layer](x, intrinsics=intrinsics)
         pr = self.pose_regressor
+        if self.noess:
+            # src/model.py:178,183-188.  features.reshape([B,24,24,-1]).permute(0,3,1,2) on the contiguous [2B,576,192] norm
+            # output: "pixel" m of pair b holds tokens 2m, 2m+1 of the concatenated (image 0, image 1) token list -- in
+            # channels-last memory that NCHW tensor IS the buffer, so the 1x1-conv/BN head (MIOpen, like the CNN front
+            # end) runs on a view; only its [B,43,24,24] output is re-laid out (c-major) for the regressor.
+            B = x.shape[0] // 2
+            f = ops.LayerNormFn.apply(x, ft.norm.weight, ft.norm.bias)
+            pooled = self.pool_attn(f.view(B, 24, 24, 2 * self.total_num_features).permute(0, 3, 1, 2))
+            feats = pooled.contiguous(memory_format=torch.contiguous_format).reshape(B, -1)
+            return ops.RegressFn.apply(feats, Gs_data, pr[0].weight, pr[0].bias, pr[2].weight, pr[2].bias, pr[4].weight,
+                                       pr[4].bias)
         return ops.HeadFn.apply(x, Gs_data, ft.norm.weight, ft.norm.bias, pr[0].weight, pr[0].bias, pr[2].weight,
                                 pr[2].bias, pr[4].weight, pr[4].bias)
 

@@ -4,9 +4,9 @@ Same class names, constructor arguments, attribute names (=> identical ``state_d
 signatures as reference src/modules/vision_transformer.py (Attention :307-333, Block :336-354,
 CrossAttention :160-238, CrossBlock :265-296, VisionTransformer :357-443) and vit_layers/mlp.py:8-26,
 but the modules hold parameters only: the arithmetic of a whole Block / CrossBlock runs as one autograd
-Function over hand-written gfx950 kernels (rel_pose_amd/ops.py).  Ablation flags: cross_features, use_single_softmax and l1_pos_encoding are implemented
-(forward and backward, pinned against the reference); noess (a different head) and no_pos_encoding (crashes in the
-reference itself) are rejected loudly.
+Function over hand-written gfx950 kernels (rel_pose_amd/ops.py).  Ablation flags: cross_features,
+use_single_softmax, l1_pos_encoding and noess are implemented (forward and backward, pinned against the reference);
+no_pos_encoding, which crashes in the reference itself, is rejected loudly.
 """
 import torch
 import torch.nn as nn
@@ -65,9 +65,7 @@ class CrossAttention(nn.Module):
     def __init__(self, dim, num_heads=8, qkv_bias=False, attn_drop=0., proj_drop=0., cross_features=False,
                  use_single_softmax=False, no_pos_encoding=False, noess=False, l1_pos_encoding=False):
         super().__init__()
-        if noess:
-            raise NotImplementedError("--noess (plain cross attention + conv pooling head) is out of scope (SURVEY.md 8a a14)")
-        if no_pos_encoding:
+        if no_pos_encoding and not noess:
             raise NotImplementedError("--no_pos_encoding cannot run in the reference either: proj_fundamental is always "
                                       "Linear(210,192) (vision_transformer.py:179) but the flag feeds it 192 columns (:225-227)")
         self.cross_features, self.use_single_softmax, self.l1_pos_encoding = cross_features, use_single_softmax, l1_pos_encoding
@@ -75,7 +73,11 @@ class CrossAttention(nn.Module):
         self.scale = (dim // num_heads) ** -0.5
         self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
         self.attn_drop = nn.Dropout(attn_drop)
-        self.proj_fundamental = nn.Linear(dim + 6 * num_heads, dim)
+        self.noess = noess
+        if noess:       # plain cross attention: softmax(q_i k_partner^T) v_partner (vision_transformer.py:176-177,239-262)
+            self.proj = nn.Linear(dim, dim)
+        else:
+            self.proj_fundamental = nn.Linear(dim + 6 * num_heads, dim)
         self.proj_drop = nn.Dropout(proj_drop)
 
 
@@ -96,7 +98,8 @@ class CrossBlock(nn.Module):
         self.strict_intrinsics = False
 
     def forward(self, x, camera=None, intrinsics=None):
-        """x [2B,576,192] (images 2b, 2b+1 form pair b) -> [2B,70,192].  `intrinsics` [B,2,4] on the 24x24 grid."""
+        """x [2B,576,192] (images 2b, 2b+1 form pair b) -> [2B,70,192] ([2B,576,192] with noess).
+        `intrinsics` [B,2,4] on the 24x24 grid."""
         B = x.shape[0] // 2
         if intrinsics is not None:
             intrinsics = intrinsics.to(device=x.device, dtype=torch.float32).contiguous()
@@ -104,6 +107,10 @@ class CrossBlock(nn.Module):
                 assert bool(torch.all(intrinsics[:, 0] == intrinsics[:, 1])), "intrinsics differ within a pair"
                 assert float(intrinsics[0, 0, 2] * intrinsics[0, 0, 3]) != 0.0, "principal point at the origin"
         a, m = self.cross_attn, self.mlp
+        if self.noess:  # x + CrossAttn(LN1(x)); + Mlp(LN2(.)) (vision_transformer.py:297-304): a Block with partner keys/values
+            return ops.BlockFn.apply(x, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight,
+                                     a.proj.bias, self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias,
+                                     m.fc2.weight, m.fc2.bias, True)
         pos = ops.posenc(intrinsics, B, x.device, l1=a.l1_pos_encoding)
         return ops.CrossBlockFn.apply(x, pos, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias,
                                       a.proj_fundamental.weight, a.proj_fundamental.bias, self.norm2.weight,

@@ -256,7 +256,8 @@ def layernorm_bwd(dy, x2d, gamma, mean, rstd, add=None):
 
 
 def attn_fwd(qkv, Z, stats_only=False, q_off=0, k_off=DIM, v_off=2 * DIM, q_xor=0, k_xor=0):
-    """qkv [Z*576, 576] packed (q | k | v, head-major columns).  Returns (o [Z*576,192] or None, lse [Z,H,576])."""
+    """qkv [Z*576, 576] packed (q | k | v, head-major columns).  Returns (o [Z*576,192] or None, lse [Z,H,576]).
+    k_xor: bit 0 takes K, bit 1 takes V from the partner image of the pair (3 = --noess cross attention)."""
     lib = _lib.load()
     _chk(qkv)
     ld = qkv.shape[1]
@@ -270,9 +271,10 @@ def attn_fwd(qkv, Z, stats_only=False, q_off=0, k_off=DIM, v_off=2 * DIM, q_xor=
     return o, lse
 
 
-def attn_bwd(qkv, o, lse, do, Z, fork=None):
+def attn_bwd(qkv, o, lse, do, Z, fork=None, kv_xor=0):
     """dqkv of the fused attention.  With a _Fork the dQ pass runs on the side stream next to the dK/dV pass (they write
-    disjoint column blocks of dqkv); the caller must fork.sync_main() before reading dqkv."""
+    disjoint column blocks of dqkv); the caller must fork.sync_main() before reading dqkv.
+    kv_xor=1: backward of attn_fwd(..., k_xor=3) (keys/values from the partner image)."""
     lib = _lib.load()
     _chk(qkv, o, lse, do)
     ld = qkv.shape[1]
@@ -282,6 +284,11 @@ def attn_bwd(qkv, o, lse, do, Z, fork=None):
     P = ctypes.c_void_p
     b, d = qkv.data_ptr(), dqkv.data_ptr()
     sc = (DIM // HEADS) ** -0.5
+    if kv_xor:
+        _lib.check(lib.rp_attn_bwd_cross(P(b), P(b + 4 * DIM), P(b + 8 * DIM), _p(do), _p(lse), _p(delta), P(d),
+                                         P(d + 4 * DIM), P(d + 8 * DIM), Z, HEADS, ld, ld, ld, DIM, ld, ld, ld, sc, 1, _st()),
+                   "rp_attn_bwd_cross")
+        return dqkv
     if fork is None or not fork.enabled:
         _lib.check(lib.rp_attn_bwd(P(b), P(b + 4 * DIM), P(b + 8 * DIM), _p(do), _p(lse), _p(delta), P(d), P(d + 4 * DIM),
                                    P(d + 8 * DIM), Z, HEADS, ld, ld, ld, DIM, ld, ld, ld, sc, _st()), "rp_attn_bwd")
@@ -490,14 +497,17 @@ class BlockFn(torch.autograd.Function):
     """Block.forward (vision_transformer.py:349-354) on x [Z,576,192]."""
 
     @staticmethod
-    def forward(ctx, x, n1w, n1b, qkv_w, qkv_b, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b):
+    def forward(ctx, x, n1w, n1b, qkv_w, qkv_b, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b, cross=False):
+        """cross=True: keys and values come from the partner image of each pair -- the --noess CrossBlock
+        (vision_transformer.py:239-262,297-304), which is otherwise arithmetically a Block."""
         train = any(ctx.needs_input_grad)   # (grad mode is off inside Function.forward)
         x = x.contiguous()
         Z = x.shape[0]
         x2 = x.view(Z * N_TOK, DIM)
         xn1, m1, r1 = layernorm_fwd(x2, n1w, n1b)
         qkv = linear(xn1, qkv_w, qkv_b)
-        o, lse = attn_fwd(qkv, Z)
+        o, lse = attn_fwd(qkv, Z, k_xor=3 if cross else 0)
+        ctx.cross = cross
         x1 = linear(o, proj_w, proj_b, residual=x2)
         xn2, m2, r2 = layernorm_fwd(x1, n2w, n2b)
         y, h, hpre = _mlp_fwd(xn2, fc1_w, fc1_b, fc2_w, fc2_b, x1, train)
@@ -519,7 +529,7 @@ class BlockFn(torch.autograd.Function):
         fork.sync_side()
         dprojw, dprojb = _param_grads(fork, dx1, o)
         do = linear_dx(dx1, proj_w)
-        dqkv = attn_bwd(qkv, o, lse, do, Z, fork)
+        dqkv = attn_bwd(qkv, o, lse, do, Z, fork, kv_xor=1 if ctx.cross else 0)
         fork.sync_main()                                  # dQ pass (side) done before dqkv is consumed
         fork.sync_side()
         dqkvw, dqkvb = _param_grads(fork, dqkv, xn1)
@@ -527,7 +537,7 @@ class BlockFn(torch.autograd.Function):
         dx, dn1w, dn1b = layernorm_bwd(dxn1, x2, n1w, m1, r1, add=dx1)
         fork.sync_main()
         return (dx.view(Z, N_TOK, DIM), dn1w, dn1b, dqkvw, dqkvb, dprojw, dprojb, dn2w, dn2b, dfc1w, dfc1b, dfc2w,
-                dfc2b)
+                dfc2b, None)
 
 
 class CrossBlockFn(torch.autograd.Function):
@@ -583,29 +593,51 @@ class CrossBlockFn(torch.autograd.Function):
                 dfc2b, None, None)
 
 
+def _regress_fwd(feats, gs, w0, b0, w2, b2, w4, b4):
+    """H-512-512-14 MLP + quaternion normalise (src/model.py:91-98,145-159) on feats [B,H]."""
+    lib = _lib.load()
+    B = feats.shape[0]
+    h1 = linear(feats, w0, b0, act=2)
+    h2 = linear(h1, w2, b2, act=2)
+    w4p = torch.nn.functional.pad(w4, (0, 0, 0, 2)).contiguous()    # 14 -> 16 output rows (float4 alignment)
+    b4p = torch.nn.functional.pad(b4, (0, 2)).contiguous()
+    pred = linear(h2, w4p, b4p)[:, :14].contiguous()               # [B,14] == [B,2,7]
+    gs = gs.contiguous()
+    _chk(gs)
+    out = _empty(B, 2, 7, like=feats)
+    _lib.check(lib.rp_pose_normalize_fwd(_p(pred), _p(gs), _p(out), B, _st()), "rp_pose_normalize_fwd")
+    return out, h1, h2, pred, w4p
+
+
+def _regress_bwd(dout, feats, h1, h2, pred, w0, w2, w4p):
+    lib = _lib.load()
+    B = feats.shape[0]
+    dout = dout.contiguous()
+    dpred = _empty(B, 14, like=dout)
+    _lib.check(lib.rp_pose_normalize_bwd(_p(pred), _p(dout), _p(dpred), B, _st()), "rp_pose_normalize_bwd")
+    dp16 = torch.nn.functional.pad(dpred, (0, 2)).contiguous()
+    dh2 = linear_dx(dp16, w4p, dact=2, aux=h2)
+    dw4, db4 = linear_dw(dp16, h2)[:14].contiguous(), colsum(dpred)
+    dh1 = linear_dx(dh2, w2, dact=2, aux=h1)
+    dw2, db2 = linear_dw(dh2, h1), colsum(dh2)
+    dfeats = linear_dx(dh1, w0)
+    dw0, db0 = linear_dw(dh1, feats), colsum(dh1)
+    return dfeats, dw0, db0, dw2, db2, dw4, db4
+
+
 class HeadFn(torch.autograd.Function):
     """final LayerNorm -> flatten [B,26880] -> 26880-512-512-14 MLP -> quaternion normalise
     (src/model.py:178,189,91-98,145-159).  y: [2B,70,192]; gs: [B,2,7] -> [B,2,7]."""
 
     @staticmethod
     def forward(ctx, y, gs, nw, nb, w0, b0, w2, b2, w4, b4):
-        lib = _lib.load()
         train = any(ctx.needs_input_grad)   # (grad mode is off inside Function.forward)
         y = y.contiguous()
         Z = y.shape[0]
         B = Z // 2
         y2 = y.view(Z * 70, DIM)
         fn, m, r = layernorm_fwd(y2, nw, nb)
-        feats = fn.view(B, 2 * 70 * DIM)
-        h1 = linear(feats, w0, b0, act=2)
-        h2 = linear(h1, w2, b2, act=2)
-        w4p = torch.nn.functional.pad(w4, (0, 0, 0, 2)).contiguous()    # 14 -> 16 output rows (float4 alignment)
-        b4p = torch.nn.functional.pad(b4, (0, 2)).contiguous()
-        pred = linear(h2, w4p, b4p)[:, :14].contiguous()               # [B,14] == [B,2,7]
-        gs = gs.contiguous()
-        _chk(gs)
-        out = _empty(B, 2, 7, like=y)
-        _lib.check(lib.rp_pose_normalize_fwd(_p(pred), _p(gs), _p(out), B, _st()), "rp_pose_normalize_fwd")
+        out, h1, h2, pred, w4p = _regress_fwd(fn.view(B, 2 * 70 * DIM), gs, w0, b0, w2, b2, w4, b4)
         if train:
             ctx.save_for_backward(y2, m, r, fn, h1, h2, pred, nw, w0, w2, w4p)
             ctx.B = B
@@ -613,19 +645,48 @@ class HeadFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        lib = _lib.load()
         y2, m, r, fn, h1, h2, pred, nw, w0, w2, w4p = ctx.saved_tensors
         B = ctx.B
-        dout = dout.contiguous()
-        dpred = _empty(B, 14, like=dout)
-        _lib.check(lib.rp_pose_normalize_bwd(_p(pred), _p(dout), _p(dpred), B, _st()), "rp_pose_normalize_bwd")
-        dp16 = torch.nn.functional.pad(dpred, (0, 2)).contiguous()
-        dh2 = linear_dx(dp16, w4p, dact=2, aux=h2)
-        dw4, db4 = linear_dw(dp16, h2)[:14].contiguous(), colsum(dpred)
-        dh1 = linear_dx(dh2, w2, dact=2, aux=h1)
-        dw2, db2 = linear_dw(dh2, h1), colsum(dh2)
-        feats = fn.view(B, -1)
-        dfeats = linear_dx(dh1, w0)
-        dw0, db0 = linear_dw(dh1, feats), colsum(dh1)
+        dfeats, dw0, db0, dw2, db2, dw4, db4 = _regress_bwd(dout, fn.view(B, -1), h1, h2, pred, w0, w2, w4p)
         dy, dnw, dnb = layernorm_bwd(dfeats.view(-1, DIM), y2, nw, m, r)
         return dy.view(2 * B, 70, DIM), None, dnw, dnb, dw0, db0, dw2, db2, dw4, db4
+
+
+class RegressFn(torch.autograd.Function):
+    """pose regressor + quaternion normalise on already-pooled features [B,H] (the --noess head, src/model.py:79-86,188)."""
+
+    @staticmethod
+    def forward(ctx, feats, gs, w0, b0, w2, b2, w4, b4):
+        train = any(ctx.needs_input_grad)
+        feats = feats.contiguous()
+        _chk(feats)
+        out, h1, h2, pred, w4p = _regress_fwd(feats, gs, w0, b0, w2, b2, w4, b4)
+        if train:
+            ctx.save_for_backward(feats, h1, h2, pred, w0, w2, w4p)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        feats, h1, h2, pred, w0, w2, w4p = ctx.saved_tensors
+        dfeats, dw0, db0, dw2, db2, dw4, db4 = _regress_bwd(dout, feats, h1, h2, pred, w0, w2, w4p)
+        return dfeats, None, dw0, db0, dw2, db2, dw4, db4
+
+
+class LayerNormFn(torch.autograd.Function):
+    """LayerNorm over the last dim (C = 192) on the rowwise HIP kernels: the final norm of the --noess model, whose output
+    feeds a conv head instead of HeadFn (src/model.py:178,183-188)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = x.contiguous()
+        x2 = x.view(-1, x.shape[-1])
+        y, m, r = layernorm_fwd(x2, w, b)
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(x2, m, r, w)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, m, r, w = ctx.saved_tensors
+        dx, dw, db = layernorm_bwd(dy.contiguous().view(x2.shape), x2, w, m, r)
+        return dx.view(dy.shape), dw, db

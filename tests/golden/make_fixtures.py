@@ -234,5 +234,74 @@ def main():
     print("wrote reference_outputs.npz: %d arrays, %.1f KB" % (len(out), sz / 1024))
 
 
+def noess_fixtures():
+    """SURVEY 8a row a14, --noess: plain cross attention in blocks[5] + pool_attn conv head.  Separate file so the
+    default-configuration vectors above stay byte-stable."""
+    out = {}
+    B = 2
+    model = ViTEss(ref_args(noess="1")).eval()
+    with open(os.path.join(HERE, "state_dict_keys_noess.json"), "w") as f:
+        json.dump({k: list(v.shape) for k, v in model.state_dict().items()}, f, indent=0, sort_keys=True)
+    shapes = dict(O.vit_param_shapes(noess=True))
+    shapes.update(O.cnn_param_shapes())
+    sd32 = O.make_state(shapes, torch.float32)
+    sd64 = O.make_state(shapes, torch.float64)
+    missing, unexpected = model.load_state_dict(sd32, strict=False)
+    assert not unexpected, unexpected
+    assert all(k.startswith("resnet.layer3") or k.startswith("resnet.layer4") for k in missing), missing
+    model64 = ViTEss(ref_args(noess="1")).eval()
+    model64.load_state_dict(sd32, strict=False)
+    model64 = model64.double()
+    model64.load_state_dict(sd64, strict=False)
+    intr = intrinsics_24()
+    Gs = torch.tensor([0, 0, 0, 0, 0, 0, 1.0]).repeat(B, 2, 1)
+
+    def from_tokens(m, tok, train):
+        m.train(train)
+        ft = m.fusion_transformer
+        x = tok + ft.pos_embed
+        for l in range(6):
+            x = ft.blocks[l](x, intrinsics=intr.clone().to(tok.dtype))
+        feats = ft.norm(x)
+        f = feats.reshape([B, 24, 24, -1]).permute([0, 3, 1, 2])            # src/model.py:185
+        pp = m.pose_regressor(m.pool_attn(f).reshape([B, -1]))
+        pose = m.normalize_preds(SE3(Gs.to(tok.dtype)), pp, False)[0].data
+        m.eval()
+        return feats, pose
+
+    # full model first: the train-mode passes below update pool_attn's BatchNorm running statistics
+    imgs = O.synthetic_images(B, 384, 384, key=7)
+    intr_px = torch.tensor([[0.9 * 384, 0.8 * 384, 192.0, 192.0]]).repeat(B, 2, 1).contiguous()
+    with torch.no_grad():
+        out["noess_full_sq_pose_f32"] = model(imgs.clone(), SE3(Gs), intrinsics=intr_px.clone())[0].data.numpy()
+        out["noess_full_sq_pose_f64"] = model64(imgs.double(), SE3(Gs.double()), intrinsics=intr_px.clone().double())[0].data.numpy()
+    with torch.no_grad():
+        f32, p32 = from_tokens(model, O.synthetic_tokens(2 * B), False)
+    out["noess_feat_sub_f32"] = subsample(f32, 23)
+    out["noess_pose_from_tokens_f32"] = p32.numpy()
+    for train in (False, True):       # eval before train for the same reason
+        tag = "train" if train else "eval"
+        tok64 = O.synthetic_tokens(2 * B, dtype=torch.float64).requires_grad_(True)
+        for p_ in model64.parameters():
+            p_.grad = None
+        f64, p64 = from_tokens(model64, tok64, train)
+        out["noess_pose_from_tokens_%s_f64" % tag] = p64.detach().numpy()
+        if not train:
+            out["noess_feat_sub_f64"] = subsample(f64, 23)
+        cot = O.closed_form((B, 7), 993, 1.0, dtype=torch.float64)
+        (p64[:, 1] * cot).sum().backward()
+        out["noess_grad_tokens_sub_%s_f64" % tag] = subsample(tok64.grad)
+        ca = model64.fusion_transformer.blocks[5].cross_attn
+        out["noess_grad_sums_%s_f64" % tag] = np.stack([summarize(ca.qkv.weight.grad), summarize(ca.proj.weight.grad),
+                                                         summarize(model64.pool_attn[0].weight.grad),
+                                                         summarize(model64.pool_attn[4].weight.grad),
+                                                         summarize(model64.pose_regressor[0].weight.grad)])
+    np.savez_compressed(os.path.join(HERE, "reference_outputs_noess.npz"), **out)
+    print("wrote reference_outputs_noess.npz: %d arrays, %.1f KB" %
+          (len(out), os.path.getsize(os.path.join(HERE, "reference_outputs_noess.npz")) / 1024))
+
+
 if __name__ == "__main__":
-    main()
+    if "--noess-only" not in sys.argv:
+        main()
+    noess_fixtures()

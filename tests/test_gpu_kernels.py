@@ -213,6 +213,26 @@ def test_attention_fwd_bwd(ops):
     assert max(e) < 2e-5
 
 
+def test_cross_attention_is_attention_on_partner_keys_values(ops):
+    """--noess cross attention (vision_transformer.py:239-262): rp_attn_fwd(k_xor=3) / rp_attn_bwd_cross(kv_xor=1) must be
+    BIT-identical to the plain kernels run on a copy whose k|v columns are pair-swapped (same tiles, same order)."""
+    Z = 6
+    qkv = rnd(Z * 576, 576, seed=21)
+    sw = qkv.clone().view(Z, 576, 576)
+    sw[:, :, 192:] = ops.pair_swap(qkv.view(Z, 576, 576))[:, :, 192:]
+    sw = sw.view(Z * 576, 576).contiguous()
+    o_x, lse_x = ops.attn_fwd(qkv, Z, k_xor=3)
+    o_s, lse_s = ops.attn_fwd(sw, Z)
+    assert torch.equal(o_x, o_s) and torch.equal(lse_x, lse_s)
+    do = rnd(Z * 576, 192, seed=22)
+    d_x = ops.attn_bwd(qkv, o_x, lse_x, do, Z, kv_xor=1).view(Z, 576, 576)
+    d_s = ops.attn_bwd(sw, o_s, lse_s, do, Z).view(Z, 576, 576)
+    assert torch.equal(d_x[:, :, :192], d_s[:, :, :192])                                # dq stays with the query image
+    assert torch.equal(d_x[:, :, 192:], ops.pair_swap(d_s)[:, :, 192:])                 # dk, dv land on the partner image
+    with pytest.raises(RuntimeError):
+        ops.attn_fwd(qkv[:5 * 576].contiguous(), 5, k_xor=3)                            # odd image count has no pairs
+
+
 def test_attention_stats_partner(ops):
     Z = 4
     qkv = rnd(Z * 576, 576, seed=3)

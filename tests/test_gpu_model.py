@@ -280,3 +280,77 @@ def test_odd_batch_sizes_fwd_bwd(model, states, B):
         assert max(t_err, q_err) < 1e-4 and e_tok < 1e-3 and e_w < 1e-3
     finally:
         model.eval()
+
+
+# ---- --noess ablation: plain cross attention + pool_attn head ---------------------------------------
+@pytest.fixture(scope="module")
+def golden_noess():
+    return np.load(os.path.join(ROOT, "tests", "golden", "reference_outputs_noess.npz"))
+
+
+def _noess_model(train):
+    from rel_pose_amd.model import ViTEss
+    shapes = dict(O.vit_param_shapes(noess=True))
+    shapes.update(O.cnn_param_shapes())
+    a = make_args()
+    a.noess = "1"
+    m = ViTEss(a)
+    m.load_state_dict(O.make_state(shapes, torch.float32), strict=True)
+    return m.cuda().train(train)
+
+
+def test_noess_state_dict_keys():
+    from rel_pose_amd.model import ViTEss
+    a = make_args()
+    a.noess = "1"
+    with open(os.path.join(ROOT, "tests", "golden", "state_dict_keys_noess.json")) as f:
+        ref = json.load(f)
+    sd = ViTEss(a).state_dict()
+    assert {k: list(v.shape) for k, v in sd.items() if "layer3" not in k and "layer4" not in k} == \
+        {k: v for k, v in ref.items() if "layer3" not in k and "layer4" not in k}
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_noess_fwd_bwd_vs_reference(golden_noess, train):
+    """tokens -> 5 Blocks -> cross-attention CrossBlock -> LN -> pool_attn -> regressor, forward and backward, against the
+    REAL reference's fp64 outputs and autograd; train=True uses batch statistics in pool_attn's BatchNorms."""
+    m = _noess_model(train)
+    tag = "train" if train else "eval"
+    tok = O.synthetic_tokens(4)
+    fmap = tok.permute(0, 2, 1).contiguous().view(4, 192, 24, 24).cuda().requires_grad_(True)
+    Gs = torch.tensor([0, 0, 0, 0, 0, 0, 1.0]).repeat(2, 2, 1).cuda()
+    pose = m.forward_tokens(fmap, Gs, intr24().cuda())
+    ref = torch.from_numpy(golden_noess["noess_pose_from_tokens_%s_f64" % tag])
+    t_err, q_err, ang = O.pose_errors(pose.detach().cpu(), ref)
+    cot = O.closed_form((2, 7), 993, 1.0, dtype=torch.float64).float().cuda()
+    (pose[:, 1] * cot).sum().backward()
+    e_g = rel(fmap.grad.view(4, 192, 576).permute(0, 2, 1).reshape(-1)[::37], golden_noess["noess_grad_tokens_sub_%s_f64" % tag])
+    ca = m.fusion_transformer.blocks[5].cross_attn
+    errs = []
+    for i, w in enumerate([ca.qkv.weight, ca.proj.weight, m.pool_attn[0].weight, m.pool_attn[4].weight,
+                           m.pose_regressor[0].weight]):
+        g = w.grad.double().reshape(-1).cpu()
+        r = golden_noess["noess_grad_sums_%s_f64" % tag][i]
+        errs.append(max(float(np.abs(g[:16].numpy() - r[3:]).max() / np.abs(r[3:]).max()),
+                        abs(float(g.abs().sum()) - r[1]) / r[1]))
+    report("noess_" + tag, t=t_err, q=q_err, grad_tokens=e_g, grad_params=max(errs))
+    assert max(t_err, q_err) < 1e-4 and e_g < 1e-3 and max(errs) < 2e-3
+
+
+def test_noess_features_and_full_model(golden_noess):
+    from rel_pose_amd import ops
+    m = _noess_model(False)
+    ft = m.fusion_transformer
+    with torch.no_grad():
+        x = O.synthetic_tokens(4).cuda() + ft.pos_embed
+        for l in range(6):
+            x = ft.blocks[l](x, intrinsics=intr24().cuda())
+        feats = ops.LayerNormFn.apply(x, ft.norm.weight, ft.norm.bias)
+        e_f = rel(feats.reshape(-1)[::23], golden_noess["noess_feat_sub_f64"])
+        imgs = O.synthetic_images(2, 384, 384, key=7).cuda()
+        intr = torch.tensor([[0.9 * 384, 0.8 * 384, 192.0, 192.0]]).repeat(2, 2, 1).contiguous().cuda()
+        from rel_pose_amd.se3 import SE3
+        pose = m(imgs, SE3(torch.tensor([0, 0, 0, 0, 0, 0, 1.0]).repeat(2, 2, 1).cuda()), intrinsics=intr)[0].data
+    t_err, q_err, ang = O.pose_errors(pose.cpu(), torch.from_numpy(golden_noess["noess_full_sq_pose_f64"]))
+    report("noess_full", feats=e_f, t=t_err, q=q_err)
+    assert e_f < 1e-3 and max(t_err, q_err) < 1e-4     # same bounds as the default model

@@ -59,9 +59,20 @@ def test_state_dict_contract_and_dropin_alias():
 
 def test_unsupported_variants_are_rejected_loudly():
     from rel_pose_amd.model import ViTEss
-    for kw in (dict(noess="1"), dict(no_pos_encoding=True), dict(fusion_transformer=False)):
+    # both crash inside the reference itself (vision_transformer.py:179 vs :225-227; src/model.py:63-71 vs :189)
+    for kw in (dict(no_pos_encoding=True), dict(fusion_transformer=False)):
         with pytest.raises(NotImplementedError):
             ViTEss(make_args(**kw))
+
+
+def test_noess_model_has_the_reference_state_dict():
+    import json
+    from rel_pose_amd.model import ViTEss
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "state_dict_keys_noess.json")) as f:
+        ref = json.load(f)
+    m = ViTEss(make_args(noess="1"))
+    assert {k: list(v.shape) for k, v in m.state_dict().items()} == ref
+    assert m.H == 24768 and m.pose_regressor[0].in_features == 24768      # src/model.py:74
 
 
 def test_no_cpu_fallback():

@@ -86,7 +86,7 @@ def test_gradients_fp64(golden, states):
     _, sd64 = states
     with open(os.path.join(HERE, "golden", "grad_param_names.json")) as f:
         names = json.load(f)
-    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd64.items()}
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v) for k, v in sd64.items()}
     tok = O.synthetic_tokens(4, dtype=torch.float64).requires_grad_(True)
     f = O.vit_features(sd, tok, intr24(torch.float64))
     cot = O.closed_form(tuple(f.shape), 991, 1.0, dtype=torch.float64)
@@ -152,3 +152,70 @@ def test_ablation_variants_fp64(golden, states, tag):
     cot = O.closed_form(tuple(f.shape), 991, 1.0, dtype=torch.float64)
     (f * cot).sum().backward()
     assert rel(tok.grad.reshape(-1)[::37], golden["variant_%s_grad_tokens_sub_f64" % tag]) < 1e-7
+
+
+# ---- --noess ablation (vision_transformer.py:239-262,297-304; src/model.py:73-82,183-188) ----------------------------
+@pytest.fixture(scope="module")
+def golden_noess():
+    return np.load(os.path.join(HERE, "golden", "reference_outputs_noess.npz"))
+
+
+@pytest.fixture(scope="module")
+def states_noess():
+    shapes = dict(O.vit_param_shapes(noess=True))
+    shapes.update(O.cnn_param_shapes())
+    return O.make_state(shapes, torch.float32), O.make_state(shapes, torch.float64)
+
+
+def test_noess_state_dict_keys_match_reference():
+    with open(os.path.join(HERE, "golden", "state_dict_keys_noess.json")) as f:
+        ref = json.load(f)
+    mine = dict(O.vit_param_shapes(noess=True))
+    mine.update(O.cnn_param_shapes())
+    assert set(mine) == set(ref)
+    for k, shp in mine.items():
+        assert list(shp) == ref[k], k
+
+
+def _noess_grad_sums(sd):
+    def summ(g):
+        g = g.double().reshape(-1)
+        return np.concatenate([[float(g.sum()), float(g.abs().sum()), float((g * g).sum())], g[:16].numpy()])
+    keys = ["fusion_transformer.blocks.5.cross_attn.qkv.weight", "fusion_transformer.blocks.5.cross_attn.proj.weight",
+            "pool_attn.0.weight", "pool_attn.4.weight", "pose_regressor.0.weight"]
+    return np.stack([summ(sd[k].grad) for k in keys])
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_noess_fp64_forward_and_gradients(golden_noess, states_noess, train):
+    _, sd64 = states_noess
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v) for k, v in sd64.items()}
+    tag = "train" if train else "eval"
+    tok = O.synthetic_tokens(4, dtype=torch.float64).requires_grad_(True)
+    Gs = torch.tensor([0, 0, 0, 0, 0, 0, 1.0], dtype=torch.float64).repeat(2, 2, 1)
+    if not train:
+        with torch.no_grad():
+            f = O.vit_features(sd, tok, intr24(torch.float64), noess=True)
+        assert rel(f.reshape(-1)[::23], golden_noess["noess_feat_sub_f64"]) < 1e-9
+    pose = O.vit_ess_from_tokens(sd, tok, Gs, intr24(torch.float64), train=train, noess=True)
+    assert rel(pose, golden_noess["noess_pose_from_tokens_%s_f64" % tag]) < 1e-9
+    cot = O.closed_form((2, 7), 993, 1.0, dtype=torch.float64)
+    (pose[:, 1] * cot).sum().backward()
+    assert rel(tok.grad.reshape(-1)[::37], golden_noess["noess_grad_tokens_sub_%s_f64" % tag]) < 1e-7
+    assert rel(_noess_grad_sums(sd), golden_noess["noess_grad_sums_%s_f64" % tag]) < 1e-7
+
+
+def test_noess_fp32_and_full_model(golden_noess, states_noess):
+    sd32, sd64 = states_noess
+    Gs = torch.tensor([0, 0, 0, 0, 0, 0, 1.0]).repeat(2, 2, 1)
+    with torch.no_grad():
+        f = O.vit_features(sd32, O.synthetic_tokens(4), intr24(), noess=True)
+        assert rel(f.reshape(-1)[::23], golden_noess["noess_feat_sub_f32"]) < 2e-4
+        p = O.vit_ess_from_tokens(sd32, O.synthetic_tokens(4), Gs, intr24(), noess=True)
+        assert rel(p, golden_noess["noess_pose_from_tokens_f32"]) < 2e-4
+        imgs = O.synthetic_images(2, 384, 384, key=7)
+        intr = torch.tensor([[0.9 * 384, 0.8 * 384, 192.0, 192.0]]).repeat(2, 2, 1).contiguous()
+        pose64, _ = O.vit_ess_forward(sd64, imgs.double(), Gs.double(), intr.clone().double(), noess=True)
+        assert rel(pose64, golden_noess["noess_full_sq_pose_f64"]) < 1e-7
+        pose32, _ = O.vit_ess_forward(sd32, imgs, Gs, intr.clone(), noess=True)
+        assert rel(pose32, golden_noess["noess_full_sq_pose_f32"]) < 1e-3

@@ -23,6 +23,8 @@ import torch
 import torch.distributed as dist
 
 FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+BF16_MFMA_PEAK_TFLOPS = 2500.0       # same guide, dense bf16 MFMA (never the 2:1-sparsity figure)
+PRECISIONS = {"split3": 3, "fp32": 0, "bf16": 1}
 FLOPS_FWD_PER_PAIR = 8588216320      # GEMM flops of the ViT+EMM+regressor hot path, forward
 METRIC = "image-pairs/sec fwd+bwd @384x384, 1/2/4/8 MI355X; R,t err vs ref"
 
@@ -126,6 +128,10 @@ def main():
                     help="full = images -> CNN -> hot path (the metric); hot = synthetic CNN maps -> hot path only "
                          "(kernel profiling; not the headline number)")
     ap.add_argument("--timer-instance", default="0,0,2,1", help="gemm_kernel<aL,bL,TM,TN> instance timed for `roofline`")
+    ap.add_argument("--precision", default="split3", choices=tuple(PRECISIONS),
+                    help="how rp_gemm multiplies its fp32 operands: split3 = three bf16 limbs per operand, six limb products "
+                         "on the bf16 MFMA pipe, fp32-grade results (default); fp32 = exact v_mfma_f32_32x32x2_f32; "
+                         "bf16 = operands truncated to bf16 (BASELINE.json configs[4]; NOT the headline metric)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -193,6 +199,7 @@ def main():
         with torch.no_grad():
             return net(images, Gs, intrinsics=intr.clone())[0].data
 
+    ops.set_gemm_precision(PRECISIONS[args.precision])
     timer = ops.KernelTimer([int(v) for v in args.timer_instance.split(",")])
     ops.TIMER = timer
     eager_step = step
@@ -249,29 +256,43 @@ def main():
         achieved = flops / max(n_launch, 1) / max(t_launch, 1e-12) / 1e12
         pairs = world * args.batch * args.steps
         traffic, traffic_src = None, None
+        nl = PRECISIONS[args.precision]
+        kname = "gemm_kernel<%s, %d>" % (", ".join(args.timer_instance.split(",")), nl)
+        # matrix-pipe ceiling of the timed kernel in ALGORITHMIC (2MNK) flops: the exact-fp32 MFMA peak, or the dense
+        # bf16 MFMA peak divided by the limb products issued per fp32 product (6 for split3, 1 for bf16)
+        peak = {0: FP32_MFMA_PEAK_TFLOPS, 3: BF16_MFMA_PEAK_TFLOPS / 6.0, 1: BF16_MFMA_PEAK_TFLOPS}[nl]
+        peak_note = {0: "fp32 MFMA peak (v_mfma_f32_32x32x2_f32)",
+                     3: "dense bf16 MFMA peak 2500 TF / 6 limb products per fp32 multiply-add (v_mfma_f32_32x32x16_bf16); "
+                        "the same kernel is %.2f of the 157.3 TF fp32-MFMA peak it replaces" % (achieved / FP32_MFMA_PEAK_TFLOPS),
+                     1: "dense bf16 MFMA peak"}[nl]
         tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")      # PMC passes cannot run inside the timed process:
         if os.path.exists(tpath):                                     # tools/pmc_bench.sh measured this command's kernels
             with open(tpath) as f:
                 tj = json.load(f)
-            ent = tj["kernels"].get("gemm_kernel<%s>" % ", ".join(args.timer_instance.split(",")))
+            ent = tj["kernels"].get(kname)
             if ent:
                 traffic, traffic_src = round(ent["hbm_bytes_per_launch"]), "profiles/r1_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE)"
         rec = {
             "metric": METRIC, "value": round(pairs / el, 2), "unit": "image-pairs/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if nl == 1 else "f32",
+            "data": "synthetic",
             "config": {"workload": ("train.py step (ViTEss fwd + geodesic loss + bwd + grad all-reduce + clip + Adam)"
                                     if train else "ViTEss.forward, eval, no_grad") +
                                    ", synthetic %dx%d pairs" % (args.hw, args.hw),
                        "scope": args.scope, "pairs_per_gpu": args.batch, "global_batch_pairs": world * args.batch,
                        "parallelism": "dp%d" % world, "finite": finite,
+                       "gemm_operand_precision": {0: "exact fp32 MFMA", 3: "fp32 operands split into 3 bf16 limbs, 6 limb "
+                                                  "products on the bf16 MFMA pipe, fp32 accumulate (fp32-grade: measured "
+                                                  "error vs fp64 <= the fp32-MFMA kernel's)", 1: "bf16 operands, fp32 accumulate "
+                                                  "(Linear GEMMs only; attention/EMM stay fp32)"}[nl],
                        "launch": "HIP graph replay (fwd+loss+bwd | flat grad all-reduce | clip+Adam)" if graphed else "eager",
                        "hot_path_share": "ViT+EMM+regressor on HIP kernels; ResNet front-end on MIOpen (SURVEY 8f-1)"},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1),
+                         "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "peak_note": peak_note, "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch_avg": timer.bytes / max(n_launch, 1),
-                         "kernel": "gemm_kernel<%s>" % args.timer_instance, "launches_timed": n_launch,
+                         "kernel": kname, "launches_timed": n_launch,
                          "avg_launch_us": round(t_launch * 1e6, 2),
                          "flops_per_launch_avg": flops / max(n_launch, 1),
                          "hot_path_tflops_whole_step": round((3 if train else 1) * FLOPS_FWD_PER_PAIR * pairs / el / 1e12, 2)},

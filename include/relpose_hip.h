@@ -69,13 +69,15 @@ typedef struct RpGemm {
   const float* aux; /* ld = ldc */
   const float* residual; /* ld = ldc */
   int trans_c; /* split_k > 1 only, no epilogue operands: store C^T, i.e. C[n*ldc + m] */
+  int precision; /* how the fp32 operands are multiplied (inputs, outputs and accumulation are fp32 in every case):
+                  *   0  exact fp32 MFMA (v_mfma_f32_32x32x2_f32)
+                  *   3  split-bf16, 3 limbs per operand, the 6 limb products >= 2^-16 on v_mfma_f32_32x32x16_bf16:
+                  *      fp32-grade result (dropped terms <= 2^-24 relative) at 16/6 the matrix-pipe rate
+                  *   1  operands truncated to bf16 (the bf16 configuration, BASELINE.json configs[4]) */
 } RpGemm;
 int rp_gemm(const RpGemm* g, void* stream);
 size_t rp_gemm_workspace_bytes(int M, int N, int split_k);
-/* EXPERIMENTAL, not on the default path: C = act(A B^T + bias) (+ residual), fp32 in/out, products on the bf16 MFMA pipe
- * with the 3xBF16 split (a_hi b_hi + a_hi b_lo + a_lo b_hi, fp32 accumulate).  A [M,K], B [N,K], K-contiguous. */
-int rp_gemm_nt_bf16x3(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
-                      const float* bias, const float* residual, float* pre_out, int act, void* stream);
+
 
 /* LayerNorm over the last dim C (multiple of 64, <= 512), eps as given (reference uses 1e-6,
  * vision_transformer.py:396).  Saves mean / rstd per row for the backward. */

@@ -22,7 +22,7 @@ class RpGemm(Structure):
                 ("stride_a", c_longlong), ("stride_b", c_longlong), ("stride_c", c_longlong),
                 ("split_k", c_int), ("workspace", c_void_p), ("workspace_bytes", c_size_t),
                 ("bias", c_void_p), ("pre_out", c_void_p), ("act", c_int), ("dact", c_int),
-                ("aux", c_void_p), ("residual", c_void_p), ("trans_c", c_int)]
+                ("aux", c_void_p), ("residual", c_void_p), ("trans_c", c_int), ("precision", c_int)]
 
 
 P, I, F, L = c_void_p, c_int, c_float, c_longlong
@@ -31,7 +31,6 @@ _SIGS = {
     "rp_target_arch": (c_char_p, []),
     "rp_gemm": (c_int, [POINTER(RpGemm), P]),
     "rp_gemm_workspace_bytes": (c_size_t, [I, I, I]),
-    "rp_gemm_nt_bf16x3": (c_int, [P, P, P, I, I, I, I, I, I, P, P, P, I, P]),
     "rp_layernorm_fwd": (c_int, [P, P, P, P, P, P, I, I, F, P]),
     "rp_layernorm_bwd_blocks": (c_int, [I]),
     "rp_layernorm_bwd": (c_int, [P, P, P, P, P, P, P, P, P, I, I, P]),

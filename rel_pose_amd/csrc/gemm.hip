@@ -36,6 +36,7 @@ struct GemmP {
   const float* residual;
   int epi_mode;
   int trans_c;
+  int limbs;
 };
 
 RP_DEV float epilogue(float v, int m, int n, const GemmP& p) {
@@ -50,12 +51,108 @@ RP_DEV float epilogue(float v, int m, int n, const GemmP& p) {
   return v;
 }
 
-template <int ALAY, int BLAY, int TM, int TN>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
+// ---- split-bf16 operand path (NL = 1..3 limbs) ---------------------------------------------------------------------
+// x = x1 + x2 + x3 exactly, each limb a bf16 (8 significant bits): x1 = top 8 bits of x (truncation), x2 = top 8 bits of
+// x - x1, x3 = the rest.  With NL = 3 the product a*b is accumulated (fp32, inside v_mfma_f32_32x32x16_bf16) as the six
+// limb products whose weight is >= 2^-16: a1b1 + a1b2 + a2b1 + a2b2 + a1b3 + a3b1; the three dropped ones are <= 2^-24
+// relative -- the size of one fp32 rounding -- so the result is fp32-grade while the contraction runs on the bf16
+// matrix pipe (16 k per 32-cycle MFMA instead of 2 k per 64-cycle fp32 MFMA: 16/6 = 2.7x fewer pipe cycles).
+// NL = 2 (3 products, ~2^-17 operand truncation) and NL = 1 (plain bf16 operands, the bf16 configuration) share the code.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// packed bf16 pair (lo half = a's limb, hi half = b's limb) by truncation: v_perm_b32 picks the two high halves
+RP_DEV unsigned pack_hi16(float a, float b) {
+  return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, a), 0x07060302u);
+}
+// single-limb (plain bf16) operands are rounded to nearest-even instead (v_cvt_pk_bf16_f32): no truncation bias
+RP_DEV unsigned pack_rne(float a, float b) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  bf16x2 v;
+  v[0] = (__bf16)a;
+  v[1] = (__bf16)b;
+  return __builtin_bit_cast(unsigned, v);
+}
+template <int NL>
+RP_DEV unsigned pack_limb(float a, float b) { return NL == 1 ? pack_rne(a, b) : pack_hi16(a, b); }
+RP_DEV float drop_hi16(float x) {   // x - (top 16 bits of x), exact
+  return x - __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & 0xffff0000u);
+}
+
+// split NV staged float4 of one operand tile into NL bf16 limb images in LDS (layouts: see gemm_kernel)
+template <int LAY, int EXT, int NL, int NV>
+RP_DEV void limb_store(unsigned* w, int tid, const float4 (&r)[NV]) {
+  constexpr int RSW = 20;
+  constexpr int WORDS = LAY == 0 ? EXT * RSW : 16 * (EXT + 4);
+  if (LAY == 0) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int f = tid + 256 * j;
+      unsigned* dst = w + (f >> 3) * RSW + (f & 7) * 2;
+      float4 v = r[j];
+#pragma unroll
+      for (int l = 0; l < NL; ++l) {
+        *reinterpret_cast<uint2*>(dst + l * WORDS) = make_uint2(pack_limb<NL>(v.x, v.y), pack_limb<NL>(v.z, v.w));
+        if (l + 1 < NL) { v.x = drop_hi16(v.x); v.y = drop_hi16(v.y); v.z = drop_hi16(v.z); v.w = drop_hi16(v.w); }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int jp = 0; jp < NV / 2; ++jp) {
+      const int f = tid + 256 * jp;
+      unsigned* dst = w + (f / (EXT / 4)) * (EXT + 4) + (f % (EXT / 4)) * 4;
+      float4 v0 = r[2 * jp], v1 = r[2 * jp + 1];          // k = 2 kp and 2 kp + 1 of the same four rows
+#pragma unroll
+      for (int l = 0; l < NL; ++l) {
+        u32x4 o;
+        o[0] = pack_limb<NL>(v0.x, v1.x); o[1] = pack_limb<NL>(v0.y, v1.y); o[2] = pack_limb<NL>(v0.z, v1.z); o[3] = pack_limb<NL>(v0.w, v1.w);
+        *reinterpret_cast<u32x4*>(dst + l * WORDS) = o;
+        if (l + 1 < NL) {
+          v0.x = drop_hi16(v0.x); v0.y = drop_hi16(v0.y); v0.z = drop_hi16(v0.z); v0.w = drop_hi16(v0.w);
+          v1.x = drop_hi16(v1.x); v1.y = drop_hi16(v1.y); v1.z = drop_hi16(v1.z); v1.w = drop_hi16(v1.w);
+        }
+      }
+    }
+  }
+}
+
+// MFMA operand (8 bf16: k = 16 s + 8 hb .. +7 of tile row `row`) of one limb image
+template <int LAY, int EXT>
+RP_DEV bf16x8 limb_frag(const unsigned* w, int row, int s, int hb) {
+  constexpr int RSW = 20;
+  u32x4 v;
+  if (LAY == 0) {
+    v = *reinterpret_cast<const u32x4*>(w + row * RSW + 8 * s + 4 * hb);
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = w[(8 * s + 4 * hb + q) * (EXT + 4) + row];
+  }
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// k row / first column of the j-th float4 a thread stages from an MN-contiguous operand tile [32 k][EXT].  fp32 path: plain
+// round-robin.  bf16 path: consecutive j are the two k of one k-pair, so the thread can pack (k, k+1) into one word.
+template <int EXT, int NL>
+RP_DEV int mnk(int tid, int j) {
+  return NL == 0 ? (tid + 256 * j) / (EXT / 4) : 2 * ((tid + 256 * (j >> 1)) / (EXT / 4)) + (j & 1);
+}
+template <int EXT, int NL>
+RP_DEV int mnc(int tid, int j) {
+  return NL == 0 ? ((tid + 256 * j) % (EXT / 4)) * 4 : ((tid + 256 * (j >> 1)) % (EXT / 4)) * 4;
+}
+
+template <int ALAY, int BLAY, int TM, int TN, int NL>
+__global__ __launch_bounds__(256, NL > 0 ? 2 : 1) void gemm_kernel(GemmP p) {
   constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32;
   constexpr int KST = BK + 4;                       // padded row stride of a K-contiguous tile
-  constexpr int A_FLOATS = ALAY == 0 ? BM * KST : BK * BM;
-  constexpr int B_FLOATS = BLAY == 0 ? BN * KST : BK * BN;
+  // bf16 limb images (NL > 0), per limb, in 32-bit words: a K-contiguous operand is [rows][RSW = 20 words = 32 bf16 + pad]
+  // (MFMA operand = one ds_read_b128: row l&31, k = 16 s + 8 (l>>5) .. +7); an MN-contiguous operand is k-pair-major
+  // [16 k-pairs][rows + 4] words (word = bf16 of k, k+1 for one row; MFMA operand = 4 conflict-free ds_read_b32)
+  constexpr int RSW = 20;
+  constexpr int A_WORDS = ALAY == 0 ? BM * RSW : 16 * (BM + 4);
+  constexpr int B_WORDS = BLAY == 0 ? BN * RSW : 16 * (BN + 4);
+  constexpr int A_FLOATS = NL > 0 ? NL * A_WORDS : (ALAY == 0 ? BM * KST : BK * BM);
+  constexpr int B_FLOATS = NL > 0 ? NL * B_WORDS : (BLAY == 0 ? BN * KST : BK * BN);
   constexpr int NA = BM / 32, NB = BN / 32;         // float4 per thread per k-tile
   constexpr int STAGE = A_FLOATS + B_FLOATS;
   constexpr int CST = 32 * TN + 4;                  // row stride of a wave's C tile staged in LDS for the epilogue
@@ -114,13 +211,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
       for (int j = 0; j < NA; ++j) {
         const int f = tid + 256 * j;
         if (ALAY == 0) ra[j] = ld4(A + (long long)(m0 + (f >> 3)) * p.lda + k0 + (f & 7) * 4);
-        else ra[j] = ld4(A + (long long)(k0 + f / (BM / 4)) * p.lda + m0 + (f % (BM / 4)) * 4);
+        else ra[j] = ld4(A + (long long)(k0 + mnk<BM, NL>(tid, j)) * p.lda + m0 + mnc<BM, NL>(tid, j));
       }
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
         const int f = tid + 256 * j;
         if (BLAY == 0) rb[j] = ld4(B + (long long)(n0 + (f >> 3)) * p.ldb + k0 + (f & 7) * 4);
-        else rb[j] = ld4(B + (long long)(k0 + f / (BN / 4)) * p.ldb + n0 + (f % (BN / 4)) * 4);
+        else rb[j] = ld4(B + (long long)(k0 + mnk<BN, NL>(tid, j)) * p.ldb + n0 + mnc<BN, NL>(tid, j));
       }
       return;
     }
@@ -132,7 +229,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
         const int gm = m0 + (f >> 3), gk = k0 + (f & 7) * 4;
         if (gm < p.M && gk < kend) v = ld4(A + (long long)gm * p.lda + gk);
       } else {
-        const int gk = k0 + f / (BM / 4), gm = m0 + (f % (BM / 4)) * 4;
+        const int gk = k0 + mnk<BM, NL>(tid, j), gm = m0 + mnc<BM, NL>(tid, j);
         if (gk < kend && gm < p.M) v = ld4(A + (long long)gk * p.lda + gm);
       }
       ra[j] = v;
@@ -145,7 +242,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
         const int gn = n0 + (f >> 3), gk = k0 + (f & 7) * 4;
         if (gn < p.N && gk < kend) v = ld4(B + (long long)gn * p.ldb + gk);
       } else {
-        const int gk = k0 + f / (BN / 4), gn = n0 + (f % (BN / 4)) * 4;
+        const int gk = k0 + mnk<BN, NL>(tid, j), gn = n0 + mnc<BN, NL>(tid, j);
         if (gk < kend && gn < p.N) v = ld4(B + (long long)gk * p.ldb + gn);
       }
       rb[j] = v;
@@ -154,6 +251,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   auto sstore = [&](int stage = 0) {
     float* as = As + stage * STAGE;
     float* bs = Bs + stage * STAGE;
+    if (NL > 0) {
+      limb_store<ALAY, BM, NL, NA>(reinterpret_cast<unsigned*>(as), tid, ra);
+      limb_store<BLAY, BN, NL, NB>(reinterpret_cast<unsigned*>(bs), tid, rb);
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
       const int f = tid + 256 * j;
@@ -210,6 +312,32 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   __syncthreads();
   for (int kt = 0; kt < nkt; ++kt) {
     if (kt + 1 < nkt) gload(kt + 1);
+    if (NL > 0) {
+      constexpr int L = NL > 0 ? NL : 1;
+      const unsigned* aw = reinterpret_cast<const unsigned*>(As);
+      const unsigned* bw = reinterpret_cast<const unsigned*>(Bs);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 a[TM][L], b[TN][L];
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) a[i][l] = limb_frag<ALAY, BM>(aw + l * A_WORDS, wm0 + 32 * i + l31, s2, hi);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) b[j][l] = limb_frag<BLAY, BN>(bw + l * B_WORDS, wn0 + 32 * j + l31, s2, hi);
+        }
+        // limb products, smallest weight first; la + lb <= L - 1 keeps every term >= 2^-8(L-1) of the leading one
+#pragma unroll
+        for (int w = L - 1; w >= 0; --w)
+#pragma unroll
+          for (int la = 0; la <= w; ++la)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][la], b[j][w - la], acc[i][j], 0, 0, 0);
+      }
+    } else {
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       float a[TM][8], b[TN][8];
@@ -220,6 +348,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(a[i][t], b[j][t], acc[i][j]);
+    }
     }
     __syncthreads();
     if (kt + 1 < nkt) {
@@ -331,25 +460,33 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, const float
   }
 }
 
-template <int ALAY, int BLAY, int TM, int TN>
+template <int ALAY, int BLAY, int TM, int TN, int NL>
 int launch(const GemmP& p, int nz, hipStream_t st) {
   const int ntn = (p.N + 64 * TN - 1) / (64 * TN), ntm = (p.M + 64 * TM - 1) / (64 * TM);
   dim3 grid(ntm >= 16 ? ntn * ((ntm + 7) / 8) * 8 : ntn * ntm, 1, nz);
   if (p.split_k > 1) grid = dim3(ntn * ntm * ((p.split_k + 7) / 8) * 8, 1, 1);
-  hipLaunchKernelGGL((gemm_kernel<ALAY, BLAY, TM, TN>), grid, dim3(256), 0, st, p);
+  hipLaunchKernelGGL((gemm_kernel<ALAY, BLAY, TM, TN, NL>), grid, dim3(256), 0, st, p);
   return 0;
 }
 
-template <int ALAY, int BLAY>
+template <int ALAY, int BLAY, int NL>
 int launch_tiles(const GemmP& p, int nz, int tm, int tn, hipStream_t st) {
   if (tm == 1) {
-    if (tn == 1) return launch<ALAY, BLAY, 1, 1>(p, nz, st);
-    if (tn == 2) return launch<ALAY, BLAY, 1, 2>(p, nz, st);
-    return launch<ALAY, BLAY, 1, 3>(p, nz, st);
+    if (tn == 1) return launch<ALAY, BLAY, 1, 1, NL>(p, nz, st);
+    if (tn == 2) return launch<ALAY, BLAY, 1, 2, NL>(p, nz, st);
+    return launch<ALAY, BLAY, 1, 3, NL>(p, nz, st);
   }
-  if (tn == 1) return launch<ALAY, BLAY, 2, 1>(p, nz, st);
-  if (tn == 2) return launch<ALAY, BLAY, 2, 2>(p, nz, st);
-  return launch<ALAY, BLAY, 2, 3>(p, nz, st);
+  if (tn == 1) return launch<ALAY, BLAY, 2, 1, NL>(p, nz, st);
+  if (tn == 2) return launch<ALAY, BLAY, 2, 2, NL>(p, nz, st);
+  return launch<ALAY, BLAY, 2, 3, NL>(p, nz, st);
+}
+
+template <int NL>
+int launch_layouts(const GemmP& p, int nz, int al, int bl, int tm, int tn, hipStream_t st) {
+  if (al == 0 && bl == 0) return launch_tiles<0, 0, NL>(p, nz, tm, tn, st);
+  if (al == 0 && bl == 1) return launch_tiles<0, 1, NL>(p, nz, tm, tn, st);
+  if (al == 1 && bl == 0) return launch_tiles<1, 0, NL>(p, nz, tm, tn, st);
+  return launch_tiles<1, 1, NL>(p, nz, tm, tn, st);
 }
 
 }  // namespace
@@ -395,15 +532,25 @@ extern "C" int rp_gemm(const RpGemm* g, void* stream) {
     p.epi_mode = m;
   }
   p.trans_c = g->trans_c;
+  p.limbs = g->precision;
+  if (p.limbs != 0 && p.limbs != 1 && p.limbs != 3) return RP_EUNSUPPORTED;
   if (g->trans_c && (split == 1 || g->bias || g->pre_out || g->aux || g->residual)) return RP_EUNSUPPORTED;
   // tile shape (TM,TN) = wave tile in 32x32 units; measured on MI355X (tools/gemm_tiles.py): with fp32 MFMA (64
   // cycles per 32x32x2) operand reuse is cheap and occupancy wins -- 128x64 / 64x192 tiles beat 128x192.
   int tm = g->M <= 64 ? 1 : 2;
   int tn = g->N <= 64 ? 1 : 2;
-  if (g->M > 64) {
+  if (g->M > 64 && p.limbs == 0) {
     const bool reads_mn = g->aux || g->residual;
     if (g->a_layout == 0 && g->b_layout == 0) { tm = 2; tn = 1; }
     else if (g->N % 192 == 0 && !reads_mn) { tm = 1; tn = 3; }
+    else { tm = 2; tn = 1; }
+  }
+  // bf16 limb paths (measured, tools/split_probe.py): 128x64 tiles (3 workgroups per CU) for the forward and input-gradient
+  // layouts, 64x192 for the split-K weight gradient; 128x128 would halve the LDS operand reads per MFMA but only fits
+  // 2 workgroups per CU and quantises worse (2592 workgroups on 512 slots)
+  if (g->M > 64 && p.limbs != 0) {
+    const bool reads_mn = g->aux || g->residual;
+    if (g->a_layout == 1 && g->b_layout == 1 && g->N % 192 == 0 && !reads_mn) { tm = 1; tn = 3; }
     else { tm = 2; tn = 1; }
   }
   if (const char* ov = getenv("RP_GEMM_TILE")) {   // tuning aid only: "TM,TN"
@@ -411,10 +558,9 @@ extern "C" int rp_gemm(const RpGemm* g, void* stream) {
   }
   hipStream_t st = (hipStream_t)stream;
   const int nz = batch * split;
-  if (g->a_layout == 0 && g->b_layout == 0) launch_tiles<0, 0>(p, nz, tm, tn, st);
-  else if (g->a_layout == 0 && g->b_layout == 1) launch_tiles<0, 1>(p, nz, tm, tn, st);
-  else if (g->a_layout == 1 && g->b_layout == 0) launch_tiles<1, 0>(p, nz, tm, tn, st);
-  else launch_tiles<1, 1>(p, nz, tm, tn, st);
+  if (p.limbs == 3) launch_layouts<3>(p, nz, g->a_layout, g->b_layout, tm, tn, st);
+  else if (p.limbs == 1) launch_layouts<1>(p, nz, g->a_layout, g->b_layout, tm, tn, st);
+  else launch_layouts<0>(p, nz, g->a_layout, g->b_layout, tm, tn, st);
   RP_CHECK_LAUNCH();
   if (split > 1) {
     GemmP r = p;

@@ -51,10 +51,25 @@ def _empty(*shape, like):
     return torch.empty(shape, device=like.device, dtype=torch.float32)
 
 
-def gemm_tile(M, N, a_layout, b_layout, reads_mn=False):
+# how rp_gemm multiplies its fp32 operands (RpGemm.precision): 0 exact fp32 MFMA, 3 split-bf16 (3 limbs, fp32-grade),
+# 1 bf16 operands.  Process-wide default; bench.py / tests switch it through set_gemm_precision().
+GEMM_PRECISION = int(os.environ.get("RP_GEMM_PRECISION", "3"))
+
+
+def set_gemm_precision(p):
+    global GEMM_PRECISION
+    if p not in (0, 1, 3):
+        raise ValueError("precision must be 0 (fp32 MFMA), 3 (split-bf16, fp32-grade) or 1 (bf16 operands)")
+    GEMM_PRECISION = p
+
+
+def gemm_tile(M, N, a_layout, b_layout, reads_mn=False, precision=None):
     """(TM, TN) that rp_gemm picks (mirrors csrc/gemm.hip)."""
+    precision = GEMM_PRECISION if precision is None else precision
     if M <= 64:
         return 1, (1 if N <= 64 else 2)
+    if precision:
+        return (1, 3) if (a_layout == 1 and b_layout == 1 and N % 192 == 0 and not reads_mn) else (2, 1)
     if a_layout == 0 and b_layout == 0:
         return 2, 1
     if N % 192 == 0 and not reads_mn:
@@ -142,7 +157,8 @@ def gemm_instance(M, N, a_layout, b_layout, reads_mn=False):
 
 
 def gemm(A, B, M, N, K, *, a_layout=0, b_layout=0, lda=None, ldb=None, out=None, ldc=None, bias=None, act=0,
-         pre_out=None, dact=0, aux=None, residual=None, split_k=None, batch=1, strides=(0, 0, 0), trans_c=False):
+         pre_out=None, dact=0, aux=None, residual=None, split_k=None, batch=1, strides=(0, 0, 0), trans_c=False,
+         precision=None):
     """C[M,N] = epilogue(op(A) op(B)); see RpGemm in include/relpose_hip.h."""
     lib = _lib.load()
     _chk(A, B, out, bias, pre_out, aux, residual)
@@ -174,6 +190,7 @@ def gemm(A, B, M, N, K, *, a_layout=0, b_layout=0, lda=None, ldb=None, out=None,
     g.aux = None if aux is None else aux.data_ptr()
     g.residual = None if residual is None else residual.data_ptr()
     g.trans_c = 1 if trans_c else 0
+    g.precision = GEMM_PRECISION if precision is None else precision
     tm = TIMER
     if (tm is not None and tm.enabled and split_k == 1 and
             gemm_instance(M, N, a_layout, b_layout, aux is not None or residual is not None) == tm.instance):

@@ -46,7 +46,9 @@ def rnd(*shape, seed=0, scale=1.0):
 @pytest.mark.parametrize("M,N,K", [(128, 192, 192), (1152, 576, 192), (200, 768, 192), (70, 192, 224), (64, 512, 2688),
                                    (33, 16, 512), (1152, 192, 768), (130, 100, 36)])
 @pytest.mark.parametrize("al,bl", [(0, 0), (0, 1), (1, 0), (1, 1)])
-def test_gemm_layouts(ops, M, N, K, al, bl):
+@pytest.mark.parametrize("prec", [3, 0])
+def test_gemm_layouts(ops, M, N, K, al, bl, prec):
+    """both fp32-grade operand precisions (3 = split-bf16 limbs, the default; 0 = exact fp32 MFMA), same tolerance"""
     if (al == 1 and M % 4) or (bl == 1 and N % 4):
         pytest.skip("contiguous extent must be a multiple of 4")
     A = rnd(M, K, seed=1)
@@ -54,14 +56,43 @@ def test_gemm_layouts(ops, M, N, K, al, bl):
     ref = A.double() @ Bm.double().t()
     Ain = A if al == 0 else A.t().contiguous()
     Bin = Bm if bl == 0 else Bm.t().contiguous()
-    out = ops.gemm(Ain, Bin, M, N, K, a_layout=al, b_layout=bl, split_k=1)
+    out = ops.gemm(Ain, Bin, M, N, K, a_layout=al, b_layout=bl, split_k=1, precision=prec)
     e = rel(out, ref)
-    report("gemm[%d,%d,%d|%d%d]" % (M, N, K, al, bl), rel=e)
+    report("gemm[%d,%d,%d|%d%d|p%d]" % (M, N, K, al, bl, prec), rel=e)
     assert e < 2e-6
-    # A = I with an asymmetric B catches transposed C writes
+    # A = I with an asymmetric B catches transposed C writes (exact in both precisions: 1 * b = b1 + b2 + b3)
     if M == K and al == 0 and bl == 0:
         eye = torch.eye(M, device="cuda")
-        assert torch.equal(ops.gemm(eye, Bm, M, N, K, split_k=1), Bm.t().contiguous())
+        assert torch.equal(ops.gemm(eye, Bm, M, N, K, split_k=1, precision=prec), Bm.t().contiguous())
+
+
+def test_gemm_operand_precisions(ops):
+    """RpGemm.precision: 3 (three bf16 limbs per operand, six limb products) must be fp32-grade -- no worse than the exact
+    fp32 MFMA kernel against fp64, also with a wide dynamic range and cancellation; 1 (bf16 operands) must really be bf16."""
+    M, N, K = 1152, 192, 768
+    g = torch.Generator(device="cpu").manual_seed(5)
+    A = (torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-12, 12, (M, 1), generator=g).float())).cuda()
+    W = (torch.randn(N, K, generator=g) * torch.exp2(torch.randint(-6, 6, (1, K), generator=g).float())).cuda()
+    A[:, 1::2] = -A[:, ::2] * (1 + 1e-3 * torch.randn(M, K // 2, generator=g).cuda())      # pairwise cancellation
+    W[:, 1::2] = W[:, ::2]
+    ref = A.double() @ W.double().t()
+    scale = (A.double().abs() @ W.double().abs().t())          # condition-aware: error relative to sum |a||b| per row
+
+    def err(p):
+        c = ops.gemm(A, W, M, N, K, precision=p, split_k=1)
+        return float(((c.double() - ref).abs() / scale).max())
+    e0, e3, e1 = err(0), err(3), err(1)
+    report("gemm_precisions", fp32_mfma=e0, split_bf16x3=e3, bf16=e1)
+    assert e0 < 3e-7 and e3 < 3e-7 and e3 < 2 * e0 + 1e-8
+    assert 1e-4 < e1 < 1e-2
+    with pytest.raises(RuntimeError):
+        ops.gemm(A, W, M, N, K, precision=2)
+    # very small and huge operands survive the truncation split (bf16 has fp32's exponent range; only below ~1e-33 would
+    # the third limb drop into the subnormals)
+    tiny = torch.full((64, 32), 3e-30, device="cuda")
+    big = torch.full((64, 32), 1e18, device="cuda")
+    out = ops.gemm(tiny, big, 64, 64, 32, precision=3, split_k=1)
+    assert rel(out, tiny.double() @ big.double().t()) < 1e-6
 
 
 def test_gemm_epilogues_splitk_batch(ops):
@@ -298,20 +329,6 @@ def test_emm_backward(ops):
     e = [rel(dqkv[:, i * 192:(i + 1) * 192], q64.grad[:, i * 192:(i + 1) * 192]) for i in range(3)]
     report("emm_bwd", dq=e[0], dk=e[1], dv=e[2])
     assert max(e) < 5e-5
-
-
-def test_experimental_bf16x3_gemm(ops):
-    """The 3xBF16-split GEMM (not on the default path): fp32-class accuracy (<= 2e-5 of max|ref|) on the bf16 MFMA pipe."""
-    from rel_pose_amd import _lib
-    lib = _lib.load()
-    M, N, K = 1152, 192, 768
-    A, W, b, R = rnd(M, K, seed=21), rnd(N, K, seed=22, scale=K ** -0.5), rnd(N, seed=23), rnd(M, N, seed=24)
-    C = torch.empty(M, N, device="cuda")
-    _lib.check(lib.rp_gemm_nt_bf16x3(ops._p(A), ops._p(W), ops._p(C), M, N, K, K, K, N, ops._p(b), ops._p(R), None, 0,
-                                     ops._st()), "rp_gemm_nt_bf16x3")
-    e = rel(C, A.double() @ W.double().t() + b.double() + R.double())
-    report("gemm_bf16x3", rel=e)
-    assert e < 2e-5
 
 
 @pytest.mark.parametrize("H,W", [(384, 384), (256, 320), (384, 512), (480, 640)])

@@ -354,3 +354,28 @@ def test_noess_features_and_full_model(golden_noess):
     t_err, q_err, ang = O.pose_errors(pose.cpu(), torch.from_numpy(golden_noess["noess_full_sq_pose_f64"]))
     report("noess_full", feats=e_f, t=t_err, q=q_err)
     assert e_f < 1e-3 and max(t_err, q_err) < 1e-4     # same bounds as the default model
+
+
+def test_bf16_operand_mode_is_a_different_precision(model, states):
+    """BASELINE.json configs[4] (bf16): rp_gemm precision 1 feeds the Linear GEMMs bf16-truncated operands (fp32 accumulate).
+    Not the headline path -- checked here only to be what it says: close to the fp64 oracle at bf16 level, visibly
+    different from the fp32-grade default, and switched off again afterwards."""
+    from rel_pose_amd import ops
+    _, sd64 = states
+    tok = O.synthetic_tokens(4)
+    Gs = torch.tensor([0, 0, 0, 0, 0, 0, 1.0]).repeat(2, 2, 1)
+    ref = O.vit_ess_from_tokens(sd64, tok.double(), Gs.double(), intr24(torch.float64))
+    fmap = tok.permute(0, 2, 1).contiguous().view(4, 192, 24, 24).cuda()
+    prev = ops.GEMM_PRECISION
+    try:
+        errs = {}
+        for p in (3, 0, 1):
+            ops.set_gemm_precision(p)
+            with torch.no_grad():
+                out = model.forward_tokens(fmap, Gs.cuda(), intr24().cuda())
+            errs[p] = max(O.pose_errors(out.cpu(), ref)[:2])
+    finally:
+        ops.set_gemm_precision(prev)
+    report("precision_modes", split3=errs[3], fp32=errs[0], bf16=errs[1])
+    assert errs[3] < 1e-4 and errs[0] < 1e-4
+    assert 1e-4 < errs[1] < 1e-1

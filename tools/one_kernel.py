@@ -16,7 +16,9 @@ b1 = torch.zeros(768, device="cuda")
 Wq = torch.randn(576, 192, device="cuda") * 0.07
 bq = torch.zeros(576, device="cuda")
 for _ in range(3):
-    if what == "fc1":
+    if what == "qkv":
+        ops.linear(x, Wq, bq)
+    elif what == "fc1":
         ops.linear(x, W1, b1, act=1)
     elif what == "dw":
         dY = torch.randn(M, 768, device="cuda")

@@ -124,7 +124,10 @@ def pick_split_k(M, N, K, a_layout=0, b_layout=0, target_wgs=768, min_ktiles=8, 
         return 1
     # ~3 workgroups per CU keeps >=2 waves per SIMD resident (measured: 0.76 waves/SIMD at 288 WGs left the MFMA pipe
     # 44 % busy); more than 128 partial slabs makes the reduce pass visible
-    return max(1, min(ktiles // min_ktiles, -(-target_wgs // tiles), max_split))
+    # floor, not ceil: tiles * split must not spill past the resident slots (9 tiles x 86 splits = 774 workgroups on 768 slots
+    # ran a second, nearly empty round: 173 vs 137 us); whole groups of 8 because split z is pinned to XCD z % 8
+    sk = max(1, min(ktiles // min_ktiles, target_wgs // tiles, max_split))
+    return sk - sk % 8 if sk >= 16 else sk
 
 
 class KernelTimer:

@@ -465,8 +465,7 @@ int launch(const GemmP& p, int nz, hipStream_t st) {
   const int ntn = (p.N + 64 * TN - 1) / (64 * TN), ntm = (p.M + 64 * TM - 1) / (64 * TM);
   dim3 grid(ntm >= 16 ? ntn * ((ntm + 7) / 8) * 8 : ntn * ntm, 1, nz);
   if (p.split_k > 1) grid = dim3(ntn * ntm * ((p.split_k + 7) / 8) * 8, 1, 1);
-  const char* pad = getenv("RP_GEMM_PAD_LDS");   // experiment: extra dynamic LDS lowers the workgroups per CU
-  hipLaunchKernelGGL((gemm_kernel<ALAY, BLAY, TM, TN, NL>), grid, dim3(256), pad ? atoi(pad) : 0, st, p);
+  hipLaunchKernelGGL((gemm_kernel<ALAY, BLAY, TM, TN, NL>), grid, dim3(256), 0, st, p);
   return 0;
 }
 

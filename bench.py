@@ -24,7 +24,7 @@ import torch.distributed as dist
 
 FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 BF16_MFMA_PEAK_TFLOPS = 2500.0       # same guide, dense bf16 MFMA (never the 2:1-sparsity figure)
-PRECISIONS = {"split3": 3, "fp32": 0, "bf16": 1}
+PRECISIONS = {"fp32": 0, "split3": 3, "bf16": 1}
 FLOPS_FWD_PER_PAIR = 8588216320      # GEMM flops of the ViT+EMM+regressor hot path, forward
 METRIC = "image-pairs/sec fwd+bwd @384x384, 1/2/4/8 MI355X; R,t err vs ref"
 
@@ -128,10 +128,10 @@ def main():
                     help="full = images -> CNN -> hot path (the metric); hot = synthetic CNN maps -> hot path only "
                          "(kernel profiling; not the headline number)")
     ap.add_argument("--timer-instance", default="0,0,2,1", help="gemm_kernel<aL,bL,TM,TN> instance timed for `roofline`")
-    ap.add_argument("--precision", default="split3", choices=tuple(PRECISIONS),
-                    help="how rp_gemm multiplies its fp32 operands: split3 = three bf16 limbs per operand, six limb products "
-                         "on the bf16 MFMA pipe, fp32-grade results (default); fp32 = exact v_mfma_f32_32x32x2_f32; "
-                         "bf16 = operands truncated to bf16 (BASELINE.json configs[4]; NOT the headline metric)")
+    ap.add_argument("--precision", default="fp32", choices=tuple(PRECISIONS),
+                    help="how rp_gemm multiplies its fp32 operands: fp32 = exact v_mfma_f32_32x32x2_f32 (default); split3 = "
+                         "three bf16 limbs per operand, six limb products on the bf16 MFMA pipe, fp32-grade results; "
+                         "bf16 = operands rounded to bf16 (BASELINE.json configs[4]; NOT the headline metric)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -51,9 +51,10 @@ def _empty(*shape, like):
     return torch.empty(shape, device=like.device, dtype=torch.float32)
 
 
-# how rp_gemm multiplies its fp32 operands (RpGemm.precision): 0 exact fp32 MFMA, 3 split-bf16 (3 limbs, fp32-grade),
-# 1 bf16 operands.  Process-wide default; bench.py / tests switch it through set_gemm_precision().
-GEMM_PRECISION = int(os.environ.get("RP_GEMM_PRECISION", "3"))
+# how rp_gemm multiplies its fp32 operands (RpGemm.precision): 0 exact fp32 MFMA (default), 3 split-bf16 (3 limbs,
+# fp32-grade, 1.45x on isolated GEMMs but only +1-2 % on the step: DESIGN.md section 4), 1 bf16 operands.
+# Process-wide default; bench.py / tests switch it through set_gemm_precision().
+GEMM_PRECISION = int(os.environ.get("RP_GEMM_PRECISION", "0"))
 
 
 def set_gemm_precision(p):

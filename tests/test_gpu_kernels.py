@@ -46,9 +46,9 @@ def rnd(*shape, seed=0, scale=1.0):
 @pytest.mark.parametrize("M,N,K", [(128, 192, 192), (1152, 576, 192), (200, 768, 192), (70, 192, 224), (64, 512, 2688),
                                    (33, 16, 512), (1152, 192, 768), (130, 100, 36)])
 @pytest.mark.parametrize("al,bl", [(0, 0), (0, 1), (1, 0), (1, 1)])
-@pytest.mark.parametrize("prec", [3, 0])
+@pytest.mark.parametrize("prec", [0, 3])
 def test_gemm_layouts(ops, M, N, K, al, bl, prec):
-    """both fp32-grade operand precisions (3 = split-bf16 limbs, the default; 0 = exact fp32 MFMA), same tolerance"""
+    """both fp32-grade operand precisions (0 = exact fp32 MFMA, the default; 3 = split-bf16 limbs), same tolerance"""
     if (al == 1 and M % 4) or (bl == 1 and N % 4):
         pytest.skip("contiguous extent must be a multiple of 4")
     A = rnd(M, K, seed=1)

@@ -97,13 +97,14 @@ def test_update_intrinsics_mutates_caller_tensor():
 
 def test_gemm_tile_and_splitk_selection():
     from rel_pose_amd import ops
-    # mirrors of the tile choice in csrc/gemm.hip, per operand precision (3 = split-bf16 default, 0 = exact fp32 MFMA)
-    assert ops.GEMM_PRECISION == 3
+    # mirrors of the tile choice in csrc/gemm.hip, per operand precision (0 = exact fp32 MFMA, the default; 3 = split-bf16)
+    assert ops.GEMM_PRECISION == 0
     assert ops.gemm_instance(73728, 576, 0, 0) == (0, 0, 2, 1)
-    assert ops.gemm_instance(73728, 768, 0, 1) == (0, 1, 2, 1)
+    assert ops.gemm_instance(73728, 768, 0, 1) == (0, 1, 1, 3)
+    assert ops.gemm_instance(73728, 768, 0, 1, reads_mn=True) == (0, 1, 2, 1)
     assert ops.gemm_instance(576, 192, 1, 1) == (1, 1, 1, 3)
-    assert ops.gemm_tile(73728, 768, 0, 1, precision=0) == (1, 3)
-    assert ops.gemm_tile(73728, 768, 0, 1, reads_mn=True, precision=0) == (2, 1)
+    assert ops.gemm_tile(73728, 768, 0, 1, precision=3) == (2, 1)
+    assert ops.gemm_tile(576, 192, 1, 1, precision=3) == (1, 3)
     assert ops.gemm_instance(64, 512, 0, 0) == (0, 0, 1, 2)
     with pytest.raises(ValueError):
         ops.set_gemm_precision(2)

@@ -148,6 +148,8 @@ def main():
         dist.init_process_group(backend=os.environ.get("RP_DIST_BACKEND", "nccl"), init_method="env://",
                                 world_size=world, rank=rank)
 
+    if os.environ.get("RP_CUDNN_BENCHMARK"):
+        torch.backends.cudnn.benchmark = True          # MIOpen find mode for the CNN front-end (experiment)
     from rel_pose_amd import _lib, ops
     from rel_pose_amd.losses import geodesic_loss_tensors
     from rel_pose_amd.model import ViTEss

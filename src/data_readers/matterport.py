@@ -1,0 +1,1 @@
+from rel_pose_amd.data_readers.matterport import *  # noqa: F401,F403  (drop-in alias of reference src/data_readers/matterport.py)

@@ -1,0 +1,181 @@
+"""Dataset readers, augmentation and evaluation metrics on tiny fake datasets written in the
+reference's on-disk layout (reference src/data_readers/*.py, test_matterport.py, test_streetlearn_interiornet.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image, ImageEnhance
+from scipy.spatial.transform import Rotation
+
+from rel_pose_amd import evaluation as E
+from rel_pose_amd.data_readers import augmentation as A
+from rel_pose_amd.data_readers import viewpoint as V
+
+
+def _write_img(path, h, w, seed):
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    rng = np.random.default_rng(seed)
+    Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(path)
+
+
+@pytest.fixture()
+def matterport_root(tmp_path):
+    root = tmp_path / "matterport_fake"
+    data = []
+    for i in range(3):
+        names = []
+        for k in range(2):
+            rel = "rgb/house%d/img_%d_%d.png" % (i, i, k)
+            _write_img(str(root / rel), 48, 64, 10 * i + k)
+            names.append("/a/b/c/d/e/" + rel)              # the reader drops the first 6 path components
+        q = Rotation.from_euler("xyz", [10 * i, -20, 5 + i], degrees=True).as_quat()       # xyzw
+        wxyz = [float(q[3]), float(q[0]), float(q[1]), float(q[2])]
+        if i == 1:
+            wxyz = [-v for v in wxyz]                        # a negative-w ground truth
+        data.append({"0": {"file_name": names[0]}, "1": {"file_name": names[1]},
+                     "rel_pose": {"position": [1.0 + i, -2.0, 0.5], "rotation": wxyz}})
+    for split in ("train", "val", "test"):
+        os.makedirs(root / "mp3d_planercnn_json", exist_ok=True)
+        with open(root / "mp3d_planercnn_json" / ("cached_set_%s.json" % split), "w") as f:
+            json.dump({"data": data if split != "val" else data[:1]}, f)
+    return str(root), data
+
+
+def test_matterport_reader_conventions(matterport_root):
+    from rel_pose_amd.data_readers.factory import dataset_factory
+    from rel_pose_amd.data_readers.matterport import Matterport
+    root, data = matterport_root
+    db = Matterport(datapath=root, subepoch=0, reshape_size=[96, 128])
+    assert len(db) == 3 and len(Matterport(datapath=root, subepoch=10)) == 1          # sub-epoch 10 = validation split
+    images, poses, intr = db[1]
+    assert images.shape == (2, 3, 96, 128) and images.dtype == torch.float32 and 0 <= float(images.min()) and float(images.max()) <= 255
+    assert torch.equal(poses[0], torch.tensor([0, 0, 0, 0, 0, 0, 1.0]))
+    t = np.array(data[1]["rel_pose"]["position"]) / 5.0                                # DEPTH_SCALE
+    w, x, y, z = data[1]["rel_pose"]["rotation"]
+    # the reference swaps slots 3 and 6 of (t, w, x, y, z) (matterport.py:46-48): the stored quaternion is (z, x, y, w) --
+    # a quirk the evaluation (test_matterport.py:150-151) and demo.py:86-92 undo with the same swap; sign made w-positive
+    q = -np.array([z, x, y, w])
+    assert np.allclose(poses[1].numpy(), np.concatenate([t, q]), atol=1e-6) and poses[1, 6] > 0
+    # intrinsics of the 480x640 camera rescaled by reshape/actual image size (augmentation.py:28-34)
+    assert torch.allclose(intr[0], torch.tensor([517.97 * 128 / 64, 517.97 * 96 / 48, 320 * 128 / 64, 240 * 96 / 48]))
+    loader = torch.utils.data.DataLoader(dataset_factory(["matterport"], datapath=root, subepoch=0, reshape_size=[96, 128]), batch_size=3)
+    bi, bp, bk = next(iter(loader))
+    assert bi.shape == (3, 2, 3, 96, 128) and bp.shape == (3, 2, 7) and bk.shape == (3, 2, 4)
+    import src.data_readers.factory as alias                                            # drop-in module path of the reference
+    assert alias.dataset_factory is dataset_factory
+
+
+def test_panorama_readers_and_viewpoint_rotation(tmp_path):
+    from rel_pose_amd.data_readers.interiornet import InteriorNet
+    from rel_pose_amd.data_readers.streetlearn import StreetLearn
+    root = tmp_path / "pano"
+    rng = np.random.default_rng(3)
+    for meta, folder, cls, typ in (("interiornet", "interiornet", InteriorNet, ""), ("streetlearnT", "streetlearn_2016", StreetLearn, "T")):
+        split = {}
+        for i in range(40):
+            p1, p2 = "s%d/a.png" % i, "s%d/b.png" % i
+            if i < 12:
+                _write_img(str(root / "data" / folder / p1), 32, 32, i)
+                _write_img(str(root / "data" / folder / p2), 32, 32, 100 + i)
+            split[i] = {"img1": {"path": p1, "x": float(rng.uniform(-0.5, 0.5)), "y": float(rng.uniform(-3, 3))},
+                        "img2": {"path": p2, "x": float(rng.uniform(-0.5, 0.5)), "y": float(rng.uniform(-3, 3))}}
+        os.makedirs(root / "metadata" / meta, exist_ok=True)
+        name = "train_pair_translation_overlap.npy" if typ else "train_pair_rotation_overlap.npy"
+        np.save(root / "metadata" / meta / name, split, allow_pickle=True)
+        db = cls(datapath=str(root), subepoch=2, streetlearn_interiornet_type=typ, reshape_size=[64, 64])
+        assert len(db) == 4                                          # a tenth of the 40 pairs: keys 8..11
+        images, poses, intr = db[0]
+        assert images.shape == (2, 3, 64, 64) and torch.allclose(intr, torch.full((2, 4), 128.0 * 2))
+        a, b = split[8]["img1"], split[8]["img2"]
+        assert np.allclose(poses[1, 3:].numpy(), V.relative_quaternion(a["x"], a["y"], b["x"], b["y"]), atol=1e-6)
+        assert torch.equal(poses[1, :3], torch.zeros(3))             # rotation-only ground truth
+        mini = cls(datapath=str(root), subepoch=7, streetlearn_interiornet_type=typ, use_mini_dataset=True)
+        assert len(mini) == 40                                       # first 32000 pairs regardless of the sub-epoch
+    # unreadable samples are skipped forward (base.py:72-97): pair 12 has no files -> error only past the end
+    with pytest.raises(OSError):
+        mini[39]
+    # the viewpoint rotation: orthonormal, identity for equal views, pure yaw difference = that angle about the y axis
+    R = V.relative_rotation(0.3, 1.0, -0.2, 2.5)
+    assert np.allclose(R @ R.T, np.eye(3), atol=1e-6) and np.isclose(np.linalg.det(R), 1.0, atol=1e-6)
+    assert np.allclose(V.relative_rotation(0.1, 0.7, 0.1, 0.7), np.eye(3), atol=1e-6)
+    ang = np.degrees(np.arccos((np.trace(V.relative_rotation(0.0, 0.2, 0.0, 0.9)) - 1) / 2))
+    assert np.isclose(ang, np.degrees(0.7), atol=1e-3)
+
+
+def test_colour_jitter_matches_pil_enhancers():
+    """brightness / saturation / contrast are PIL's ImageEnhance blends (what torchvision's PIL path calls)"""
+    rng = np.random.default_rng(0)
+    rgb8 = rng.integers(0, 256, (24, 32, 3), dtype=np.uint8)
+    pil = Image.fromarray(rgb8)
+    x = torch.from_numpy(rgb8).permute(2, 0, 1).float() / 255.0
+    for fn, enh, f in ((A.adjust_brightness, ImageEnhance.Brightness, 1.2), (A.adjust_brightness, ImageEnhance.Brightness, 0.8),
+                       (A.adjust_saturation, ImageEnhance.Color, 0.77), (A.adjust_saturation, ImageEnhance.Color, 1.21),
+                       (A.adjust_contrast, ImageEnhance.Contrast, 0.8), (A.adjust_contrast, ImageEnhance.Contrast, 1.25)):
+        ref = np.asarray(enh(pil).enhance(f)).astype(np.float32)
+        got = (fn(x, f) * 255.0).permute(1, 2, 0).numpy()
+        assert np.abs(got - ref).max() <= 2.0, (fn.__name__, f)            # PIL rounds to 8 bits (and its gray mean too)
+    # hue: inverse shifts cancel, grays are fixed points, a shift of 1/3 rotates the primaries
+    y = A.adjust_hue(A.adjust_hue(x, 0.11), -0.11)
+    assert float((y - x).abs().max()) < 1e-4
+    g = torch.full((3, 4, 4), 0.4)
+    assert torch.allclose(A.adjust_hue(g, 0.3), g)
+    red = torch.tensor([1.0, 0.0, 0.0]).view(3, 1, 1)
+    assert torch.allclose(A.adjust_hue(red, 1.0 / 3.0), torch.tensor([0.0, 1.0, 0.0]).view(3, 1, 1), atol=1e-5)
+
+
+def test_augmentor_pair_semantics_and_batch():
+    aug = A.RGBDAugmentor([40, 48], generator=torch.Generator().manual_seed(5))
+    img = torch.floor(torch.rand(1, 3, 20, 24, generator=torch.Generator().manual_seed(1)) * 255)
+    pair = img.repeat(2, 1, 1, 1)                                    # two identical images
+    out = aug.color_transform(pair)
+    assert torch.equal(out[0], out[1])                               # one parameter draw per sample, like the reference
+    assert out.shape == pair.shape and float(out.min()) >= 0 and float(out.max()) <= 255
+    ident = dict(order=[0, 1, 2, 3], b=1.0, c=1.0, s=1.0, h=0.0, gray=False)
+    assert float((A.RGBDAugmentor.apply(pair, ident) - pair).abs().max()) < 1e-3
+    gray = A.RGBDAugmentor.apply(pair, dict(ident, gray=True))
+    assert torch.allclose(gray[:, 0], gray[:, 1]) and torch.allclose(gray[:, 1], gray[:, 2])
+    # draws stay inside torchvision's ColorJitter ranges
+    for _ in range(50):
+        p = aug.draw()
+        assert 0.75 <= p["b"] <= 1.25 and 0.75 <= p["c"] <= 1.25 and 0.75 <= p["s"] <= 1.25 and abs(p["h"]) <= 0.4 / 3.14
+        assert sorted(p["order"]) == [0, 1, 2, 3]
+    intr = torch.tensor([[10.0, 20.0, 12.0, 10.0]] * 2)
+    images, poses, k = aug(pair.clone(), torch.zeros(2, 7), intr)
+    assert images.shape == (2, 3, 40, 48) and torch.allclose(k[0], torch.tensor([20.0, 40.0, 24.0, 20.0]))
+    batch = torch.floor(torch.rand(3, 2, 3, 20, 24) * 255)
+    kb = torch.tensor([[[10.0, 20.0, 12.0, 10.0]] * 2] * 3)
+    ob, kb2 = aug.augment_batch(batch, kb)
+    assert ob.shape == (3, 2, 3, 40, 48) and torch.allclose(kb2[2, 1], torch.tensor([20.0, 40.0, 24.0, 20.0]))
+
+
+def test_matterport_metrics_known_answers(tmp_path):
+    gt_t = [[1.0, 0, 0], [0, 2.0, 0], [0, 0, 3.0], [1.0, 1.0, 1.0]]
+    gt_q = [Rotation.from_euler("z", a, degrees=True).as_quat()[[3, 0, 1, 2]] for a in (0, 40, 90, 10)]     # wxyz
+    errs_deg = (5.0, 20.0, 45.0, 0.0)
+    pred_q = [(Rotation.from_euler("z", a, degrees=True) * Rotation.from_euler("x", e, degrees=True)).as_quat()[[3, 0, 1, 2]]
+              for a, e in zip((0, 40, 90, 10), errs_deg)]
+    pred_q[1] = -pred_q[1]                                            # sign of a quaternion must not matter
+    pred_t = [[1.5, 0, 0], [0, 2.0, 0], [0, 0, 5.0], [1.0, 1.0, 1.0]]
+    m = E.camera_metrics_matterport(pred_t, pred_q, gt_t, gt_q, str(tmp_path / "out"))
+    assert np.isclose(m["R mean err"], np.mean(errs_deg), atol=1e-4) and np.isclose(m["R median err"], 12.5, atol=1e-4)
+    assert np.isclose(m["top1 R err < 30"], 75.0) and np.isclose(m["top1 T err < 1.0"], 75.0)
+    assert np.isclose(m["T mean err"], (0.5 + 0 + 2 + 0) / 4) and np.isclose(m["T median err"], 0.25)
+    rows = np.loadtxt(tmp_path / "out" / "gt_rotation_magnitude_vs_error.csv", delimiter=",")
+    assert rows.shape == (4, 2) and np.allclose(rows[:, 0], [0, 40, 90, 10], atol=1e-3)
+    # model output -> evaluation convention (test_matterport.py:147-153): w back in front, metres again
+    t, q = E.matterport_prediction(np.array([0.2, -0.4, 0.1, 0.1, 0.2, 0.3, 0.9]))
+    assert np.allclose(t, [1.0, -2.0, 0.5]) and np.allclose(q, [0.9, 0.2, 0.3, 0.1])
+    assert np.allclose(E.matterport_gt_rotation([-0.5, 0.5, 0.5, 0.5]), [0.5, -0.5, -0.5, -0.5])
+
+
+def test_panorama_rotation_metrics_known_answers(tmp_path):
+    gt = [Rotation.from_euler("y", a, degrees=True) for a in (10, 30, 60, 80, 120)]
+    err = (2.0, 15.0, 8.0, 30.0, 1.0)
+    pred = [Rotation.from_euler("x", e, degrees=True) * g for g, e in zip(gt, err)]
+    m = E.rotation_metrics_panorama([p.as_quat() for p in pred], [g.as_quat() for g in gt], str(tmp_path / "o"))
+    assert np.isclose(m["rotation_geodesic_error_overlap_large/mean"], 8.5, atol=1e-4)       # gt angle < 45: errors 2, 15
+    assert np.isclose(m["rotation_geodesic_error_overlap_large/10deg"], 0.5)
+    assert np.isclose(m["rotation_geodesic_error_overlap_small/median"], 19.0, atol=1e-4)   # 45 <= gt < 90: errors 8, 30
+    assert np.loadtxt(tmp_path / "o" / "all_rotation_err_degrees.csv").shape == (4,)         # the 120-degree pair is dropped

@@ -3,10 +3,11 @@
 
 One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI), batch-of-pairs data parallel through
 DistributedDataParallel: the only exchange per step is the gradient all-reduce.  The model is the drop-in ViTEss of
-rel_pose_amd (HIP hot path).  Datasets (Matterport / InteriorNet / StreetLearn readers, reference
-src/data_readers/*) are out of scope: `--dataset synthetic` (default here) streams
-seeded random pairs of the real tensor shapes so the whole loop -- forward, geodesic loss, backward, clip, Adam,
-OneCycle schedule, checkpoint save / auto-resume with the reference's file layout and keys -- runs anywhere.
+rel_pose_amd (HIP hot path).  `--dataset matterport|interiornet|streetlearn --datapath ...` reads the reference's
+dataset layouts through rel_pose_amd/data_readers (ten sub-epochs then a validation pass, reference train.py:108-131);
+no dataset exists in the build environment, so `--dataset synthetic` (default here) streams seeded random pairs of the real
+tensor shapes and the whole loop -- forward, geodesic loss, backward, clip, Adam, OneCycle schedule, checkpoint save /
+auto-resume with the reference's file layout and keys -- runs anywhere.
 
     python train.py --name run0 --gpus 1 --batch 64 --steps 100 --fusion_transformer          # single GPU
     python -m torch.distributed.run --nproc-per-node 8 train.py --name run0 --gpus 8 ...       # one rank per GPU
@@ -102,21 +103,40 @@ def run(args):
         if rank == 0:
             print("resumed from", resume, "at step", resumed_step)
 
-    if args.dataset != "synthetic":
-        raise SystemExit("dataset readers are out of scope here (no datasets in this environment): use --dataset synthetic")
-    db = SyntheticPairs(args.batch * world * 50, tuple(args.image_size))
-    sampler = torch.utils.data.distributed.DistributedSampler(db, num_replicas=world, rank=rank, shuffle=True) if ddp else None
-    loader = torch.utils.data.DataLoader(db, batch_size=args.batch, sampler=sampler, shuffle=sampler is None,
-                                         num_workers=args.num_workers, pin_memory=True, drop_last=True)
+    def make_loader(subepoch):
+        """(loader, sampler, is_training): the reference rebuilds its dataset every sub-epoch; the 11th is validation"""
+        is_training = subepoch != 10
+        if args.dataset == "synthetic":
+            db = SyntheticPairs(args.batch * world * 50, tuple(args.image_size))
+        else:
+            from rel_pose_amd.data_readers.factory import dataset_factory
+            db = dataset_factory([args.dataset], datapath=args.datapath, subepoch=subepoch, is_training=is_training, gpu=local,
+                                 streetlearn_interiornet_type=args.streetlearn_interiornet_type,
+                                 use_mini_dataset=args.use_mini_dataset, reshape_size=list(args.image_size))
+        smp = (torch.utils.data.distributed.DistributedSampler(db, num_replicas=world, rank=rank, shuffle=is_training)
+               if ddp else None)
+        ld = torch.utils.data.DataLoader(db, batch_size=args.batch, sampler=smp, shuffle=(smp is None and is_training),
+                                         num_workers=args.num_workers, pin_memory=True, drop_last=is_training)
+        return ld, smp, is_training
+
     os.makedirs("output/%s/checkpoints" % args.name, exist_ok=True)
     step, t0 = (resumed_step if resume else 0), time.time()
+    subepoch = 0
     while step < args.steps:
+        loader, sampler, is_training = make_loader(subepoch)
         if sampler is not None:
             sampler.set_epoch(step)
+        net.train(is_training)
+        val = []
         for images, poses, intr in loader:
             images, poses, intr = images.to(dev, non_blocking=True), poses.to(dev), intr.to(dev)
             Ps = SE3(poses)
             Gs = SE3.IdentityLike(Ps)
+            if not is_training:                       # validation pass (reference train.py:147-150)
+                with torch.no_grad():
+                    est = net(images, Gs, intrinsics=intr)
+                    val.append(geodesic_loss(Ps, est, train_val="val")[2])
+                continue
             opt.zero_grad(set_to_none=True)
             est = net(images, Gs, intrinsics=intr)
             ltr, lrot, metrics = geodesic_loss(Ps, est)
@@ -132,6 +152,9 @@ def run(args):
                            "output/%s/checkpoints/%06d.pth" % (args.name, step))
             if step >= args.steps:
                 break
+        if val and rank == 0:
+            print("validation  %s" % {k: sum(v[k] for v in val) / len(val) for k in val[0]}, flush=True)
+        subepoch = (subepoch + 1) % 11 if args.dataset != "synthetic" else 0
     if rank == 0:
         print("finished training!")
     if ddp:

@@ -73,6 +73,7 @@ def run(args):
     if ddp:
         parallel.setup(rank, world, backend="nccl")
     torch.manual_seed(0)
+    torch.backends.cudnn.benchmark = True      # MIOpen solver search for CNN shapes missing from rel_pose_amd/miopen_db (once)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

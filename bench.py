@@ -149,9 +149,10 @@ def main():
         dist.init_process_group(backend=os.environ.get("RP_DIST_BACKEND", "nccl"), init_method="env://",
                                 world_size=world, rank=rank)
 
-    # CNN front-end: MIOpen "find" for configurations missing from the shipped user db (rel_pose_amd/_env.py); searched once,
-    # in the untimed priming step below
-    torch.backends.cudnn.benchmark = os.environ.get("RP_CUDNN_BENCHMARK", "1") != "0"
+    # CNN front-end: the convolution solvers for the bench shapes (128 images of 224x224 per GPU) come from the shipped MIOpen
+    # user db (rel_pose_amd/_env.py), immediate mode, no search.  Other --batch / --hw values are not in it:
+    # RP_CUDNN_BENCHMARK=1 lets MIOpen search them once, inside the untimed priming step below (takes tens of seconds).
+    torch.backends.cudnn.benchmark = os.environ.get("RP_CUDNN_BENCHMARK", "0") == "1"
     from rel_pose_amd import _lib, ops
     from rel_pose_amd.losses import geodesic_loss_tensors
     from rel_pose_amd.model import ViTEss

@@ -79,6 +79,27 @@ int rp_gemm(const RpGemm* g, void* stream);
 size_t rp_gemm_workspace_bytes(int M, int N, int split_k);
 
 
+/* ---------------------------------------------------------------------------------------------
+ * Channels-last BatchNorm2d fused with the residual add and ReLU that follow it in the CNN front-end
+ * (torchvision BasicBlock as driven by src/model.py:127-132; ResidualBlock, src/modules/extractor.py:51-65).
+ * x, y, dy, dx, residual: [R, C], R = N*H*W rows, C contiguous channels (C % 4 == 0, C <= 256).
+ *   rp_bn_stats      mean[c], rstd[c] = 1/sqrt(biased var + eps) over the R rows; if running_* != NULL also the PyTorch
+ *                    running-statistics update (momentum, unbiased variance).  partial: [rp_bn_partial_blocks(R)][2][C] doubles.
+ *   rp_bn_apply_fwd  y = relu?((x - mean) * rstd * gamma + beta (+ residual))   (training: batch stats; eval: running stats)
+ *   rp_bn_bwd        g = dy * (relu ? y > 0 : 1) (y == NULL: the forward had no residual and its output sign is re-evaluated
+ *                    from x, bit-identically -- y then need not be kept);  dbeta = sum g;  dgamma = sum g * xhat;
+ *                    training: dx = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat));  eval: dx = gamma*rstd*g;
+ *                    dres != NULL: g is also stored there (gradient of the residual branch).  c12: [2][C] floats scratch.
+ * ------------------------------------------------------------------------------------------- */
+int rp_bn_partial_blocks(long long R);
+int rp_bn_stats(const float* x, long long R, int C, double* partial, float* mean, float* rstd, float* running_mean,
+                float* running_var, float momentum, float eps, void* stream);
+int rp_bn_apply_fwd(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                    const float* residual, float* y, long long R, int C, int relu, void* stream);
+int rp_bn_bwd(const float* dy, const float* y, const float* x, const float* mean, const float* rstd, const float* gamma,
+              const float* beta, float* dx, float* dres, float* dgamma, float* dbeta, double* partial, float* c12, long long R, int C, int relu,
+              int training, void* stream);
+
 /* LayerNorm over the last dim C (multiple of 64, <= 512), eps as given (reference uses 1e-6,
  * vision_transformer.py:396).  Saves mean / rstd per row for the backward. */
 int rp_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,

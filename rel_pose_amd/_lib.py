@@ -31,6 +31,10 @@ _SIGS = {
     "rp_target_arch": (c_char_p, []),
     "rp_gemm": (c_int, [POINTER(RpGemm), P]),
     "rp_gemm_workspace_bytes": (c_size_t, [I, I, I]),
+    "rp_bn_partial_blocks": (c_int, [L]),
+    "rp_bn_stats": (c_int, [P, L, I, P, P, P, P, P, F, F, P]),
+    "rp_bn_apply_fwd": (c_int, [P, P, P, P, P, P, P, L, I, I, P]),
+    "rp_bn_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, P]),
     "rp_layernorm_fwd": (c_int, [P, P, P, P, P, P, I, I, F, P]),
     "rp_layernorm_bwd_blocks": (c_int, [I]),
     "rp_layernorm_bwd": (c_int, [P, P, P, P, P, P, P, P, P, I, I, P]),

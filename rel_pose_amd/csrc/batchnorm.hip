@@ -1,0 +1,290 @@
+// batchnorm.hip -- channels-last BatchNorm2d fused with the residual add and ReLU that follow it in the CNN front-end
+// (torchvision BasicBlock: relu(bn1(.)), relu(bn2(.) + identity); reference src/modules/extractor.py:51-65:
+// relu(norm1(.)), relu(norm2(.)), relu(norm3(downsample) + y)), forward and backward.
+//
+// Why (profiles/r1_full_step_summary.txt): around MIOpen's convolutions the front-end spent 4.7 ms per step in separate
+// BatchNorm (2 passes forward, 2 backward), ReLU (forward clamp, backward mask) and residual-add kernels, all HBM-bound
+// over the same [N*H*W, C] activations.  Here a BatchNorm+add+ReLU is 2 passes forward (column statistics; normalise + add +
+// clamp) and 2 backward (masked column sums; dx), i.e. the ReLU and add passes disappear.
+//
+// Layout: x is [R, C] with R = N*H*W rows and C (multiple of 4, <= 256) contiguous channels -- a channels-last NCHW tensor.
+// Statistics: per-thread fp32 partial sums over <= 64 rows, everything above that in double (block partials and the
+// final combine), so E[x^2] - mean^2 has no cancellation problem at R = 1.6 M rows.
+#include "common.h"
+#include "../../include/relpose_hip.h"
+
+namespace {
+
+constexpr int BN_MAXC = 256;
+
+// the normalisation, written with explicit fmas: the backward kernels re-evaluate it to rebuild the ReLU mask from x alone
+// (no residual), and must get bit-identical values
+RP_DEV float4 bn_affine(const float4 xv, const float4 mu, const float4 rs, const float4 ga, const float4 be) {
+  float4 v;
+  v.x = __builtin_fmaf(xv.x - mu.x, rs.x * ga.x, be.x); v.y = __builtin_fmaf(xv.y - mu.y, rs.y * ga.y, be.y);
+  v.z = __builtin_fmaf(xv.z - mu.z, rs.z * ga.z, be.z); v.w = __builtin_fmaf(xv.w - mu.w, rs.w * ga.w, be.w);
+  return v;
+}
+
+inline int bn_rows_per_block(long long R) {
+  long long rpb = (R + 1023) / 1024;       // ~1024 blocks (4 per CU)
+  if (rpb < 128) rpb = 128;
+  return (int)rpb;
+}
+
+// stage 1: column sums of (a, b) over this block's rows.  MODE 0: a = x, b = x*x.
+// MODE 1: g = dy * (relu ? y > 0 : 1); a = g, b = g * xhat, xhat = (x - mean) * rstd; optionally stores g.
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                        const float* __restrict__ y, const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ gout,
+                                                        double* __restrict__ partial, long long R, int C, int rpb, int relu) {
+  __shared__ double red[2][256][4];
+  const int c4n = C >> 2, nrl = 256 / c4n;
+  const int tid = threadIdx.x, cg = tid % c4n, rl = tid / c4n;
+  const long long r0 = (long long)blockIdx.x * rpb, r1 = min(R, r0 + rpb);
+  double a0[4] = {0, 0, 0, 0}, b0[4] = {0, 0, 0, 0};
+  if (rl < nrl) {
+    float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), rs = mu, ga = mu, be = mu;
+    if (MODE == 1) { mu = ld4(mean + 4 * cg); rs = ld4(rstd + 4 * cg); }
+    const bool remask = MODE == 1 && relu && y == nullptr;       // ReLU mask rebuilt from x (no residual was added)
+    if (remask) { ga = ld4(gamma + 4 * cg); be = ld4(beta + 4 * cg); }
+    float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa;
+    int cnt = 0;
+    auto acc1 = [&](const float4 xv, float4 g, const float4 yv) {
+      if (MODE == 0) {
+        sa.x += xv.x; sa.y += xv.y; sa.z += xv.z; sa.w += xv.w;
+        sb.x += xv.x * xv.x; sb.y += xv.y * xv.y; sb.z += xv.z * xv.z; sb.w += xv.w * xv.w;
+      } else {
+        sa.x += g.x; sa.y += g.y; sa.z += g.z; sa.w += g.w;
+        sb.x += g.x * (xv.x - mu.x) * rs.x; sb.y += g.y * (xv.y - mu.y) * rs.y;
+        sb.z += g.z * (xv.z - mu.z) * rs.z; sb.w += g.w * (xv.w - mu.w) * rs.w;
+      }
+    };
+    auto mask = [&](float4 g, const float4 yv) {
+      g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f; g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+      return g;
+    };
+    constexpr int U = 4;                     // rows in flight per thread (independent 16-byte loads)
+    long long r = r0 + rl;
+    for (; r + (U - 1) * (long long)nrl < r1; r += (long long)U * nrl) {
+      float4 xv[U], g[U], yv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long long off = (r + (long long)u * nrl) * C + 4 * cg;
+        xv[u] = ld4(x + off);
+        if (MODE == 1) {
+          g[u] = ld4(dy + off);
+          if (relu && !remask) yv[u] = ld4(y + off);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (MODE == 1) {
+          if (remask) yv[u] = bn_affine(xv[u], mu, rs, ga, be);
+          if (relu) g[u] = mask(g[u], yv[u]);
+          if (gout) st4(gout + (r + (long long)u * nrl) * C + 4 * cg, g[u]);
+        }
+        acc1(xv[u], g[u], yv[u]);
+      }
+      cnt += U;
+      if (cnt >= 64) {       // flush the fp32 partials into double
+        a0[0] += sa.x; a0[1] += sa.y; a0[2] += sa.z; a0[3] += sa.w;
+        b0[0] += sb.x; b0[1] += sb.y; b0[2] += sb.z; b0[3] += sb.w;
+        sa = make_float4(0.f, 0.f, 0.f, 0.f); sb = sa; cnt = 0;
+      }
+    }
+    for (; r < r1; r += nrl) {
+      const long long off = r * C + 4 * cg;
+      const float4 xv = ld4(x + off);
+      float4 g = make_float4(0.f, 0.f, 0.f, 0.f), yv = g;
+      if (MODE == 1) {
+        g = ld4(dy + off);
+        if (relu) { yv = remask ? bn_affine(xv, mu, rs, ga, be) : ld4(y + off); g = mask(g, yv); }
+        if (gout) st4(gout + off, g);
+      }
+      acc1(xv, g, yv);
+    }
+    a0[0] += sa.x; a0[1] += sa.y; a0[2] += sa.z; a0[3] += sa.w;
+    b0[0] += sb.x; b0[1] += sb.y; b0[2] += sb.z; b0[3] += sb.w;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { red[0][tid][e] = a0[e]; red[1][tid][e] = b0[e]; }
+  __syncthreads();
+  if (tid < c4n) {          // row lane 0 of each column group sums the others (fixed order)
+    for (int l = 1; l < nrl; ++l)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { a0[e] += red[0][tid + l * c4n][e]; b0[e] += red[1][tid + l * c4n][e]; }
+    double* p = partial + (long long)blockIdx.x * 2 * C;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { p[4 * cg + e] = a0[e]; p[C + 4 * cg + e] = b0[e]; }
+  }
+}
+
+// stage 2: a block takes 16 channels x 16 lanes; each lane sums every 16th block partial, lanes are combined in fixed order
+// (all in double).  MODE 0: mean, rstd (+ running statistics update).  MODE 1: dbeta, dgamma and the two means of the dx pass.
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ partial, int nblk, int C, long long R,
+                                                          float* __restrict__ o0, float* __restrict__ o1,
+                                                          float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                          float momentum, float eps, float* __restrict__ c12) {
+  __shared__ double red[2][16][16];
+  const int cl = threadIdx.x & 15, lane = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  double a = 0.0, b = 0.0;
+  if (c < C) {
+    double a1 = 0.0, b1 = 0.0;
+    int k = lane;
+    for (; k + 16 < nblk; k += 32) {          // two independent chains
+      a += partial[(long long)k * 2 * C + c];
+      b += partial[(long long)k * 2 * C + C + c];
+      a1 += partial[(long long)(k + 16) * 2 * C + c];
+      b1 += partial[(long long)(k + 16) * 2 * C + C + c];
+    }
+    if (k < nblk) {
+      a += partial[(long long)k * 2 * C + c];
+      b += partial[(long long)k * 2 * C + C + c];
+    }
+    a += a1;
+    b += b1;
+  }
+  red[0][lane][cl] = a;
+  red[1][lane][cl] = b;
+  __syncthreads();
+  if (lane != 0 || c >= C) return;
+  for (int l = 1; l < 16; ++l) { a += red[0][l][cl]; b += red[1][l][cl]; }
+  if (MODE == 0) {
+    const double m = a / (double)R;
+    double var = b / (double)R - m * m;
+    if (var < 0.0) var = 0.0;
+    o0[c] = (float)m;
+    o1[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (run_mean) {
+      const double unb = R > 1 ? var * (double)R / (double)(R - 1) : var;
+      run_mean[c] = (float)((1.0 - momentum) * run_mean[c] + momentum * m);
+      run_var[c] = (float)((1.0 - momentum) * run_var[c] + momentum * unb);
+    }
+  } else {
+    o0[c] = (float)a;            // dbeta
+    o1[c] = (float)b;            // dgamma
+    c12[c] = (float)(a / (double)R);
+    c12[C + c] = (float)(b / (double)R);
+  }
+}
+
+// y = relu?((x - mean) * rstd * gamma + beta (+ residual))
+__global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ res,
+                                                           float* __restrict__ y, long long n4, int c4n, int relu) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const int c = 4 * (int)(i % c4n);
+    const float4 xv = ld4(x + 4 * i), mu = ld4(mean + c), rs = ld4(rstd + c), ga = ld4(gamma + c), be = ld4(beta + c);
+    float4 v;
+    v = bn_affine(xv, mu, rs, ga, be);
+    if (res) {
+      const float4 r = ld4(res + 4 * i);
+      v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    st4(y + 4 * i, v);
+  }
+}
+
+// dx = gamma * rstd * (g - c1 - xhat * c2)   (training);   dx = gamma * rstd * g   (eval: c12 == nullptr)
+// g is read from `g` when given (it was stored by the reduce pass for the residual branch), else recomputed from dy, y
+__global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                           const float* __restrict__ gin, const float* __restrict__ x,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ c12, float* __restrict__ dx, long long n4,
+                                                           int c4n, int relu) {
+  const int C = 4 * c4n;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const int c = 4 * (int)(i % c4n);
+    const float4 rs = ld4(rstd + c), ga = ld4(gamma + c), mu = ld4(mean + c);
+    const float4 xv = ld4(x + 4 * i);
+    float4 g;
+    if (gin) {
+      g = ld4(gin + 4 * i);
+    } else {
+      g = ld4(dy + 4 * i);
+      if (relu) {
+        const float4 yv = y ? ld4(y + 4 * i) : bn_affine(xv, mu, rs, ga, ld4(beta + c));
+        g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f; g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+      }
+    }
+    float4 v;
+    if (c12) {
+      const float4 c1 = ld4(c12 + c), c2 = ld4(c12 + C + c);
+      v.x = (ga.x * rs.x) * (g.x - c1.x - (xv.x - mu.x) * rs.x * c2.x);
+      v.y = (ga.y * rs.y) * (g.y - c1.y - (xv.y - mu.y) * rs.y * c2.y);
+      v.z = (ga.z * rs.z) * (g.z - c1.z - (xv.z - mu.z) * rs.z * c2.z);
+      v.w = (ga.w * rs.w) * (g.w - c1.w - (xv.w - mu.w) * rs.w * c2.w);
+    } else {
+      v.x = ga.x * rs.x * g.x; v.y = ga.y * rs.y * g.y; v.z = ga.z * rs.z * g.z; v.w = ga.w * rs.w * g.w;
+    }
+    st4(dx + 4 * i, v);
+  }
+}
+
+int bn_check(long long R, int C) {
+  if (R <= 0 || C <= 0 || (C & 3) || C > BN_MAXC) return RP_EBADSHAPE;
+  return RP_OK;
+}
+int apply_grid(long long n4) {
+  long long b = (n4 + 255) / 256;
+  return (int)(b > 8192 ? 8192 : b);
+}
+
+}  // namespace
+
+extern "C" int rp_bn_partial_blocks(long long R) {
+  const int rpb = bn_rows_per_block(R);
+  return (int)((R + rpb - 1) / rpb);
+}
+
+extern "C" int rp_bn_stats(const float* x, long long R, int C, double* partial, float* mean, float* rstd, float* running_mean,
+                           float* running_var, float momentum, float eps, void* stream) {
+  if (int e = bn_check(R, C)) return e;
+  hipStream_t st = (hipStream_t)stream;
+  const int rpb = bn_rows_per_block(R), nblk = (int)((R + rpb - 1) / rpb);
+  hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(nblk), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                     nullptr, partial, R, C, rpb, 0);
+  RP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3((C + 15) / 16), dim3(256), 0, st, (const double*)partial, nblk, C, R, mean,
+                     rstd, running_mean, running_var, momentum, eps, nullptr);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
+extern "C" int rp_bn_apply_fwd(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                               const float* residual, float* y, long long R, int C, int relu, void* stream) {
+  if (int e = bn_check(R, C)) return e;
+  const long long n4 = R * C / 4;
+  hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(apply_grid(n4)), dim3(256), 0, (hipStream_t)stream, x, mean, rstd, gamma, beta,
+                     residual, y, n4, C / 4, relu);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
+extern "C" int rp_bn_bwd(const float* dy, const float* y, const float* x, const float* mean, const float* rstd,
+                         const float* gamma, const float* beta, float* dx, float* dres, float* dgamma, float* dbeta,
+                         double* partial, float* c12, long long R, int C, int relu, int training, void* stream) {
+  if (int e = bn_check(R, C)) return e;
+  if (relu && !y && !beta) return RP_EBADSHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const int rpb = bn_rows_per_block(R), nblk = (int)((R + rpb - 1) / rpb);
+  hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3(nblk), dim3(256), 0, st, x, dy, y, mean, rstd, gamma, beta, dres, partial, R, C, rpb,
+                     relu);
+  RP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3((C + 15) / 16), dim3(256), 0, st, (const double*)partial, nblk, C, R, dbeta,
+                     dgamma, nullptr, nullptr, 0.f, 0.f, c12);
+  RP_CHECK_LAUNCH();
+  const long long n4 = R * C / 4;
+  hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(apply_grid(n4)), dim3(256), 0, st, dy, y, (const float*)dres, x, mean, rstd, gamma,
+                     beta, training ? (const float*)c12 : nullptr, dx, n4, C / 4, relu);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}

@@ -5,10 +5,12 @@ The reference builds ``torchvision.models.resnet18(pretrained=True)`` and drives
 ``layer3``/``layer4`` exist only so that checkpoints load and ``train.py`` can freeze them
 (reference train.py:60-64).  torchvision is not installed in this image, so the trunk is
 restated here with identical ``state_dict`` keys.  Runs on
-PyTorch-ROCm (MIOpen) -- the CNN front-end is a "next" row, not a
-hand-kernel target this round.
+PyTorch-ROCm (MIOpen) for the convolutions; the BatchNorm + residual-add + ReLU chains around them
+are fused HIP kernels (ops.bn_act) -- the CNN front-end is the first "next" row.
 """
 import torch.nn as nn
+
+from ..ops import bn_act
 
 
 class BasicBlock(nn.Module):
@@ -25,10 +27,10 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        idt = x if self.downsample is None else self.downsample(x)
-        y = self.relu(self.bn1(self.conv1(x)))
-        y = self.bn2(self.conv2(y))
-        return self.relu(y + idt)
+        # BatchNorm + residual add + ReLU as one fused pass pair on the GPU (rel_pose_amd/csrc/batchnorm.hip)
+        idt = x if self.downsample is None else bn_act(self.downsample[1], self.downsample[0](x), relu=False)
+        y = bn_act(self.bn1, self.conv1(x))
+        return bn_act(self.bn2, self.conv2(y), residual=idt)
 
 
 class ResNet18(nn.Module):

@@ -711,3 +711,75 @@ class LayerNormFn(torch.autograd.Function):
         x2, m, r, w = ctx.saved_tensors
         dx, dw, db = layernorm_bwd(dy.contiguous().view(x2.shape), x2, w, m, r)
         return dx.view(dy.shape), dw, db
+
+
+# ------------------------------------------------------------------------------------------------
+# CNN front-end: channels-last BatchNorm2d + residual add + ReLU in two passes each way (csrc/batchnorm.hip)
+# ------------------------------------------------------------------------------------------------
+class BnActFn(torch.autograd.Function):
+    """y = relu?(batch_norm(x) (+ residual)) for a channels-last NCHW x; same statistics / running-buffer semantics as
+    torch.nn.BatchNorm2d (biased batch variance for the normalisation, unbiased for running_var, momentum update in
+    training; running statistics in eval).  Returns a channels-last tensor."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, training, momentum, eps, relu):
+        lib = _lib.load()
+        N, C, H, W = x.shape
+        xr = x.permute(0, 2, 3, 1)                       # [N,H,W,C] view of the channels-last buffer
+        if not xr.is_contiguous():
+            xr = xr.contiguous()
+        rr = None
+        if residual is not None:
+            rr = residual.permute(0, 2, 3, 1)
+            if not rr.is_contiguous():
+                rr = rr.contiguous()
+        _chk(xr, gamma, beta, rr)
+        R = N * H * W
+        y = torch.empty_like(xr)
+        if training:
+            mean, rstd = _empty(C, like=xr), _empty(C, like=xr)
+            part = torch.empty(lib.rp_bn_partial_blocks(R) * 2 * C, device=x.device, dtype=torch.float64)
+            _lib.check(lib.rp_bn_stats(_p(xr), R, C, _p(part), _p(mean), _p(rstd), _p(running_mean), _p(running_var),
+                                       float(momentum), float(eps), _st()), "rp_bn_stats")
+        else:
+            mean, rstd = running_mean, torch.rsqrt(running_var + eps)
+        _lib.check(lib.rp_bn_apply_fwd(_p(xr), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(rr), _p(y), R, C, 1 if relu else 0,
+                                       _st()), "rp_bn_apply_fwd")
+        if any(ctx.needs_input_grad):
+            # without a residual the ReLU mask is re-evaluated from x in the backward: y is not kept alive for it
+            keep_y = y if (relu and residual is not None) else None
+            ctx.save_for_backward(xr, keep_y, mean, rstd, gamma, beta)
+            ctx.cfg = (R, C, bool(relu), bool(training), residual is not None)
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        xr, y, mean, rstd, gamma, beta = ctx.saved_tensors
+        R, C, relu, training, has_res = ctx.cfg
+        dyr = dy.permute(0, 2, 3, 1)
+        if not dyr.is_contiguous():
+            dyr = dyr.contiguous()
+        _chk(dyr)
+        dx = torch.empty_like(xr)
+        dres = torch.empty_like(xr) if has_res and ctx.needs_input_grad[5] else None
+        dgamma, dbeta, c12 = _empty(C, like=xr), _empty(C, like=xr), _empty(2 * C, like=xr)
+        part = torch.empty(lib.rp_bn_partial_blocks(R) * 2 * C, device=xr.device, dtype=torch.float64)
+        _lib.check(lib.rp_bn_bwd(_p(dyr), _p(y), _p(xr), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dx), _p(dres), _p(dgamma), _p(dbeta),
+                                 _p(part), _p(c12), R, C, 1 if relu else 0, 1 if training else 0, _st()), "rp_bn_bwd")
+        return (dx.permute(0, 3, 1, 2), dgamma, dbeta, None, None,
+                None if dres is None else dres.permute(0, 3, 1, 2), None, None, None, None)
+
+
+def bn_act(bn, x, residual=None, relu=True):
+    """BatchNorm2d module `bn` applied to x, then (+ residual), then ReLU.  GPU tensors take the fused HIP path; CPU tensors
+    (only the fixture generator uses the trunk on the CPU, as the reference's torchvision stand-in) take plain PyTorch."""
+    if not x.is_cuda:
+        y = bn(x)
+        if residual is not None:
+            y = y + residual
+        return torch.relu(y) if relu else y
+    if bn.training and bn.track_running_stats:
+        bn.num_batches_tracked += 1
+    return BnActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, bn.training, bn.momentum, bn.eps,
+                         relu)

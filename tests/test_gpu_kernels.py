@@ -341,3 +341,48 @@ def test_preprocess_bit_exact(ops, H, W):
     got = ops.preprocess(imgs.cuda())
     assert got.shape == (4, 3, 224, 224) and got.is_contiguous(memory_format=torch.channels_last)
     assert torch.equal(got.cpu(), ref)
+
+
+# ------------------------------------------------------------------------------------------------ CNN front-end BatchNorm
+@pytest.mark.parametrize("shape", [(4, 64, 28, 28), (3, 192, 12, 12), (2, 128, 9, 7)])
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("with_res,relu", [(False, True), (True, True), (False, False)])
+def test_fused_batchnorm_add_relu(ops, shape, training, with_res, relu):
+    """ops.bn_act (csrc/batchnorm.hip) against torch.nn.BatchNorm2d (+ add + relu) in fp64: output, input / residual /
+    affine gradients and the running-statistics update."""
+    N, C, H, W = shape
+    g = torch.Generator(device="cpu").manual_seed(C + H)
+    x = (torch.randn(N, C, H, W, generator=g) * 1.7 + 0.6)
+    res = torch.randn(N, C, H, W, generator=g) if with_res else None
+    cot = torch.randn(N, C, H, W, generator=g)
+    bn = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=g) * 0.3)
+        bn.running_mean.copy_(torch.randn(C, generator=g) * 0.2)
+        bn.running_var.copy_(torch.rand(C, generator=g) + 0.5)
+    ref_bn = torch.nn.BatchNorm2d(C).double()
+    ref_bn.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in bn.state_dict().items()})
+    bn = bn.cuda().train(training)
+    ref_bn.train(training)
+    xr = x.double().requires_grad_(True)
+    rr = None if res is None else res.double().requires_grad_(True)
+    yr = ref_bn(xr)
+    if rr is not None:
+        yr = yr + rr
+    if relu:
+        yr = yr.relu()
+    (yr * cot.double()).sum().backward()
+    xg = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    rg = None if res is None else res.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = ops.bn_act(bn, xg, residual=rg, relu=relu)
+    assert y.is_contiguous(memory_format=torch.channels_last)
+    (y * cot.cuda()).sum().backward()
+    errs = dict(y=rel(y, yr), dx=rel(xg.grad, xr.grad), dgamma=rel(bn.weight.grad, ref_bn.weight.grad),
+                dbeta=rel(bn.bias.grad, ref_bn.bias.grad), rmean=rel(bn.running_mean, ref_bn.running_mean),
+                rvar=rel(bn.running_var, ref_bn.running_var))
+    if rg is not None:
+        errs["dres"] = rel(rg.grad, rr.grad)
+    report("bn_act[%s|train=%d|res=%d|relu=%d]" % ("x".join(map(str, shape)), training, with_res, relu), **errs)
+    assert max(errs.values()) < 5e-6
+    assert int(bn.num_batches_tracked) == (1 if training else 0)

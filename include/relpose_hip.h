@@ -100,6 +100,13 @@ int rp_bn_bwd(const float* dy, const float* y, const float* x, const float* mean
               const float* beta, float* dx, float* dres, float* dgamma, float* dbeta, double* partial, float* c12, long long R, int C, int relu,
               int training, void* stream);
 
+/* Geodesic pose loss of the training step (reference src/geom/losses.py:3-21; SE(3) arithmetic as restated in
+ * rel_pose_amd/se3.py since lietorch is not vendored): Ps, Gs [B,2,7] (t, q xyzw);
+ *   losses[0] = mean_{b,j} |tau|, losses[1] = mean_{b,j} |phi| of log(dG_j dP_j^-1), dG_j = G[1-j] G[j]^-1, dP_j likewise;
+ *   dmean[m][b][k] = d losses[m] / d Gs[b].flat[k]  (m < 2, k < 14; exact forward-mode derivatives of the same arithmetic).
+ * scratch: 60*B floats. */
+int rp_geodesic_loss(const float* Ps, const float* Gs, float* losses, float* dmean, float* scratch, int B, void* stream);
+
 /* LayerNorm over the last dim C (multiple of 64, <= 512), eps as given (reference uses 1e-6,
  * vision_transformer.py:396).  Saves mean / rstd per row for the backward. */
 int rp_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,

@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librelpose_hip.so")
-SOURCES = ["gemm.hip", "rowwise.hip", "attention.hip", "emm.hip", "batchnorm.hip"]
+SOURCES = ["gemm.hip", "rowwise.hip", "attention.hip", "emm.hip", "batchnorm.hip", "se3loss.hip"]
 ARCH = "gfx950"
 
 

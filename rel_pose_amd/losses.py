@@ -14,7 +14,17 @@ def _pair_swap(G):
 
 
 def geodesic_loss_tensors(Ps, Gs):
-    """(translation, rotation) geodesic losses as device scalars -- no .item(), no host sync."""
+    """(translation, rotation) geodesic losses as device scalars -- no .item(), no host sync.  fp32 GPU poses take the fused
+    kernel (ops.GeodesicLossFn: same formulas, one launch, exact derivatives); anything else the PyTorch formulation below."""
+    g = Gs[0].data
+    if g.is_cuda and g.dtype == torch.float32 and g.dim() == 3 and Ps.data.dtype == torch.float32:
+        from . import ops
+        return ops.GeodesicLossFn.apply(Ps.data, g)
+    return geodesic_loss_tensors_torch(Ps, Gs)
+
+
+def geodesic_loss_tensors_torch(Ps, Gs):
+    """reference formulation on rel_pose_amd.se3.SE3 (any device / dtype; autograd supplies the gradient)"""
     dP = _pair_swap(Ps) * Ps.inv()
     dG = _pair_swap(Gs[0]) * Gs[0].inv()
     tau, phi = (dG * dP.inv()).log().split([3, 3], dim=-1)

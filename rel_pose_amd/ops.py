@@ -783,3 +783,26 @@ def bn_act(bn, x, residual=None, relu=True):
         bn.num_batches_tracked += 1
     return BnActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, bn.training, bn.momentum, bn.eps,
                          relu)
+
+
+class GeodesicLossFn(torch.autograd.Function):
+    """(mean |tau|, mean |phi|) of the geodesic pose loss as one kernel with exact derivatives (csrc/se3loss.hip): the
+    PyTorch formulation costs ~240 tiny launches per step.  Ps, Gs: [B,2,7] fp32 on the GPU."""
+
+    @staticmethod
+    def forward(ctx, Ps, Gs):
+        lib = _lib.load()
+        Ps, Gs = Ps.contiguous(), Gs.contiguous()
+        _chk(Ps, Gs)
+        B = Gs.shape[0]
+        losses = _empty(2, like=Gs)
+        dmean = _empty(2, B, 2, 7, like=Gs)
+        scratch = _empty(60 * B, like=Gs)
+        _lib.check(lib.rp_geodesic_loss(_p(Ps), _p(Gs), _p(losses), _p(dmean), _p(scratch), B, _st()), "rp_geodesic_loss")
+        ctx.save_for_backward(dmean)
+        return losses[0], losses[1]
+
+    @staticmethod
+    def backward(ctx, gtr, grot):
+        (dmean,) = ctx.saved_tensors
+        return None, gtr * dmean[0] + grot * dmean[1]

@@ -87,3 +87,44 @@ def test_overfits_a_fixed_batch():
         losses.append(float(loss.detach()))
     assert all(l == l for l in losses), "NaN in the loss"
     assert min(losses[-10:]) < 0.35 * losses[0], (losses[0], losses[-10:])
+
+
+def _fake_matterport(root, n=6):
+    import json
+    import numpy as np
+    from PIL import Image
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(0)
+    data = []
+    for i in range(n):
+        names = []
+        for k in range(2):
+            rel = "rgb/h%d/i_%d_%d.png" % (i, i, k)
+            os.makedirs(os.path.dirname(os.path.join(root, rel)), exist_ok=True)
+            Image.fromarray(rng.integers(0, 256, (120, 160, 3), dtype=np.uint8)).save(os.path.join(root, rel))
+            names.append("/a/b/c/d/e/" + rel)
+        q = Rotation.from_euler("xyz", [5 * i, -10, 3], degrees=True).as_quat()
+        data.append({"0": {"file_name": names[0]}, "1": {"file_name": names[1]},
+                     "rel_pose": {"position": [0.5 * i, -1.0, 0.25], "rotation": [float(q[3]), float(q[0]), float(q[1]), float(q[2])]}})
+    os.makedirs(os.path.join(root, "mp3d_planercnn_json"), exist_ok=True)
+    for split in ("train", "val", "test"):
+        with open(os.path.join(root, "mp3d_planercnn_json", "cached_set_%s.json" % split), "w") as f:
+            json.dump({"data": data}, f)
+
+
+def test_train_and_evaluate_on_a_fake_matterport_dataset(tmp_path):
+    """train.py --dataset matterport through rel_pose_amd/data_readers (PIL decode, colour jitter, resize, DataLoader workers),
+    then test_matterport.py on the checkpoint it wrote: the reference's two entry points around the dataset layout."""
+    root = str(tmp_path / "matterport_fake")
+    _fake_matterport(root)
+    r = run([os.path.join(ROOT, "train.py"), "--name", "m0", "--batch", "2", "--steps", "4", "--warmup", "2", "--fusion_transformer",
+             "--dataset", "matterport", "--datapath", root, "--image_size", "192", "256", "--num_workers", "2"], str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "finished training!" in r.stdout
+    ck = tmp_path / "output" / "m0" / "checkpoints" / "000004.pth"
+    assert ck.exists()
+    r = run([os.path.join(ROOT, "test_matterport.py"), "--datapath", root, "--exp", "e0", "--ckpt", str(ck), "--fusion_transformer"],
+            str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = (tmp_path / "output" / "e0" / "matterport_test" / "results.txt").read_text()
+    assert "R mean err" in res and "top1 T err < 1.0" in res

@@ -159,3 +159,23 @@ def test_identity_like_and_indexing():
     I = SE3.IdentityLike(P)
     assert I.data.shape == (4, 2, 7) and torch.equal(I.data[..., 6], torch.ones(4, 2)) and float(I.data[..., :6].abs().sum()) == 0
     assert I[:, :1].data.shape == (4, 1, 7) and I[0][1].data.shape == (7,)
+
+
+def test_miopen_user_db_is_private_per_rank(tmp_path, monkeypatch):
+    """rel_pose_amd/_env.py: the shipped MIOpen find-db is copied to a per-rank directory and selected through
+    MIOPEN_USER_DB_PATH; a value set by the user wins."""
+    import importlib
+    import rel_pose_amd._env as env
+    monkeypatch.setenv("TMPDIR", str(tmp_path))
+    import tempfile
+    tempfile.tempdir = None
+    monkeypatch.delenv("MIOPEN_USER_DB_PATH", raising=False)
+    monkeypatch.setenv("LOCAL_RANK", "3")
+    importlib.reload(env)
+    p = os.environ["MIOPEN_USER_DB_PATH"]
+    assert p.startswith(str(tmp_path)) and p.endswith("_3")
+    assert sorted(os.listdir(p)) == sorted(f for f in os.listdir(env.MIOPEN_DB) if f.endswith(".txt")) and len(os.listdir(p)) == 3
+    monkeypatch.setenv("MIOPEN_USER_DB_PATH", "/somewhere/else")
+    importlib.reload(env)
+    assert os.environ["MIOPEN_USER_DB_PATH"] == "/somewhere/else"
+    tempfile.tempdir = None

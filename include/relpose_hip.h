@@ -100,6 +100,12 @@ int rp_bn_bwd(const float* dy, const float* y, const float* x, const float* mean
               const float* beta, float* dx, float* dres, float* dgamma, float* dbeta, double* partial, float* c12, long long R, int C, int relu,
               int training, void* stream);
 
+/* 3x3 / stride 2 / pad 1 max-pool (torchvision resnet.maxpool as driven by src/model.py:130), channels-last:
+ * x [N,H,W,C] -> y [N,OH,OW,C], OH = (H-1)/2+1; idx (bytes, same shape as y) = window position 0..8 of the first maximum in scan
+ * order (PyTorch's tie rule); backward gathers dy through idx into dx [N,H,W,C] (no atomics). */
+int rp_maxpool3x3s2_fwd(const float* x, float* y, unsigned char* idx, int N, int H, int W, int C, void* stream);
+int rp_maxpool3x3s2_bwd(const float* dy, const unsigned char* idx, float* dx, int N, int H, int W, int C, void* stream);
+
 /* Geodesic pose loss of the training step (reference src/geom/losses.py:3-21; SE(3) arithmetic as restated in
  * rel_pose_amd/se3.py since lietorch is not vendored): Ps, Gs [B,2,7] (t, q xyzw);
  *   losses[0] = mean_{b,j} |tau|, losses[1] = mean_{b,j} |phi| of log(dG_j dP_j^-1), dG_j = G[1-j] G[j]^-1, dP_j likewise;

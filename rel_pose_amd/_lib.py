@@ -31,6 +31,8 @@ _SIGS = {
     "rp_target_arch": (c_char_p, []),
     "rp_gemm": (c_int, [POINTER(RpGemm), P]),
     "rp_gemm_workspace_bytes": (c_size_t, [I, I, I]),
+    "rp_maxpool3x3s2_fwd": (c_int, [P, P, P, I, I, I, I, P]),
+    "rp_maxpool3x3s2_bwd": (c_int, [P, P, P, I, I, I, I, P]),
     "rp_geodesic_loss": (c_int, [P, P, P, P, P, I, P]),
     "rp_bn_partial_blocks": (c_int, [L]),
     "rp_bn_stats": (c_int, [P, L, I, P, P, P, P, P, F, F, P]),

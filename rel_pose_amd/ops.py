@@ -806,3 +806,44 @@ class GeodesicLossFn(torch.autograd.Function):
     def backward(ctx, gtr, grot):
         (dmean,) = ctx.saved_tensors
         return None, gtr * dmean[0] + grot * dmean[1]
+
+
+class MaxPool3x3s2Fn(torch.autograd.Function):
+    """nn.MaxPool2d(3, 2, 1) on a channels-last tensor (the stem's pool, src/model.py:130): streaming forward that keeps a
+    one-byte window position per output, gather backward (csrc/batchnorm.hip)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        N, C, H, W = x.shape
+        xr = x.permute(0, 2, 3, 1)
+        if not xr.is_contiguous():
+            xr = xr.contiguous()
+        _chk(xr)
+        OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = torch.empty(N, OH, OW, C, device=x.device, dtype=torch.float32)
+        idx = torch.empty(N, OH, OW, C, device=x.device, dtype=torch.uint8)
+        _lib.check(lib.rp_maxpool3x3s2_fwd(_p(xr), _p(y), ctypes.c_void_p(idx.data_ptr()), N, H, W, C, _st()), "rp_maxpool3x3s2_fwd")
+        ctx.save_for_backward(idx)
+        ctx.shape = (N, C, H, W)
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        (idx,) = ctx.saved_tensors
+        N, C, H, W = ctx.shape
+        dyr = dy.permute(0, 2, 3, 1)
+        if not dyr.is_contiguous():
+            dyr = dyr.contiguous()
+        _chk(dyr)
+        dx = torch.empty(N, H, W, C, device=dy.device, dtype=torch.float32)
+        _lib.check(lib.rp_maxpool3x3s2_bwd(_p(dyr), ctypes.c_void_p(idx.data_ptr()), _p(dx), N, H, W, C, _st()), "rp_maxpool3x3s2_bwd")
+        return dx.permute(0, 3, 1, 2)
+
+
+def maxpool3x3s2(pool, x):
+    """the stem's nn.MaxPool2d(3, 2, 1): HIP kernels on the GPU, the module itself on CPU tensors (fixture generation only)"""
+    if not x.is_cuda:
+        return pool(x)
+    return MaxPool3x3s2Fn.apply(x)

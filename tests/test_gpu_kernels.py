@@ -418,3 +418,21 @@ def test_fused_geodesic_loss_matches_se3_autograd(ops):
     report("geodesic_loss", **e)
     assert torch.isfinite(Gg.grad).all() and float(Gg.grad[0].abs().max()) < 17.0 / (2 * B) * 4
     assert e["tr"] < 2e-6 and e["rot"] < 2e-6 and e["grad"] < 2e-5
+
+
+@pytest.mark.parametrize("shape", [(3, 64, 20, 28), (2, 8, 7, 9), (1, 4, 1, 2)])
+def test_maxpool3x3s2_matches_torch_including_ties(ops, shape):
+    """values, and gradient routing with many exact ties (post-ReLU zeros), bit-identical to torch.nn.MaxPool2d(3, 2, 1)"""
+    N, C, H, W = shape
+    g = torch.Generator(device="cpu").manual_seed(H * W)
+    x = torch.relu(torch.randn(N, C, H, W, generator=g)).round(decimals=1)         # zeros and repeated values
+    pool = torch.nn.MaxPool2d(3, 2, 1)
+    xr = x.clone().requires_grad_(True)
+    yr = pool(xr)
+    cot = torch.randn(yr.shape, generator=g)
+    (yr * cot).sum().backward()
+    xg = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = ops.maxpool3x3s2(pool, xg)
+    (y * cot.cuda()).sum().backward()
+    assert y.shape == yr.shape and torch.equal(y.cpu(), yr)
+    assert torch.equal(xg.grad.cpu(), xr.grad)

@@ -48,14 +48,18 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
   if (rl < nrl) {
     float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), rs = mu, ga = mu, be = mu;
     if (MODE == 1) { mu = ld4(mean + 4 * cg); rs = ld4(rstd + 4 * cg); }
+    // MODE 0 sums (x - pivot) and (x - pivot)^2 with pivot = row 0 of the tensor: E[d^2] - E[d]^2 then has no cancellation
+    // even when |mean| >> std (d is O(std) whenever the data are concentrated anywhere)
+    const float4 pv = MODE == 0 ? ld4(x + 4 * cg) : make_float4(0.f, 0.f, 0.f, 0.f);
     const bool remask = MODE == 1 && relu && y == nullptr;       // ReLU mask rebuilt from x (no residual was added)
     if (remask) { ga = ld4(gamma + 4 * cg); be = ld4(beta + 4 * cg); }
     float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa;
     int cnt = 0;
     auto acc1 = [&](const float4 xv, float4 g, const float4 yv) {
       if (MODE == 0) {
-        sa.x += xv.x; sa.y += xv.y; sa.z += xv.z; sa.w += xv.w;
-        sb.x += xv.x * xv.x; sb.y += xv.y * xv.y; sb.z += xv.z * xv.z; sb.w += xv.w * xv.w;
+        const float dx_ = xv.x - pv.x, dy_ = xv.y - pv.y, dz_ = xv.z - pv.z, dw_ = xv.w - pv.w;
+        sa.x += dx_; sa.y += dy_; sa.z += dz_; sa.w += dw_;
+        sb.x += dx_ * dx_; sb.y += dy_ * dy_; sb.z += dz_ * dz_; sb.w += dw_ * dw_;
       } else {
         sa.x += g.x; sa.y += g.y; sa.z += g.z; sa.w += g.w;
         sb.x += g.x * (xv.x - mu.x) * rs.x; sb.y += g.y * (xv.y - mu.y) * rs.y;
@@ -128,7 +132,8 @@ template <int MODE>
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ partial, int nblk, int C, long long R,
                                                           float* __restrict__ o0, float* __restrict__ o1,
                                                           float* __restrict__ run_mean, float* __restrict__ run_var,
-                                                          float momentum, float eps, float* __restrict__ c12) {
+                                                          float momentum, float eps, float* __restrict__ c12,
+                                                          const float* __restrict__ pivot) {
   __shared__ double red[2][16][16];
   const int cl = threadIdx.x & 15, lane = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl;
@@ -155,9 +160,10 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
   if (lane != 0 || c >= C) return;
   for (int l = 1; l < 16; ++l) { a += red[0][l][cl]; b += red[1][l][cl]; }
   if (MODE == 0) {
-    const double m = a / (double)R;
-    double var = b / (double)R - m * m;
+    const double md = a / (double)R;                 // mean of (x - pivot)
+    double var = b / (double)R - md * md;
     if (var < 0.0) var = 0.0;
+    const double m = md + (double)pivot[c];
     o0[c] = (float)m;
     o1[c] = (float)(1.0 / sqrt(var + (double)eps));
     if (run_mean) {
@@ -254,7 +260,7 @@ extern "C" int rp_bn_stats(const float* x, long long R, int C, double* partial, 
                      nullptr, partial, R, C, rpb, 0);
   RP_CHECK_LAUNCH();
   hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3((C + 15) / 16), dim3(256), 0, st, (const double*)partial, nblk, C, R, mean,
-                     rstd, running_mean, running_var, momentum, eps, nullptr);
+                     rstd, running_mean, running_var, momentum, eps, nullptr, x);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }
@@ -280,7 +286,7 @@ extern "C" int rp_bn_bwd(const float* dy, const float* y, const float* x, const 
                      relu);
   RP_CHECK_LAUNCH();
   hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3((C + 15) / 16), dim3(256), 0, st, (const double*)partial, nblk, C, R, dbeta,
-                     dgamma, nullptr, nullptr, 0.f, 0.f, c12);
+                     dgamma, nullptr, nullptr, 0.f, 0.f, c12, nullptr);
   RP_CHECK_LAUNCH();
   const long long n4 = R * C / 4;
   hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(apply_grid(n4)), dim3(256), 0, st, dy, y, (const float*)dres, x, mean, rstd, gamma,

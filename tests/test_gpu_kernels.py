@@ -436,3 +436,17 @@ def test_maxpool3x3s2_matches_torch_including_ties(ops, shape):
     (y * cot.cuda()).sum().backward()
     assert y.shape == yr.shape and torch.equal(y.cpu(), yr)
     assert torch.equal(xg.grad.cpu(), xr.grad)
+
+
+def test_fused_batchnorm_statistics_are_cancellation_safe(ops):
+    """|mean| >> std (1000 vs 0.01): the column statistics are accumulated about a pivot row, so E[d^2] - E[d]^2 keeps the
+    variance; a plain fp32 E[x^2] - mean^2 would return noise here"""
+    g = torch.Generator(device="cpu").manual_seed(9)
+    x = (1000.0 + 0.01 * torch.randn(16, 64, 24, 24, generator=g))
+    bn = torch.nn.BatchNorm2d(64).cuda().train()
+    y = ops.bn_act(bn, x.cuda().contiguous(memory_format=torch.channels_last), relu=False)
+    xd = x.double()
+    ref = (xd - xd.mean((0, 2, 3), keepdim=True)) / torch.sqrt(xd.var((0, 2, 3), unbiased=False, keepdim=True) + 1e-5)
+    # x itself only carries ~6e-5 of absolute resolution at 1000, i.e. ~6e-3 of a 0.01 standard deviation
+    assert float((y.cpu().double() - ref).abs().max()) < 2e-2
+    assert rel(bn.running_var, 0.9 + 0.1 * xd.var((0, 2, 3), unbiased=True)) < 1e-6

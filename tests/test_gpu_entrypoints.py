@@ -128,3 +128,18 @@ def test_train_and_evaluate_on_a_fake_matterport_dataset(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     res = (tmp_path / "output" / "e0" / "matterport_test" / "results.txt").read_text()
     assert "R mean err" in res and "top1 T err < 1.0" in res
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py's N>1 path (one process per rank, DDP gradient all-reduce, barrier + max-over-ranks timing) launched exactly as
+    the driver launches it, but with both ranks sharing cuda:0 over gloo (RP_BENCH_SHARE_GPU: a 1-GPU box cannot run RCCL)."""
+    import json
+    env = dict(os.environ, PYTHONPATH=ROOT, RP_BENCH_SHARE_GPU="1", RP_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "8"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch_pairs"] == 16 and rec["config"]["finite"] and rec["scaling"] == "weak"
+    assert "cpu_baseline" not in rec and rec["roofline"]["launches_timed"] > 0

@@ -117,8 +117,10 @@ int rp_geodesic_loss(const float* Ps, const float* Gs, float* losses, float* dme
  * vision_transformer.py:396).  Saves mean / rstd per row for the backward. */
 int rp_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                      int rows, int C, float eps, void* stream);
-/* dx = LN'(dy) (+ add if non-null); partial sums are written to dgamma_part as [nblk][2][C] (dgamma row, dbeta row per
- * block; dbeta_part is ignored), nblk = rp_layernorm_bwd_blocks(rows) <= 2048: one rp_colsum over [nblk, 2C] finishes both */
+/* dx = LN'(dy) (+ add if non-null); partial sums are written to dgamma_part as [nblk][np][C], np = 2 (dgamma row, dbeta row
+ * per block) or, when add != NULL, np = 3 with a third row = column sums of `add` (the bias gradient of the Linear whose
+ * output gradient `add` is -- read here anyway); dbeta_part is ignored.  nblk = rp_layernorm_bwd_blocks(rows) <= 2048: one
+ * rp_colsum over [nblk, np*C] finishes all of them */
 int rp_layernorm_bwd_blocks(int rows);
 int rp_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                      const float* add, float* dx, float* dgamma_part, float* dbeta_part, int rows, int C, void* stream);

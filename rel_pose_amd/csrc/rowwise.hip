@@ -58,14 +58,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      float* __restrict__ dx, float* __restrict__ dgp,
                                                      float* __restrict__ dbp, int rows) {
   constexpr int C = 64 * J;
-  __shared__ float red[2][4][C];
+  __shared__ float red[3][4][C];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float g[J], dg[J], db[J];
+  float g[J], dg[J], db[J], da[J];
 #pragma unroll
   for (int j = 0; j < J; ++j) {
     g[j] = gamma[lane + 64 * j];
     dg[j] = 0.f;
     db[j] = 0.f;
+    da[j] = 0.f;
   }
   for (int chunk = blockIdx.x; chunk * LNB_ROWS < rows; chunk += gridDim.x) {
   const int r0 = chunk * LNB_ROWS + wave * (LNB_ROWS / 4);
@@ -91,7 +92,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     for (int j = 0; j < J; ++j) {
       const long long o = (long long)row * C + lane + 64 * j;
       float v = rs * (dxh[j] - c1 - xh[j] * c2);
-      if (add) v += add[o];
+      if (add) {
+        const float a = add[o];
+        da[j] += a;          // column sum of the residual-branch gradient = bias gradient of the Linear that produced it
+        v += a;
+      }
       dx[o] = v;
     }
   }
@@ -100,12 +105,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   for (int j = 0; j < J; ++j) {
     red[0][wave][lane + 64 * j] = dg[j];
     red[1][wave][lane + 64 * j] = db[j];
+    red[2][wave][lane + 64 * j] = da[j];
   }
   __syncthreads();
+  const int np = add ? 3 : 2;
   for (int c = threadIdx.x; c < C; c += 256) {
-    // partials interleaved as [block][2][C] so ONE column-sum launch finishes both dgamma and dbeta
-    dgp[(long long)blockIdx.x * 2 * C + c] = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
-    dgp[(long long)blockIdx.x * 2 * C + C + c] = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+    // partials interleaved as [block][np][C] so ONE column-sum launch finishes dgamma, dbeta (and the column sums of `add`)
+    float* p = dgp + (long long)blockIdx.x * np * C;
+    p[c] = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+    p[C + c] = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+    if (add) p[2 * C + c] = red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c];
   }
 }
 

@@ -263,17 +263,20 @@ def layernorm_fwd(x2d, gamma, beta, eps=LN_EPS, want_stats=True):
 
 
 def layernorm_bwd(dy, x2d, gamma, mean, rstd, add=None):
-    """returns dx (+add), dgamma, dbeta"""
+    """returns dx (+add), dgamma, dbeta [, column sums of add]"""
     lib = _lib.load()
     _chk(dy, x2d, gamma, mean, rstd, add)
     rows, C = x2d.shape
     nblk = lib.rp_layernorm_bwd_blocks(rows)
+    np_ = 3 if add is not None else 2
     dx = torch.empty_like(x2d)
-    part = _empty(nblk, 2 * C, like=x2d)
+    part = _empty(nblk, np_ * C, like=x2d)
     _lib.check(lib.rp_layernorm_bwd(_p(dy), _p(x2d), _p(gamma), _p(mean), _p(rstd), _p(add), _p(dx), _p(part),
                                     None, rows, C, _st()), "rp_layernorm_bwd")
-    dgb = colsum(part)                                  # one launch: [dgamma | dbeta]
-    return dx, dgb[:C], dgb[C:]
+    sums = colsum(part)                                 # one launch: [dgamma | dbeta (| colsum(add))]
+    if add is None:
+        return dx, sums[:C], sums[C:]
+    return dx, sums[:C], sums[C:2 * C], sums[2 * C:]
 
 
 def attn_fwd(qkv, Z, stats_only=False, q_off=0, k_off=DIM, v_off=2 * DIM, q_xor=0, k_xor=0):
@@ -504,9 +507,12 @@ def _param_grads(fork, dy, x):
     return fork.on_side(lambda: linear_dw_db(dy, x))
 
 
-def _mlp_bwd(fork, dy, xn, h, hpre, w1, w2):
+def _mlp_bwd(fork, dy, xn, h, hpre, w1, w2, want_db2=True):
     fork.sync_side()
-    dw2, db2 = _param_grads(fork, dy, h)
+    if want_db2:
+        dw2, db2 = _param_grads(fork, dy, h)
+    else:                     # the caller gets colsum(dy) for free from the LayerNorm backward that adds dy
+        dw2, db2 = fork.on_side(lambda: linear_dw(dy, h)), None
     dh = linear_dx(dy, w2, dact=1, aux=hpre)          # grad wrt fc1 pre-activation (GELU' fused)
     fork.sync_side()
     dw1, db1 = _param_grads(fork, dh, xn)
@@ -545,17 +551,19 @@ class BlockFn(torch.autograd.Function):
         Z = ctx.Z
         dy = dy.contiguous().view(Z * N_TOK, DIM)
         fork = _Fork(dy.device)
-        dxn2, dfc1w, dfc1b, dfc2w, dfc2b = _mlp_bwd(fork, dy, xn2, h, hpre, fc1_w, fc2_w)
-        dx1, dn2w, dn2b = layernorm_bwd(dxn2, x1, n2w, m2, r2, add=dy)
+        # the two LayerNorm backwards read dy / dx1 as their residual-branch operand anyway: they also return its column
+        # sums, which ARE the fc2 / proj bias gradients (two 57 MB column-sum passes per block saved)
+        dxn2, dfc1w, dfc1b, dfc2w, _ = _mlp_bwd(fork, dy, xn2, h, hpre, fc1_w, fc2_w, want_db2=False)
+        dx1, dn2w, dn2b, dfc2b = layernorm_bwd(dxn2, x1, n2w, m2, r2, add=dy)
         fork.sync_side()
-        dprojw, dprojb = _param_grads(fork, dx1, o)
+        dprojw = fork.on_side(lambda: linear_dw(dx1, o))
         do = linear_dx(dx1, proj_w)
         dqkv = attn_bwd(qkv, o, lse, do, Z, fork, kv_xor=1 if ctx.cross else 0)
         fork.sync_main()                                  # dQ pass (side) done before dqkv is consumed
         fork.sync_side()
         dqkvw, dqkvb = _param_grads(fork, dqkv, xn1)
         dxn1 = linear_dx(dqkv, qkv_w)
-        dx, dn1w, dn1b = layernorm_bwd(dxn1, x2, n1w, m1, r1, add=dx1)
+        dx, dn1w, dn1b, dprojb = layernorm_bwd(dxn1, x2, n1w, m1, r1, add=dx1)
         fork.sync_main()
         return (dx.view(Z, N_TOK, DIM), dn1w, dn1b, dqkvw, dqkvb, dprojw, dprojb, dn2w, dn2b, dfc1w, dfc1b, dfc2w,
                 dfc2b, None)
@@ -597,8 +605,8 @@ class CrossBlockFn(torch.autograd.Function):
         Z = ctx.Z
         dy = dy.contiguous().view(Z * 70, DIM)
         fork = _Fork(dy.device)
-        dfn, dfc1w, dfc1b, dfc2w, dfc2b = _mlp_bwd(fork, dy, fn, h, hpre, fc1_w, fc2_w)
-        df_, dn2w, dn2b = layernorm_bwd(dfn, f, n2w, m2, r2, add=dy)
+        dfn, dfc1w, dfc1b, dfc2w, _ = _mlp_bwd(fork, dy, fn, h, hpre, fc1_w, fc2_w, want_db2=False)
+        df_, dn2w, dn2b, dfc2b = layernorm_bwd(dfn, f, n2w, m2, r2, add=dy)       # 4th: colsum(dy) = fc2 bias gradient
         fork.sync_side()
         dpfw_full, dpfb = _param_grads(fork, df_, g)
         dg = linear_dx(df_, pf_wp)                                      # [Z*70, 224]

@@ -162,10 +162,12 @@ def test_layernorm_fwd_bwd(ops):
     y64 = torch.nn.functional.layer_norm(x64, (C,), g64, b64, 1e-6)
     assert rel(y, y64) < 2e-6
     (y64 * dy.double()).sum().backward()
-    dx, dg, db = ops.layernorm_bwd(dy, x, g, mean, rstd, add=add)
-    e = max(rel(dx, x64.grad + add.double()), rel(dg, g64.grad), rel(db, b64.grad))
+    dx, dg, db, asum = ops.layernorm_bwd(dy, x, g, mean, rstd, add=add)
+    e = max(rel(dx, x64.grad + add.double()), rel(dg, g64.grad), rel(db, b64.grad), rel(asum, add.double().sum(0)))
     report("layernorm", rel=e)
     assert e < 5e-6
+    dx0, dg0, db0 = ops.layernorm_bwd(dy, x, g, mean, rstd)          # without a residual-branch operand: 3 results
+    assert rel(dx0, x64.grad) < 5e-6 and torch.equal(dg0, dg) and torch.equal(db0, db)
 
 
 def test_colsum_tokens_posenc_pose(ops, golden):

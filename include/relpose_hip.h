@@ -73,7 +73,11 @@ typedef struct RpGemm {
                   *   0  exact fp32 MFMA (v_mfma_f32_32x32x2_f32)
                   *   3  split-bf16, 3 limbs per operand, the 6 limb products >= 2^-16 on v_mfma_f32_32x32x16_bf16:
                   *      fp32-grade result (dropped terms <= 2^-24 relative) at 16/6 the matrix-pipe rate
-                  *   1  operands truncated to bf16 (the bf16 configuration, BASELINE.json configs[4]) */
+                  *   1  operands rounded to bf16 (the bf16 configuration, BASELINE.json configs[4]) */
+  float* colsum_part; /* optional: [2*ceil(M/(64*TM))][N] floats; row (2*mt + wave row) receives the column sums of the FINAL
+                       * values that tile stored over its 32*TM rows -- one small rp_colsum over it yields sum_m C[m][n] (the bias
+                       * gradient when C is a pre-activation gradient) without re-reading C.  split_k = batch = 1, N % 4 == 0,
+                       * not the [K,M]x[K,N] layout, and the tile must be TN <= 2 (true whenever aux / residual is given). */
 } RpGemm;
 int rp_gemm(const RpGemm* g, void* stream);
 size_t rp_gemm_workspace_bytes(int M, int N, int split_k);

@@ -37,6 +37,7 @@ struct GemmP {
   int epi_mode;
   int trans_c;
   int limbs;
+  float* colsum_part;
 };
 
 RP_DEV float epilogue(float v, int m, int n, const GemmP& p) {
@@ -383,6 +384,8 @@ __global__ __launch_bounds__(256, NL > 0 ? 2 : 1) void gemm_kernel(GemmP p) {
         for (int r = 0; r < 16; ++r) cs[(32 * i + acc_row(r, hi)) * CST + 32 * j + l31] = acc[i][j][r];
     __syncthreads();
     constexpr int C4 = 8 * TN;             // float4 per staged row
+    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);   // this lane's column sums of the final values (colsum_part != nullptr)
+    const bool want_cs = (64 % C4) == 0 && p.colsum_part != nullptr && !partial;
 #pragma unroll
     for (int it = 0; it < (32 * TM * C4) / 64; ++it) {
       const int idx = lane + 64 * it;
@@ -413,7 +416,19 @@ __global__ __launch_bounds__(256, NL > 0 ? 2 : 1) void gemm_kernel(GemmP p) {
           v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
         }
         st4(C + off, v);
+        if (want_cs) { csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w; }
       }
+    }
+    if (want_cs) {
+      // a lane keeps the same column group c4 = lane % C4 through the loop: fold the 64 / C4 lanes of each group, then lanes
+      // 0..C4-1 store one row of per-(tile, wave-row) column sums; a small rp_colsum over them finishes the bias gradient
+#pragma unroll
+      for (int o = 32; o >= C4; o >>= 1) {
+        csum.x += __shfl_xor(csum.x, o, 64); csum.y += __shfl_xor(csum.y, o, 64);
+        csum.z += __shfl_xor(csum.z, o, 64); csum.w += __shfl_xor(csum.w, o, 64);
+      }
+      const int n = n0 + wn0 + 4 * lane;
+      if (lane < C4 && n < p.N) st4(p.colsum_part + (long long)(2 * mt + (wave >> 1)) * p.N + n, csum);
     }
   } else {
 #define RP_EPI_LOOP(BODY)                                                              \
@@ -533,6 +548,8 @@ extern "C" int rp_gemm(const RpGemm* g, void* stream) {
   }
   p.trans_c = g->trans_c;
   p.limbs = g->precision;
+  p.colsum_part = g->colsum_part;
+  if (g->colsum_part && (split > 1 || batch > 1 || (g->N & 3) || (g->a_layout == 1 && g->b_layout == 1))) return RP_EUNSUPPORTED;
   if (p.limbs != 0 && p.limbs != 1 && p.limbs != 3) return RP_EUNSUPPORTED;
   if (g->trans_c && (split == 1 || g->bias || g->pre_out || g->aux || g->residual)) return RP_EUNSUPPORTED;
   // tile shape (TM,TN) = wave tile in 32x32 units; measured on MI355X (tools/gemm_tiles.py): with fp32 MFMA (64
@@ -556,6 +573,7 @@ extern "C" int rp_gemm(const RpGemm* g, void* stream) {
   if (const char* ov = getenv("RP_GEMM_TILE")) {   // tuning aid only: "TM,TN"
     if (ov[0] >= '1' && ov[0] <= '2' && ov[1] == ',' && ov[2] >= '1' && ov[2] <= '3') { tm = ov[0] - '0'; tn = ov[2] - '0'; }
   }
+  if (p.colsum_part && (tn == 3 || p.epi_mode == EPI_GENERIC)) return RP_EUNSUPPORTED;   // needs the staged epilogue, 64 % (8 TN) == 0
   hipStream_t st = (hipStream_t)stream;
   const int nz = batch * split;
   if (p.limbs == 3) launch_layouts<3>(p, nz, g->a_layout, g->b_layout, tm, tn, st);

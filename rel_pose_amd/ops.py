@@ -162,7 +162,7 @@ def gemm_instance(M, N, a_layout, b_layout, reads_mn=False):
 
 def gemm(A, B, M, N, K, *, a_layout=0, b_layout=0, lda=None, ldb=None, out=None, ldc=None, bias=None, act=0,
          pre_out=None, dact=0, aux=None, residual=None, split_k=None, batch=1, strides=(0, 0, 0), trans_c=False,
-         precision=None):
+         precision=None, want_colsum=False):
     """C[M,N] = epilogue(op(A) op(B)); see RpGemm in include/relpose_hip.h."""
     lib = _lib.load()
     _chk(A, B, out, bias, pre_out, aux, residual)
@@ -195,6 +195,13 @@ def gemm(A, B, M, N, K, *, a_layout=0, b_layout=0, lda=None, ldb=None, out=None,
     g.residual = None if residual is None else residual.data_ptr()
     g.trans_c = 1 if trans_c else 0
     g.precision = GEMM_PRECISION if precision is None else precision
+    cpart = None
+    if want_colsum:      # column sums of the stored values, folded into the epilogue (see RpGemm.colsum_part)
+        tm_, tn_ = gemm_tile(M, N, a_layout, b_layout, aux is not None or residual is not None, g.precision)
+        if tn_ > 2 or split_k != 1 or batch != 1:
+            raise RuntimeError("want_colsum needs a TN <= 2 tile without split-K (pass aux/residual GEMMs)")
+        cpart = _empty(2 * (-(-M // (64 * tm_))), N, like=A)
+        g.colsum_part = cpart.data_ptr()
     tm = TIMER
     if (tm is not None and tm.enabled and split_k == 1 and
             gemm_instance(M, N, a_layout, b_layout, aux is not None or residual is not None) == tm.instance):
@@ -205,9 +212,9 @@ def gemm(A, B, M, N, K, *, a_layout=0, b_layout=0, lda=None, ldb=None, out=None,
         tm.events.append((e0, e1))
         tm.flops += 2.0 * M * N * K * batch
         tm.bytes += 4.0 * batch * (M * K + N * K + M * N * (1 + (aux is not None) + (residual is not None) + (pre_out is not None)))
-        return out
+        return (out, colsum(cpart)) if want_colsum else out
     _lib.check(lib.rp_gemm(ctypes.byref(g), _st()), "rp_gemm")
-    return out
+    return (out, colsum(cpart)) if want_colsum else out
 
 
 def linear(x, W, b=None, act=0, want_pre=False, residual=None):
@@ -219,11 +226,12 @@ def linear(x, W, b=None, act=0, want_pre=False, residual=None):
     return (y, pre) if want_pre else y
 
 
-def linear_dx(dy, W, dact=0, aux=None):
-    """dx = (dy W) o act'(aux); dy [M,N], W [N,K] -> [M,K]."""
+def linear_dx(dy, W, dact=0, aux=None, want_colsum=False):
+    """dx = (dy W) o act'(aux); dy [M,N], W [N,K] -> [M,K].  want_colsum: also sum_m dx[m][:] (the bias gradient of the
+    layer below when dx is its pre-activation gradient), from the epilogue."""
     M, N = dy.shape
     K = W.shape[1]
-    return gemm(dy, W, M, K, N, b_layout=1, dact=dact, aux=aux)
+    return gemm(dy, W, M, K, N, b_layout=1, dact=dact, aux=aux, want_colsum=want_colsum)
 
 
 def linear_dw(dy, x):
@@ -513,9 +521,10 @@ def _mlp_bwd(fork, dy, xn, h, hpre, w1, w2, want_db2=True):
         dw2, db2 = _param_grads(fork, dy, h)
     else:                     # the caller gets colsum(dy) for free from the LayerNorm backward that adds dy
         dw2, db2 = fork.on_side(lambda: linear_dw(dy, h)), None
-    dh = linear_dx(dy, w2, dact=1, aux=hpre)          # grad wrt fc1 pre-activation (GELU' fused)
+    # grad wrt fc1 pre-activation (GELU' fused) and, from the same epilogue, its column sums = the fc1 bias gradient
+    dh, db1 = linear_dx(dy, w2, dact=1, aux=hpre, want_colsum=True)
     fork.sync_side()
-    dw1, db1 = _param_grads(fork, dh, xn)
+    dw1 = fork.on_side(lambda: linear_dw(dh, xn))
     dxn = linear_dx(dh, w1)
     return dxn, dw1, db1, dw2, db2
 

@@ -144,6 +144,25 @@ def test_gemm_epilogues_splitk_batch(ops):
     assert e < 5e-6
 
 
+@pytest.mark.parametrize("prec", [0, 3])
+def test_gemm_epilogue_column_sums(ops, prec):
+    """RpGemm.colsum_part: sum_m C[m][n] of the stored (post-epilogue) values from the epilogue itself -- ragged M and N tiles,
+    GELU' epilogue (the fc1 bias gradient) and plain bias epilogue"""
+    M, N, K = 1000, 200, 192
+    dy, W, aux, b = rnd(M, K, seed=31), rnd(K, N, seed=32, scale=0.1), rnd(M, N, seed=33), rnd(N, seed=34)
+    out, cs = ops.gemm(dy, W, M, N, K, b_layout=1, dact=1, aux=aux, want_colsum=True, precision=prec, split_k=1)
+    x = aux.double()
+    ggrad = 0.5 * (1 + torch.erf(x / 2 ** 0.5)) + x * torch.exp(-0.5 * x * x) / (2 * torch.pi) ** 0.5
+    ref = (dy.double() @ W.double()) * ggrad
+    assert rel(out, ref) < 5e-6 and rel(cs, ref.sum(0)) < 5e-6
+    assert rel(cs, out.double().sum(0)) < 2e-6                 # sums of exactly the values that were stored
+    Wt = rnd(N, K, seed=35, scale=0.1)
+    out2, cs2 = ops.gemm(dy, Wt, M, N, K, bias=b, want_colsum=True, precision=prec, split_k=1)
+    assert rel(cs2, out2.double().sum(0)) < 2e-6
+    with pytest.raises(RuntimeError):
+        ops.gemm(dy, Wt, M, 192, K, b_layout=0, a_layout=0, want_colsum=True, split_k=2)
+
+
 def test_gemm_errors_are_loud(ops):
     A = rnd(64, 30)
     with pytest.raises(RuntimeError):

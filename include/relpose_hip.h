@@ -168,6 +168,11 @@ int rp_attn_bwd_cross(const float* q, const float* k, const float* v, const floa
 int rp_attn_bwd_dkdv(const float* q, const float* k, const float* v, const float* dout, const float* lse,
                      const float* delta, float* dk, float* dv, int Z, int H, int ldq, int ldk, int ldv, int lddo, int lddk,
                      int lddv, float scale, void* stream);
+/* dK/dV pass that also stores ds[z][h][i][j] = scale * dS_ij ([Z,H,576,576] floats): dQ = ds K is then one batched rp_gemm per
+ * head (M=576, N=64, K=576, b_layout 1) instead of the dQ pass, which would recompute S and dP (5 executed GEMMs instead of 7) */
+int rp_attn_bwd_dkdv_ds(const float* q, const float* k, const float* v, const float* dout, const float* lse,
+                        const float* delta, float* dk, float* dv, float* ds, int Z, int H, int ldq, int ldk, int ldv, int lddo,
+                        int lddk, int lddv, float scale, void* stream);
 int rp_attn_bwd_dq(const float* q, const float* k, const float* v, const float* dout, const float* lse, const float* delta,
                    float* dq, int Z, int H, int ldq, int ldk, int ldv, int lddo, int lddq, float scale, void* stream);
 

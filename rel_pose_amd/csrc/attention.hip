@@ -252,6 +252,7 @@ struct AttnBwdP {
   float scale;
   int ZH;
   int kv_xor;   // 1: keys/values (and dK, dV) of problem z live at image z^1 relative to its queries (cross attention)
+  float* ds;    // optional [Z][H][576 q][576 key]: scale * dS written by the dK/dV pass, so dQ = dS K is a plain batched GEMM
 };
 
 template <int NW, int WPS>
@@ -302,6 +303,11 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dkdv_kernel(AttnBwdP p)
       const float pr = fast_exp2(s[r] - Ls[cur][qi]);
       s[r] = pr;
       dp[r] = pr * (dp[r] - Ls[cur][32 + qi]);
+    }
+    if (p.ds) {      // 128-byte row segments (32 keys) per register; the dQ pass then needs neither S nor dP again
+      float* dsb = p.ds + ((((long long)zq * p.H + h) * NTOK + t * 32) * NTOK) + k0 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dsb[(long long)acc_row(r, hi) * NTOK] = dp[r] * p.scale;
     }
     accum_tile<KST>(Ds[cur], l31, hi, s, dv0, dv1);     // dV^T += dO^T P
     accum_tile<KST>(Qs[cur], l31, hi, dp, dk0, dk1);    // dK^T += Q^T dS
@@ -401,10 +407,11 @@ static int launch_bwd(const AttnBwdP& p, int Z, int H, int which, hipStream_t st
 
 static int attn_bwd_impl(const float* q, const float* k, const float* v, const float* dout, const float* lse,
                          const float* delta, float* dq, float* dk, float* dv, int Z, int H, int ldq, int ldk, int ldv,
-                         int lddo, int lddq, int lddk, int lddv, float scale, int which, void* stream, int kv_xor = 0) {
+                         int lddo, int lddq, int lddk, int lddv, float scale, int which, void* stream, int kv_xor = 0,
+                         float* ds = nullptr) {
   if (Z <= 0 || H <= 0 || (kv_xor & ~1) || (kv_xor && (Z & 1))) return RP_EBADSHAPE;
   if ((ldq | ldk | ldv | lddo | lddq | lddk | lddv) & 3) return RP_EALIGN;
-  AttnBwdP p{q, k, v, dout, lse, delta, dq, dk, dv, H, ldq, ldk, ldv, lddo, lddq, lddk, lddv, scale, Z * H, kv_xor};
+  AttnBwdP p{q, k, v, dout, lse, delta, dq, dk, dv, H, ldq, ldk, ldv, lddo, lddq, lddk, lddv, scale, Z * H, kv_xor, ds};
   // both passes need ~190-240 VGPRs (2 waves/SIMD = 8 wave slots per CU): 2-wave workgroups pack 4 per CU, 3-wave ones only 2
   const char* ov = getenv("RP_ATTN_NW");
   if (ov && ov[0] == '3') return launch_bwd<3>(p, Z, H, which, (hipStream_t)stream);
@@ -426,6 +433,13 @@ extern "C" int rp_attn_bwd_dkdv(const float* q, const float* k, const float* v, 
                                 const float* delta, float* dk, float* dv, int Z, int H, int ldq, int ldk, int ldv, int lddo,
                                 int lddk, int lddv, float scale, void* stream) {
   return attn_bwd_impl(q, k, v, dout, lse, delta, nullptr, dk, dv, Z, H, ldq, ldk, ldv, lddo, 4, lddk, lddv, scale, 1, stream);
+}
+extern "C" int rp_attn_bwd_dkdv_ds(const float* q, const float* k, const float* v, const float* dout, const float* lse,
+                                   const float* delta, float* dk, float* dv, float* ds, int Z, int H, int ldq, int ldk, int ldv,
+                                   int lddo, int lddk, int lddv, float scale, void* stream) {
+  if (!ds) return RP_EBADSHAPE;
+  return attn_bwd_impl(q, k, v, dout, lse, delta, nullptr, dk, dv, Z, H, ldq, ldk, ldv, lddo, 4, lddk, lddv, scale, 1, stream, 0,
+                       ds);
 }
 extern "C" int rp_attn_bwd_dq(const float* q, const float* k, const float* v, const float* dout, const float* lse,
                               const float* delta, float* dq, int Z, int H, int ldq, int ldk, int ldv, int lddo, int lddq,

@@ -259,10 +259,15 @@ def test_attention_fwd_bwd(ops):
     assert e_o < 5e-6 and e_l < 2e-6
     do = rnd(Z * 576, 192, seed=2)
     (o_ref * do.double()).sum().backward()
-    dqkv = ops.attn_bwd(qkv, o, lse, do, Z)
-    e = [rel(dqkv[:, i * 192:(i + 1) * 192], q64.grad[:, i * 192:(i + 1) * 192]) for i in range(3)]
-    report("attn_bwd", dq=e[0], dk=e[1], dv=e[2])
-    assert max(e) < 2e-5
+    for store_ds in (True, False):          # dQ from the stored dS via a batched GEMM (default) / from the recompute pass
+        keep, ops.ATTN_BWD_STORE_DS = ops.ATTN_BWD_STORE_DS, store_ds
+        try:
+            dqkv = ops.attn_bwd(qkv, o, lse, do, Z)
+        finally:
+            ops.ATTN_BWD_STORE_DS = keep
+        e = [rel(dqkv[:, i * 192:(i + 1) * 192], q64.grad[:, i * 192:(i + 1) * 192]) for i in range(3)]
+        report("attn_bwd[store_ds=%d]" % store_ds, dq=e[0], dk=e[1], dv=e[2])
+        assert max(e) < 2e-5
 
 
 def test_cross_attention_is_attention_on_partner_keys_values(ops):
@@ -278,7 +283,11 @@ def test_cross_attention_is_attention_on_partner_keys_values(ops):
     assert torch.equal(o_x, o_s) and torch.equal(lse_x, lse_s)
     do = rnd(Z * 576, 192, seed=22)
     d_x = ops.attn_bwd(qkv, o_x, lse_x, do, Z, kv_xor=1).view(Z, 576, 576)
-    d_s = ops.attn_bwd(sw, o_s, lse_s, do, Z).view(Z, 576, 576)
+    keep, ops.ATTN_BWD_STORE_DS = ops.ATTN_BWD_STORE_DS, False          # the recompute-based dQ pass, like the cross kernels
+    try:
+        d_s = ops.attn_bwd(sw, o_s, lse_s, do, Z).view(Z, 576, 576)
+    finally:
+        ops.ATTN_BWD_STORE_DS = keep
     assert torch.equal(d_x[:, :, :192], d_s[:, :, :192])                                # dq stays with the query image
     assert torch.equal(d_x[:, :, 192:], ops.pair_swap(d_s)[:, :, 192:])                 # dk, dv land on the partner image
     with pytest.raises(RuntimeError):

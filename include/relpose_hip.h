@@ -208,6 +208,11 @@ int rp_rowdot96(const float* a, const float* b, float* out, long long rows, void
 int rp_emm_grad(const float* qkv, int ldqkv, const float* x, const float* w, const float* rlse, const float* clse,
                 const float* rho, const float* gamma, float* dqkv, int Z, int H, float scale, int swap, int single,
                 void* stream);
+/* the owner = query pass (swap = 0) that also stores ds[z][h][j][i] = scale * dS_ij ([Z,H,576,576] floats, key index major):
+ * the key-side gradient dk_z = ds_z q_{z^1} is then a batched rp_gemm per head and pair parity instead of the swap = 1 pass */
+int rp_emm_grad_ds(const float* qkv, int ldqkv, const float* x, const float* w, const float* rlse, const float* clse,
+                   const float* rho, const float* gamma, float* dqkv, float* ds, int Z, int H, float scale, int single,
+                   void* stream);
 
 /* q / max(|q|, 0.01), slot 0 <- Gs  (normalize_preds, src/model.py:145-159) */
 int rp_pose_normalize_fwd(const float* pred, const float* gs, float* out, int B, void* stream);

@@ -63,6 +63,7 @@ _SIGS = {
     "rp_emm_finalize_bwd": (c_int, [P, P, I, I, I, P]),
     "rp_rowdot96": (c_int, [P, P, P, L, P]),
     "rp_emm_grad": (c_int, [P, I, P, P, P, P, P, P, P, I, I, F, I, I, P]),
+    "rp_emm_grad_ds": (c_int, [P, I, P, P, P, P, P, P, P, P, I, I, F, I, P]),
     "rp_pose_normalize_fwd": (c_int, [P, P, P, I, P]),
     "rp_pose_normalize_bwd": (c_int, [P, P, P, I, P]),
 }

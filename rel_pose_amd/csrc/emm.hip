@@ -34,6 +34,8 @@ struct EmmP {
   int H; float scale; int swap; int ZH;
   int single;            // use_single_softmax (vision_transformer.py:201-203): A = softmax(S, -1) only
   const float* x_left;   // cross_features (:218-220): left operand of F = X_L^T A X comes from the partner image
+  float* ds;             // emm_grad, owner = query pass: optional [Z][H][576 j][576 i] = scale * dS_ij, so the key-side gradient
+                         // dk = scale dS^T q is a batched rp_gemm instead of a second pass that recomputes S and dA
 };
 
 template <int NTH>
@@ -281,6 +283,11 @@ __global__ __launch_bounds__(GT, 2) void emm_grad_kernel(EmmP p) {
         s[r] = 2.0f * eo * el * da[r] - eo * g_o - el * Ll[cur][32 + li];
       }
     }
+    if (p.ds) {      // (owner = query pass only) 128-byte row segments: row = loop index j, 32 consecutive owners i per register
+      float* dsb = p.ds + (zh * NTOK + t * 32) * NTOK + o0 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dsb[(long long)acc_row(r, hi) * NTOK] = s[r] * p.scale;
+    }
     // d owner^T[d][owner] += sum_loop other[loop][d] dS^T[loop][owner]
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -318,14 +325,28 @@ extern "C" int rp_emm_apply(const float* qkv, int ldqkv, const float* x, const f
   return RP_OK;
 }
 
-extern "C" int rp_emm_grad(const float* qkv, int ldqkv, const float* x, const float* w, const float* rlse,
-                           const float* clse, const float* rho, const float* gamma, float* dqkv, int Z, int H,
-                           float scale, int swap, int single, void* stream) {
+static int emm_grad_impl(const float* qkv, int ldqkv, const float* x, const float* w, const float* rlse, const float* clse,
+                         const float* rho, const float* gamma, float* dqkv, float* ds, int Z, int H, float scale, int swap,
+                         int single, void* stream) {
   if (Z <= 0 || (Z & 1) || H <= 0 || (ldqkv & 3)) return RP_EBADSHAPE;
+  if (ds && swap) return RP_EUNSUPPORTED;
   EmmP p{};
   p.qkv = qkv; p.ld = ldqkv; p.x = x; p.w = w; p.rlse = rlse; p.clse = clse; p.rho = rho; p.gamma = gamma;
-  p.dqkv = dqkv; p.H = H; p.scale = scale; p.swap = swap ? 1 : 0; p.ZH = Z * H; p.single = single ? 1 : 0;
+  p.dqkv = dqkv; p.H = H; p.scale = scale; p.swap = swap ? 1 : 0; p.ZH = Z * H; p.single = single ? 1 : 0; p.ds = ds;
   hipLaunchKernelGGL(emm_grad_kernel, dim3(xcd_grid(NTILE / GW, Z * H)), dim3(GT), 0, (hipStream_t)stream, p);
   RP_CHECK_LAUNCH();
   return RP_OK;
+}
+
+extern "C" int rp_emm_grad(const float* qkv, int ldqkv, const float* x, const float* w, const float* rlse,
+                           const float* clse, const float* rho, const float* gamma, float* dqkv, int Z, int H,
+                           float scale, int swap, int single, void* stream) {
+  return emm_grad_impl(qkv, ldqkv, x, w, rlse, clse, rho, gamma, dqkv, nullptr, Z, H, scale, swap, single, stream);
+}
+
+extern "C" int rp_emm_grad_ds(const float* qkv, int ldqkv, const float* x, const float* w, const float* rlse,
+                              const float* clse, const float* rho, const float* gamma, float* dqkv, float* ds, int Z, int H,
+                              float scale, int single, void* stream) {
+  if (!ds) return RP_EBADSHAPE;
+  return emm_grad_impl(qkv, ldqkv, x, w, rlse, clse, rho, gamma, dqkv, ds, Z, H, scale, 0, single, stream);
 }

@@ -304,6 +304,7 @@ def attn_fwd(qkv, Z, stats_only=False, q_off=0, k_off=DIM, v_off=2 * DIM, q_xor=
 
 
 ATTN_BWD_STORE_DS = os.environ.get("RP_ATTN_DS", "1") == "1"
+EMM_BWD_STORE_DS = os.environ.get("RP_EMM_DS", "1") == "1"
 
 
 def attn_bwd(qkv, o, lse, do, Z, fork=None, kv_xor=0):
@@ -464,10 +465,24 @@ def emm_backward(qkv, x, t, rlse, clse, df, Z, single=False, cross=False):
     dx = _bmm96(u, df, False, residual=pair_swap(dxl) if cross else dxl)      # + d X = U dF
     dqkv = torch.empty_like(qkv)
     ld = qkv.shape[1]
-    _lib.check(lib.rp_emm_grad(_p(qkv), ld, _p(x), _p(w), _p(rlse), _p(clse), _p(rho), _p(gam), _p(dqkv), Z, HEADS,
-                               scale, 0, sg, _st()), "rp_emm_grad(q)")
-    _lib.check(lib.rp_emm_grad(_p(qkv), ld, _p(xl), _p(wp), _p(rlse), _p(clse), _p(rho), _p(gam), _p(dqkv), Z, HEADS,
-                               scale, 1, sg, _st()), "rp_emm_grad(k)")
+    if EMM_BWD_STORE_DS:
+        # the query-side pass stores scale*dS; dk_z = dS_z^T-major x q_{z^1} is a batched GEMM per (head, pair parity) instead
+        # of a second pass that recomputes S and dA (68 of its 100 MFMAs per tile)
+        ds = _empty(Z, HEADS, N_TOK, N_TOK, like=qkv)
+        _lib.check(lib.rp_emm_grad_ds(_p(qkv), ld, _p(x), _p(w), _p(rlse), _p(clse), _p(rho), _p(gam), _p(dqkv), _p(ds), Z,
+                                      HEADS, scale, sg, _st()), "rp_emm_grad_ds")
+        dsf, qf, df = ds.view(-1), qkv.view(-1), dqkv.view(-1)
+        per, img = N_TOK * N_TOK, N_TOK * ld
+        for h in range(HEADS):
+            for e in (0, 1):                      # problems z = 2b + e take their queries from image z ^ 1
+                gemm(dsf[(e * HEADS + h) * per:], qf[(1 - e) * img + 64 * h:], N_TOK, 64, N_TOK, b_layout=1, lda=N_TOK, ldb=ld,
+                     out=df[e * img + DIM + 64 * h:], ldc=ld, split_k=1, batch=Z // 2,
+                     strides=(2 * HEADS * per, 2 * img, 2 * img))
+    else:
+        _lib.check(lib.rp_emm_grad(_p(qkv), ld, _p(x), _p(w), _p(rlse), _p(clse), _p(rho), _p(gam), _p(dqkv), Z, HEADS,
+                                   scale, 0, sg, _st()), "rp_emm_grad(q)")
+        _lib.check(lib.rp_emm_grad(_p(qkv), ld, _p(xl), _p(wp), _p(rlse), _p(clse), _p(rho), _p(gam), _p(dqkv), Z, HEADS,
+                                   scale, 1, sg, _st()), "rp_emm_grad(k)")
     _lib.check(lib.rp_emm_build_x_bwd(_p(dx), _p(dqkv), Z, HEADS, ld, _st()), "rp_emm_build_x_bwd")
     return dqkv
 

@@ -85,7 +85,7 @@ def main():
 
     model = ViTEss(args)
     if args.ckpt:
-        sd = OrderedDict((k.replace("module.", ""), v) for k, v in torch.load(args.ckpt, map_location="cpu")["model"].items())
+        sd = OrderedDict((k.replace("module.", ""), v) for k, v in torch.load(args.ckpt, map_location="cpu", weights_only=False)["model"].items())
         model.load_state_dict(sd)
     model = model.cuda().eval()
 

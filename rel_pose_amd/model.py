@@ -38,6 +38,7 @@ class ViTEss(nn.Module):
 
         self.flatten = nn.Flatten(0, 1)
         self.resnet = resnet18(pretrained=True)
+        self.resnet_pretrained = bool(getattr(self.resnet, "pretrained_loaded", False))
         self.resnet.fc = nn.Identity()
         self.extractor_final_conv = ResidualBlock(128, self.total_num_features, "batch", kernel_size=5)
 

@@ -8,6 +8,9 @@ restated here with identical ``state_dict`` keys.  Runs o
 PyTorch-ROCm (MIOpen) for the convolutions; the BatchNorm + residual-add + ReLU chains around them
 are fused HIP kernels (ops.bn_act) -- the CNN front-end is the first "next" row.
 """
+import os
+
+import torch
 import torch.nn as nn
 
 from ..ops import bn_act
@@ -68,7 +71,24 @@ class ResNet18(nn.Module):
         return nn.Sequential(*layers)
 
 
+WEIGHTS_ENV = "RELPOSE_RESNET18_WEIGHTS"
+
+
 def resnet18(pretrained=False, **kw):
-    # ImageNet weights are not obtainable offline; every rel_pose checkpoint overrides them anyway
-    # (reference src/model.py:31 comment).
-    return ResNet18(**kw)
+    """torchvision.models.resnet18(pretrained=...) (reference src/model.py:31).  ImageNet weights cannot be downloaded here:
+    with pretrained=True a local torchvision resnet18 state_dict (same keys) is loaded from $RELPOSE_RESNET18_WEIGHTS when
+    set; otherwise the trunk keeps its Kaiming init and `net.pretrained_loaded` stays False so that train.py can warn --
+    every rel_pose checkpoint overrides these weights anyway, but a from-scratch run does not reproduce the reference's
+    fine-tuning recipe without them."""
+    net = ResNet18(**kw)
+    net.pretrained_loaded = False
+    path = os.environ.get(WEIGHTS_ENV) if pretrained else None
+    if path:
+        sd = torch.load(path, map_location="cpu", weights_only=True)
+        sd = sd.get("state_dict", sd) if isinstance(sd, dict) else sd
+        missing, unexpected = net.load_state_dict(sd, strict=False)
+        bad = [k for k in missing if not k.startswith("fc.")] + [k for k in unexpected if not k.startswith("fc.")]
+        if bad:
+            raise RuntimeError("%s=%s is not a torchvision resnet18 state_dict (mismatched keys: %s)" % (WEIGHTS_ENV, path, bad[:5]))
+        net.pretrained_loaded = True
+    return net

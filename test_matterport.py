@@ -30,7 +30,7 @@ def load_model(args):
     args.noess = "1" if args.noess else ""
     model = ViTEss(args)
     if args.ckpt:
-        sd = torch.load(args.ckpt, map_location="cpu")["model"]
+        sd = torch.load(args.ckpt, map_location="cpu", weights_only=False)["model"]
         model.load_state_dict(OrderedDict((k.replace("module.", ""), v) for k, v in sd.items()))
     return model.cuda().eval()
 

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Launch every hot-path kernel at the 64-pair shapes a few times (one process for all rocprofv3 --pmc passes).
+usage: all_kernels.py [reps]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from rel_pose_amd import ops, _lib
+_lib.load()
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+torch.manual_seed(0)
+Z = 128
+M = Z * 576
+dev = "cuda"
+x = torch.randn(M, 192, device=dev)
+Wq = torch.randn(576, 192, device=dev) * 0.07; bq = torch.zeros(576, device=dev)
+Wp = torch.randn(192, 192, device=dev) * 0.07; bp = torch.zeros(192, device=dev)
+W1 = torch.randn(768, 192, device=dev) * 0.07; b1 = torch.zeros(768, device=dev)
+W2 = torch.randn(192, 768, device=dev) * 0.07; b2 = torch.zeros(192, device=dev)
+dY768 = torch.randn(M, 768, device=dev)
+dY192 = torch.randn(M, 192, device=dev)
+intr = torch.tensor([192.0, 192.0, 192.0, 192.0], device=dev).repeat(Z // 2, 2, 1).contiguous()
+for _ in range(reps):
+    qkv = ops.linear(x, Wq, bq)                       # gemm<0,0,2,1> forward
+    ops.linear(x, Wp, bp, residual=x)
+    h, hpre = ops.linear(x, W1, b1, act=1, want_pre=True)
+    ops.linear(h, W2, b2, residual=x)
+    ops.linear_dx(dY768, W1)                          # dX
+    ops.linear_dx(dY192, W2, dact=1, aux=hpre)
+    ops.linear_dw(dY768, x)                           # dW split-K
+    ops.linear_dw(dY192, h)
+    o, lse = ops.attn_fwd(qkv, Z)
+    ops.attn_bwd(qkv, o, lse, dY192, Z)
+    # EMM
+    pos = ops.posenc(intr, Z // 2, dev)
+    X = ops.emm_build_x(qkv, pos, Z)
+    rlse, clse = ops.emm_stats(qkv, Z)
+    t, f = ops.emm_apply(qkv, X, rlse, clse, Z)
+    df = torch.randn(Z, 3, 96, 96, device=dev) * 0.01
+    ops.emm_backward(qkv, X, t, rlse, clse, df, Z)
+    y, mu, rs = ops.layernorm_fwd(x, torch.ones(192, device=dev), torch.zeros(192, device=dev))
+    ops.layernorm_bwd(dY192, x, torch.ones(192, device=dev), mu, rs)
+torch.cuda.synchronize()
+print("ok")

@@ -10,7 +10,8 @@ tensor shapes and the whole loop -- forward, geodesic loss, backward, clip, Adam
 auto-resume with the reference's file layout and keys -- runs anywhere.
 
     python train.py --name run0 --gpus 1 --batch 64 --steps 100 --fusion_transformer          # single GPU
-    python -m torch.distributed.run --nproc-per-node 8 train.py --name run0 --gpus 8 ...       # one rank per GPU
+    python train.py --name run0 --gpus 8 ...      # spawns 8 ranks itself, like the reference (train.py:286-291, port 12356)
+    python -m torch.distributed.run --nproc-per-node 8 train.py --name run0 --gpus 8 ...       # or under a launcher
 """
 import argparse
 import os
@@ -65,6 +66,23 @@ def find_resume(name):
     return os.path.join(d, "%06d.pth" % max(int(f[:-4]) for f in ck))
 
 
+def load_checkpoint(path, map_location=None):
+    """Checkpoints are trusted local files written by this train.py or by the reference's (torch 1.8, whose OneCycleLR
+    state holds a bound method that the weights-only unpickler rejects) -> full unpickling, reference train.py:89."""
+    return torch.load(path, map_location=map_location, weights_only=False)
+
+
+def next_subepoch(subepoch, dataset):
+    """Ten training sub-epochs, then one validation pass -- except InteriorNet / StreetLearn, which have no validation
+    split (reference train.py:204-208)."""
+    if dataset == "synthetic":
+        return 0
+    subepoch += 1
+    if subepoch == 11 or (subepoch == 10 and dataset in ("interiornet", "streetlearn")):
+        subepoch = 0
+    return subepoch
+
+
 def run(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -78,6 +96,10 @@ def run(args):
     dev = torch.device("cuda", local)
 
     model = ViTEss(args).to(dev).train()
+    if rank == 0 and not model.resnet_pretrained and not (args.ckpt or find_resume(args.name)):
+        print("WARNING: the ResNet-18 trunk starts from random weights -- the reference fine-tunes conv1/layer1/layer2 from "
+              "torchvision's ImageNet weights (src/model.py:31).  Point RELPOSE_RESNET18_WEIGHTS (or --resnet_weights) at a "
+              "local torchvision resnet18 state_dict to reproduce its training recipe.", flush=True)
     for p in list(model.resnet.layer3.parameters()) + list(model.resnet.layer4.parameters()):
         p.requires_grad = False
     net = parallel.wrap(model, [local]) if ddp else model
@@ -86,7 +108,7 @@ def run(args):
                                                 div_factor=25, cycle_momentum=False)
     resume = args.ckpt or find_resume(args.name)
     if resume:
-        ck = torch.load(resume, map_location=dev)
+        ck = load_checkpoint(resume, map_location=dev)
         sd = ck["model"]
         if not ddp:
             sd = OrderedDict((k.replace("module.", ""), v) for k, v in sd.items())
@@ -155,7 +177,7 @@ def run(args):
                 break
         if val and rank == 0:
             print("validation  %s" % {k: sum(v[k] for v in val) / len(val) for k in val[0]}, flush=True)
-        subepoch = (subepoch + 1) % 11 if args.dataset != "synthetic" else 0
+        subepoch = next_subepoch(subepoch, args.dataset)
     if rank == 0:
         print("finished training!")
     if ddp:
@@ -188,6 +210,7 @@ def parser():
     ap.add_argument("--fc_hidden_size", type=int, default=512)
     ap.add_argument("--pool_size", type=int, default=60)
     ap.add_argument("--transformer_depth", type=int, default=6)
+    ap.add_argument("--resnet_weights", help="local torchvision resnet18 state_dict (.pth) for the pretrained trunk")
     return ap
 
 
@@ -198,4 +221,9 @@ if __name__ == "__main__":
     with open("output/%s/args_%s.txt" % (a.name, datetime.now().strftime("%Y-%m-%d_%H-%M")), "w") as f:
         for k, v in vars(a).items():
             f.write("%s  %s\n" % (k, v))
-    run(a)
+    if a.resnet_weights:
+        os.environ["RELPOSE_RESNET18_WEIGHTS"] = a.resnet_weights
+    if "WORLD_SIZE" in os.environ or a.no_ddp or a.gpus <= 1:
+        run(a)                      # under a launcher (one rank per process already), or a single GPU
+    else:
+        parallel.spawn(run, a.gpus, (a,))     # the reference's own process model: --gpus N spawns N ranks

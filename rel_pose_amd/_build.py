@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librelpose_hip.so")
-SOURCES = ["gemm.hip", "rowwise.hip", "attention.hip", "emm.hip", "batchnorm.hip", "se3loss.hip"]
+SOURCES = ["gemm.hip", "gemm_dma.hip", "rowwise.hip", "attention.hip", "emm.hip", "batchnorm.hip", "se3loss.hip"]
 ARCH = "gfx950"
 
 
@@ -22,14 +22,26 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.h"),
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"),
                                                        os.path.join(os.path.dirname(HERE), "include", "relpose_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
 def build(force=False, verbose=True):
-    if not force and not needs_build():
-        return LIB
+    """Compile under an exclusive file lock (eight ranks of a first `torchrun` would otherwise write the same .o / .so at
+    once) and move the finished library into place atomically, so a concurrent loader never maps a half-written file."""
+    import fcntl
+    with open(os.path.join(HERE, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():      # another rank built it while this one waited
+                return LIB
+            return _build_locked(verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(verbose):
     cc = _hipcc()
     objs = []
     procs = []
@@ -45,10 +57,12 @@ def build(force=False, verbose=True):
         if p.returncode != 0:
             sys.stderr.write(out.decode())
             raise RuntimeError("hipcc failed on " + s)
-    cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+    tmp = LIB + ".tmp.%d" % os.getpid()
+    cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", tmp] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    os.replace(tmp, LIB)
     return LIB
 
 

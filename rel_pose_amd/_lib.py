@@ -11,6 +11,7 @@ import torch  # noqa: F401  (must be imported first: it loads the HIP runtime th
 from . import _build
 
 _LIB = None
+ABI_VERSION = 2          # rp_abi_version() of the library this binding was written against
 RP_ERRORS = {-1: "bad shape", -2: "misaligned pointer/stride", -3: "workspace too small", -4: "unsupported"}
 
 
@@ -80,12 +81,16 @@ def load():
     if _LIB is not None:
         return _LIB
     path = _build.LIB
-    if not os.path.exists(path):
+    if _build.needs_build():           # missing, or older than a kernel source / the header (never a silently stale .so)
         _build.build(verbose=False)
     try:
         lib = ctypes.CDLL(path)
     except OSError as e:
         raise RuntimeError("rel_pose_amd: cannot load HIP extension %s (%s); there is no CPU fallback" % (path, e))
+    lib.rp_abi_version.restype = c_int
+    if lib.rp_abi_version() != ABI_VERSION:
+        raise RuntimeError("rel_pose_amd: %s has ABI version %d, this package binds version %d -- rebuild with "
+                           "`python -m rel_pose_amd._build --force`" % (path, lib.rp_abi_version(), ABI_VERSION))
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)          # AttributeError = symbol missing = broken build
         fn.restype = res

@@ -11,46 +11,12 @@
 // k = 16 + t, so a K-contiguous operand row is read as 4 x ds_read_b128 (row stride 36 floats: the 16
 // lanes of a b128 group land on 16 distinct 16-byte slots); an MN-contiguous operand is read as
 // conflict-free ds_read_b32 rows.
-#include "common.h"
+#include "gemm_common.h"
 #include "../../include/relpose_hip.h"
 #include <stdlib.h>
 
 namespace {
-
-enum { EPI_RAW = 0, EPI_BIAS, EPI_BIAS_RES, EPI_RES, EPI_BIAS_GELU, EPI_BIAS_GELU_PRE, EPI_BIAS_RELU, EPI_DGELU,
-       EPI_DRELU, EPI_GENERIC };
-
-struct GemmP {
-  const float* A;
-  const float* B;
-  float* C;
-  int M, N, K;
-  int lda, ldb, ldc;
-  long long sa, sb, sc;
-  int split_k;
-  int k_per_split;
-  const float* bias;
-  float* pre_out;
-  int act, dact;
-  const float* aux;
-  const float* residual;
-  int epi_mode;
-  int trans_c;
-  int limbs;
-  float* colsum_part;
-};
-
-RP_DEV float epilogue(float v, int m, int n, const GemmP& p) {
-  if (p.bias) v += p.bias[n];
-  const long long off = (long long)m * p.ldc + n;
-  if (p.pre_out) p.pre_out[off] = v;
-  if (p.act == 1) v = gelu_exact(v);
-  else if (p.act == 2) v = fmaxf(v, 0.f);
-  if (p.dact == 1) v *= gelu_grad(p.aux[off]);
-  else if (p.dact == 2) v = p.aux[off] > 0.f ? v : 0.f;
-  if (p.residual) v += p.residual[off];
-  return v;
-}
+using namespace rpgemm;
 
 // ---- split-bf16 operand path (NL = 1..3 limbs) ---------------------------------------------------------------------
 // x = x1 + x2 + x3 exactly, each limb a bf16 (8 significant bits): x1 = top 8 bits of x (truncation), x2 = top 8 bits of
@@ -358,102 +324,7 @@ __global__ __launch_bounds__(256, NL > 0 ? 2 : 1) void gemm_kernel(GemmP p) {
     }
   }
 
-  // ---- epilogue: one wave-uniform switch, then straight-line code per element --------------------
-  float* C = p.C + zb * p.sc;
-  const bool partial = p.split_k > 1;
-  if (partial) C = p.C + (long long)zid * p.M * p.N;   // workspace slab [z][M][N]
-  const int ldc = partial ? p.N : p.ldc;
-  const float* bias = p.bias;
-  float* pre_out = p.pre_out ? p.pre_out + zb * p.sc : nullptr;
-  const float* aux = p.aux ? p.aux + zb * p.sc : nullptr;
-  const float* res = p.residual ? p.residual + zb * p.sc : nullptr;
-  const int mode = partial ? EPI_RAW : p.epi_mode;
-  const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N);
-
-  if (STAGED && (p.N & 3) == 0 && mode != EPI_GENERIC) {
-    // LDS-staged epilogue: the accumulators (lane = column, register = row) are transposed through the wave's own LDS
-    // region so that every global access of the epilogue -- C, bias, residual, GELU'/ReLU' aux, pre-activation copy -- is a
-    // 16-byte row segment per lane (global_load/store_dwordx4) instead of 16*TM*TN dword accesses per lane.  Ablation:
-    // the dword store tail alone was 11 % of the kernel; dword aux/residual loads serialised at 96 per lane.
-    float* cs = lds + wave * (32 * TM * CST);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) cs[(32 * i + acc_row(r, hi)) * CST + 32 * j + l31] = acc[i][j][r];
-    __syncthreads();
-    constexpr int C4 = 8 * TN;             // float4 per staged row
-    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);   // this lane's column sums of the final values (colsum_part != nullptr)
-    const bool want_cs = (64 % C4) == 0 && p.colsum_part != nullptr && !partial;
-#pragma unroll
-    for (int it = 0; it < (32 * TM * C4) / 64; ++it) {
-      const int idx = lane + 64 * it;
-      const int row = idx / C4, c4 = idx % C4;
-      const int m = m0 + wm0 + row, n = n0 + wn0 + 4 * c4;
-      if ((interior || (m < p.M && n < p.N))) {
-        float4 v = ld4(cs + row * CST + 4 * c4);
-        const long long off = (long long)m * ldc + n;
-        if (mode == EPI_BIAS || mode == EPI_BIAS_RES || mode == EPI_BIAS_GELU || mode == EPI_BIAS_GELU_PRE ||
-            mode == EPI_BIAS_RELU) {
-          const float4 b4 = ld4(bias + n);
-          v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
-        }
-        if (mode == EPI_BIAS_GELU_PRE) st4(pre_out + off, v);
-        if (mode == EPI_BIAS_GELU || mode == EPI_BIAS_GELU_PRE) {
-          v.x = gelu_exact(v.x); v.y = gelu_exact(v.y); v.z = gelu_exact(v.z); v.w = gelu_exact(v.w);
-        } else if (mode == EPI_BIAS_RELU) {
-          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-        } else if (mode == EPI_DGELU) {
-          const float4 a4 = ld4(aux + off);
-          v.x *= gelu_grad(a4.x); v.y *= gelu_grad(a4.y); v.z *= gelu_grad(a4.z); v.w *= gelu_grad(a4.w);
-        } else if (mode == EPI_DRELU) {
-          const float4 a4 = ld4(aux + off);
-          v.x = a4.x > 0.f ? v.x : 0.f; v.y = a4.y > 0.f ? v.y : 0.f; v.z = a4.z > 0.f ? v.z : 0.f; v.w = a4.w > 0.f ? v.w : 0.f;
-        }
-        if (mode == EPI_BIAS_RES || mode == EPI_RES) {
-          const float4 r4 = ld4(res + off);
-          v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
-        }
-        st4(C + off, v);
-        if (want_cs) { csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w; }
-      }
-    }
-    if (want_cs) {
-      // a lane keeps the same column group c4 = lane % C4 through the loop: fold the 64 / C4 lanes of each group, then lanes
-      // 0..C4-1 store one row of per-(tile, wave-row) column sums; a small rp_colsum over them finishes the bias gradient
-#pragma unroll
-      for (int o = 32; o >= C4; o >>= 1) {
-        csum.x += __shfl_xor(csum.x, o, 64); csum.y += __shfl_xor(csum.y, o, 64);
-        csum.z += __shfl_xor(csum.z, o, 64); csum.w += __shfl_xor(csum.w, o, 64);
-      }
-      const int n = n0 + wn0 + 4 * lane;
-      if (lane < C4 && n < p.N) st4(p.colsum_part + (long long)(2 * mt + (wave >> 1)) * p.N + n, csum);
-    }
-  } else {
-#define RP_EPI_LOOP(BODY)                                                              \
-  _Pragma("unroll") for (int i = 0; i < TM; ++i)                                       \
-  _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                     \
-    const int n = n0 + wn0 + 32 * j + l31;                                             \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                   \
-      const int m = m0 + wm0 + 32 * i + acc_row(r, hi);                                \
-      if ((interior || (m < p.M && n < p.N))) {                          \
-        const long long off = (long long)m * ldc + n;                                  \
-        float v = acc[i][j][r];                                                        \
-        BODY;                                                                          \
-        C[off] = v;                                                                    \
-      }                                                                                \
-    }                                                                                  \
-  }
-  if (mode == EPI_RAW) {
-    RP_EPI_LOOP((void)0)
-  } else {
-    GemmP q = p;
-    q.pre_out = pre_out; q.aux = aux; q.residual = res;
-    RP_EPI_LOOP(v = epilogue(v, m, n, q))
-  }
-  }
-#undef RP_EPI_LOOP
+  tile_epilogue<TM, TN, STAGED>(p, acc, lds, m0, n0, mt, zb, zid);
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, const float* ws) {
@@ -576,7 +447,9 @@ extern "C" int rp_gemm(const RpGemm* g, void* stream) {
   if (p.colsum_part && (tn == 3 || p.epi_mode == EPI_GENERIC)) return RP_EUNSUPPORTED;   // needs the staged epilogue, 64 % (8 TN) == 0
   hipStream_t st = (hipStream_t)stream;
   const int nz = batch * split;
-  if (p.limbs == 3) launch_layouts<3>(p, nz, g->a_layout, g->b_layout, tm, tn, st);
+  static const bool no_dma = getenv("RP_GEMM_NO_DMA") != nullptr;      // A/B aid: force the register-staged main loop
+  if (!no_dma && dma_eligible(p)) launch_dma(p, nz, g->a_layout, g->b_layout, tm, tn, st);
+  else if (p.limbs == 3) launch_layouts<3>(p, nz, g->a_layout, g->b_layout, tm, tn, st);
   else if (p.limbs == 1) launch_layouts<1>(p, nz, g->a_layout, g->b_layout, tm, tn, st);
   else launch_layouts<0>(p, nz, g->a_layout, g->b_layout, tm, tn, st);
   RP_CHECK_LAUNCH();

@@ -529,5 +529,5 @@ extern "C" int rp_pose_normalize_bwd(const float* pred, const float* dout, float
   return RP_OK;
 }
 
-extern "C" int rp_abi_version(void) { return 1; }
+extern "C" int rp_abi_version(void) { return 2; }
 extern "C" const char* rp_target_arch(void) { return "gfx950"; }

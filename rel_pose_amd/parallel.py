@@ -23,6 +23,24 @@ def setup(rank, world_size, backend=None, master_addr="127.0.0.1", master_port="
     return backend
 
 
+def _spawn_entry(local_rank, fn, world_size, args, master_addr, master_port):
+    os.environ["MASTER_ADDR"] = master_addr
+    os.environ["MASTER_PORT"] = str(master_port)
+    os.environ["WORLD_SIZE"] = str(world_size)
+    os.environ["RANK"] = str(local_rank)
+    os.environ["LOCAL_RANK"] = str(local_rank)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # the host driver only supports dmabuf IPC (RCCL needs it)
+    fn(*args)
+
+
+def spawn(fn, nprocs, args=(), master_addr="127.0.0.1", master_port="12356"):
+    """`python train.py --gpus N` without a launcher: start N ranks of `fn(*args)` on this node, one per GPU, exactly as the
+    reference does with mp.spawn (train.py:286-291; rendezvous port 12356).  Each child gets the RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* environment a launcher would have set, so `fn` is the same code path either way."""
+    import torch.multiprocessing as mp
+    mp.spawn(_spawn_entry, nprocs=nprocs, args=(fn, nprocs, tuple(args), master_addr, str(master_port)), join=True)
+
+
 def shard_pairs(num_pairs, rank, world_size):
     """Indices of the pairs rank `rank` owns: r, r+W, r+2W, ... (what DistributedSampler(shuffle=False) yields;
     the tail is padded by wrapping so every rank gets the same count, as DistributedSampler does)."""

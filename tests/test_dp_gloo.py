@@ -62,3 +62,25 @@ def test_two_rank_data_parallel_matches_single_process():
     ref = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
     assert torch.allclose(res[0][2], ref, atol=1e-6)                                # DP grad == full-batch grad
     assert torch.allclose(res[0][3][0], torch.full((3,), 1.5)) and torch.allclose(res[1][3][1], torch.full((2, 2), 15.0))
+
+
+def _spawn_body(tmpdir):
+    """what train.run does first: read the launcher environment, join the group, one collective"""
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    assert int(os.environ["LOCAL_RANK"]) == rank and os.environ["MASTER_ADDR"] == "127.0.0.1"
+    from rel_pose_amd import parallel
+    parallel.setup(rank, world, backend="gloo")
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    with open(os.path.join(tmpdir, "rank%d.txt" % rank), "w") as f:
+        f.write("%d %d %.1f" % (rank, world, t.item()))
+    parallel.cleanup()
+
+
+@pytest.mark.timeout(120)
+def test_spawn_starts_one_rank_per_gpu_like_the_reference(tmp_path):
+    """`train.py --gpus N` without a launcher spawns N ranks itself (reference train.py:286-291)."""
+    from rel_pose_amd import parallel
+    parallel.spawn(_spawn_body, 2, (str(tmp_path),), master_port=_free_port())
+    got = sorted(open(str(tmp_path / ("rank%d.txt" % r))).read() for r in range(2))
+    assert got == ["0 2 3.0", "1 2 3.0"]

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, sym), "missing export: " + sym
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     typed = _lib.load()
-    assert typed.rp_abi_version() == 1 and typed.rp_target_arch() == b"gfx950"
+    assert typed.rp_abi_version() == _lib.ABI_VERSION and typed.rp_target_arch() == b"gfx950"
     assert typed.rp_gemm_workspace_bytes(576, 192, 103) == 103 * 576 * 192 * 4
     assert typed.rp_layernorm_bwd_blocks(73728) == 1152 and typed.rp_layernorm_bwd_blocks(100) == 2
 
@@ -179,3 +179,62 @@ def test_miopen_user_db_is_private_per_rank(tmp_path, monkeypatch):
     importlib.reload(env)
     assert os.environ["MIOPEN_USER_DB_PATH"] == "/somewhere/else"
     tempfile.tempdir = None
+
+
+def test_subepoch_schedule_follows_the_reference():
+    """ten training sub-epochs then one validation pass; InteriorNet / StreetLearn have no validation split
+    (reference train.py:204-208)"""
+    import train
+    seq, s = [], 0
+    for _ in range(23):
+        seq.append(s)
+        s = train.next_subepoch(s, "matterport")
+    assert seq == list(range(11)) + list(range(11)) + [0]
+    for ds in ("interiornet", "streetlearn"):
+        seq, s = [], 0
+        for _ in range(21):
+            seq.append(s)
+            s = train.next_subepoch(s, ds)
+        assert seq == list(range(10)) + list(range(10)) + [0] and 10 not in seq
+    assert train.next_subepoch(3, "synthetic") == 0
+
+
+class _NotATensor:
+    """stands in for the bound method torch-1.8's OneCycleLR pickles into its state_dict"""
+
+    def anneal(self, a, b, pct):
+        return a + (b - a) * pct
+
+
+def test_reference_style_checkpoint_loads(tmp_path):
+    """the reference's checkpoints hold {'model','optimizer','scheduler'} and the scheduler state contains a bound method
+    (anneal_func) that torch.load(weights_only=True) rejects; train.py / demo.py / test_matterport.py load them fully"""
+    import torch, train
+    obj = _NotATensor()
+    ck = {"model": {"module.w": torch.ones(2)}, "optimizer": {"state": {}}, "scheduler": {"anneal_func": obj.anneal, "last_epoch": 7}}
+    p = str(tmp_path / "ref_style.pth")
+    torch.save(ck, p)
+    with pytest.raises(Exception):
+        torch.load(p, weights_only=True)
+    got = train.load_checkpoint(p, map_location="cpu")
+    assert got["scheduler"]["last_epoch"] == 7 and torch.equal(got["model"]["module.w"], torch.ones(2))
+    assert got["scheduler"]["anneal_func"](0.0, 2.0, 0.5) == 1.0
+
+
+def test_pretrained_trunk_loads_from_a_local_state_dict(tmp_path, monkeypatch):
+    """resnet18(pretrained=True) takes torchvision-keyed weights from $RELPOSE_RESNET18_WEIGHTS and says whether it did"""
+    import torch
+    from rel_pose_amd.modules import resnet
+    monkeypatch.delenv(resnet.WEIGHTS_ENV, raising=False)
+    net = resnet.resnet18(pretrained=True)
+    assert net.pretrained_loaded is False
+    sd = {k: torch.full_like(v, 0.25) for k, v in net.state_dict().items()}
+    sd["fc.weight"] = torch.zeros(1000, 512)          # torchvision's classifier head is ignored
+    p = str(tmp_path / "resnet18.pth")
+    torch.save(sd, p)
+    monkeypatch.setenv(resnet.WEIGHTS_ENV, p)
+    net2 = resnet.resnet18(pretrained=True)
+    assert net2.pretrained_loaded and float(net2.conv1.weight.flatten()[0]) == 0.25
+    torch.save({"not_a_resnet": torch.zeros(1)}, p)
+    with pytest.raises(RuntimeError):
+        resnet.resnet18(pretrained=True)

@@ -65,7 +65,26 @@ def read_png_bgr(path):
     return img[:, :, ::-1].copy()               # RGB -> BGR (cv2 order)
 
 
-def main():
+def load_pair(img1, img2, matterport):
+    """[1,2,3,H,W] float32 BGR 0..255 on the CPU: reference demo.py:65-76 (cv2.imread order, nearest resize to 384x512 for the
+    Matterport checkpoints, whose training data was resized that way)."""
+    images = np.stack([read_png_bgr(img1), read_png_bgr(img2)]).astype(np.float32)
+    images = torch.from_numpy(images).permute(0, 3, 1, 2)
+    if matterport:
+        images = F.interpolate(images, size=[384, 512])                                         # demo.py:72-73
+    return images.unsqueeze(0)
+
+
+def postprocess(raw7, matterport):
+    """reference demo.py:86-92: undo the training-time depth scale and reorder the quaternion (yzxw -> xyzw) on Matterport."""
+    preds = np.array(raw7, dtype=np.float32, copy=True)
+    if matterport:
+        preds[:3] = preds[:3] * 5                                                               # DEPTH_SCALE
+        preds[3:] = np.array([raw7[4], raw7[5], raw7[3], raw7[6]])
+    return preds
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--datapath"); ap.add_argument("--weights")
     ap.add_argument("--image_size", default=[384, 512])
@@ -75,7 +94,7 @@ def main():
     ap.add_argument("--fc_hidden_size", type=int, default=512)
     ap.add_argument("--pool_size", type=int, default=60)
     ap.add_argument("--transformer_depth", type=int, default=6)
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     args.fusion_transformer = True
     args.noess = "1" if args.noess else ""
     print("predicting pose on %s and %s using model %s" % (args.img1, args.img2, args.ckpt or "<random init>"))
@@ -89,20 +108,13 @@ def main():
         model.load_state_dict(sd)
     model = model.cuda().eval()
 
-    images = np.stack([read_png_bgr(args.img1), read_png_bgr(args.img2)]).astype(np.float32)
-    images = torch.from_numpy(images).permute(0, 3, 1, 2)
-    if matterport:
-        images = F.interpolate(images, size=[384, 512])                                         # demo.py:72-73
-    images = images.unsqueeze(0).cuda()
+    images = load_pair(args.img1, args.img2, matterport).cuda()
     Gs = SE3(torch.tensor([[[0, 0, 0, 0, 0, 0, 1.0]] * 2]).cuda())
     with torch.no_grad():
         est = model(images, Gs, intrinsics=intrinsics)
-    preds = est[0][0][1].data.cpu().numpy()
-    pr = preds.copy()
+    preds = postprocess(est[0][0][1].data.cpu().numpy(), matterport)
     np.set_printoptions(suppress=True, precision=5)
     if matterport:
-        preds[:3] *= 5                                                                          # DEPTH_SCALE, demo.py:89-91
-        preds[3:] = np.array([pr[4], pr[5], pr[3], pr[6]])                                      # yzxw -> xyzw, demo.py:92
         print("predicted R&t, as quaternion, in format x,y,z,qx,qy,qz,qw:")
         print(preds)
     else:

@@ -301,7 +301,56 @@ def noess_fixtures():
           (len(out), os.path.getsize(os.path.join(HERE, "reference_outputs_noess.npz")) / 1024))
 
 
+def demo_fixture():
+    """SURVEY 8c, BASELINE configs[0]: the reference's OWN demo.py body (intrinsics selection :52-57, tensor assembly :65-81,
+    post-processing :86-92) executed on its demo/matterport_{1,2}.png (640x480 RGBA) with a closed-form checkpoint -> the [7]
+    vector it prints.  demo.py is a script (everything sits under `if __name__ == '__main__'`), needs cv2 / CUDA and cannot
+    be imported: its source is read from the read-only reference at generation time and exec'd under harness shims
+    (cv2.imread -> PIL decode in cv2's BGR / alpha-dropped convention, nn.Module.cuda -> identity); nothing of it is stored.
+    The two PNGs are copied next to the fixture as DATA so that the GPU test can feed this repo's demo.py the same bytes."""
+    import ast
+    import shutil
+    import tempfile
+    from PIL import Image
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    cv2 = types.ModuleType("cv2")
+    cv2.imread = lambda path: np.ascontiguousarray(np.asarray(Image.open(path).convert("RGB"))[:, :, ::-1])
+    sys.modules["cv2"] = cv2
+    os.makedirs(os.path.join(HERE, "demo"), exist_ok=True)
+    for n in ("matterport_1.png", "matterport_2.png"):
+        shutil.copyfile(os.path.join(REF, "demo", n), os.path.join(HERE, "demo", n))
+    shapes = dict(O.vit_param_shapes())
+    shapes.update(O.cnn_param_shapes())
+    sd32 = O.make_state(shapes, torch.float32)
+    full = ViTEss(ref_args()).state_dict()                 # layer3/4 (unused by the forward) keep their constructed values
+    full.update(sd32)
+    tmp = tempfile.mkdtemp()
+    ck = os.path.join(tmp, "matterport_closed_form.pth")    # "matterport" in the name selects that branch (demo.py:52,71,88)
+    torch.save({"model": {"module." + k: v for k, v in full.items()}}, ck)
+    src = open(os.path.join(REF, "demo.py")).read()
+    tree = ast.parse(src)
+    body = [n for n in tree.body if isinstance(n, ast.If)][-1].body          # statements under `if __name__ == '__main__':`
+    mod = ast.Module(body=[n for n in tree.body if not isinstance(n, ast.If)] + body, type_ignores=[])
+    argv, sys.argv = sys.argv, ["demo.py", "--img1", os.path.join(REF, "demo", "matterport_1.png"), "--img2",
+                                os.path.join(REF, "demo", "matterport_2.png"), "--ckpt", ck]
+    ns = {"__name__": "reference_demo"}
+    try:
+        torch.multiprocessing.set_start_method = lambda *a, **k: None
+        exec(compile(mod, os.path.join(REF, "demo.py"), "exec"), ns)
+    finally:
+        sys.argv = argv
+    out = {"demo_matterport_pred7_f32": np.asarray(ns["preds"], dtype=np.float32),
+           "demo_matterport_raw7_f32": np.asarray(ns["pr_copy"], dtype=np.float32),
+           "demo_matterport_images_sub": ns["images"][0, :, :, ::29, ::31].numpy().astype(np.float32)}
+    np.savez_compressed(os.path.join(HERE, "reference_demo.npz"), **out)
+    print("wrote reference_demo.npz:", out["demo_matterport_pred7_f32"])
+
+
 if __name__ == "__main__":
+    if "--demo-only" in sys.argv:
+        demo_fixture()
+        sys.exit(0)
     if "--noess-only" not in sys.argv:
         main()
     noess_fixtures()
+    demo_fixture()

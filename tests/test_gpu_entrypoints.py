@@ -143,3 +143,54 @@ def test_bench_two_ranks_on_one_gpu():
     rec = json.loads(line)
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch_pairs"] == 16 and rec["config"]["finite"] and rec["scaling"] == "weak"
     assert "cpu_baseline" not in rec and rec["roofline"]["launches_timed"] > 0
+
+
+def test_product_model_ddp_gradients_equal_full_batch(tmp_path):
+    """The reference's only parallelism (train.py:28-36,66-67,128-130) on the PRODUCT model: two ranks, each with a full
+    ViTEss replica under DistributedDataParallel and pairs r::2 of an 8-pair batch, must end up with the gradients of the
+    single-process full batch after DDP's all-reduce(mean).  Both ranks share cuda:0 over gloo (one-GPU test box; on a node
+    the same code runs over RCCL).  BatchNorm is in eval mode so that shard and full batch normalise identically
+    ("BatchNorm under DDP"); tolerance = fp32 summation-order noise between 4- and 8-pair launches."""
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    out = tmp_path / "ddp.txt"
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "tests", "_ddp_product_worker.py"), str(out)]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    n, worst, name, worst_hot = out.read_text().split()[:4]
+    with open(os.path.join(ROOT, "gpurun_out", "test_report.txt"), "a") as f:
+        f.write("ddp_product_2ranks: tensors=%s worst=%s (%s) worst_hot_path=%s\n" % (n, worst, name, worst_hot))
+    assert int(n) >= 120                                  # every trainable tensor (123: 227 state tensors minus buffers, layer3/4)
+    assert float(worst_hot) < 2e-4, worst_hot             # ViT / EMM / regressor tensors (the HIP kernels)
+    assert float(worst) < 1e-3, (worst, name)             # CNN trunk on MIOpen: 8- vs 16-image launches pick different split orders
+
+
+def test_demo_reproduces_reference_demo_output(tmp_path):
+    """BASELINE configs[0] / SURVEY 8c: this repo's demo.py on the reference's own demo/matterport_{1,2}.png (640x480 RGBA,
+    committed as data under tests/golden/demo) with the closed-form checkpoint prints the [7] vector the reference's demo.py
+    produced on the same files and weights (tests/golden/reference_demo.npz, generated by executing the reference's script)."""
+    import numpy as np
+    import torch
+    from oracle import relpose_oracle as O
+    sys.path.insert(0, ROOT)
+    import demo
+    shapes = dict(O.vit_param_shapes())
+    shapes.update(O.cnn_param_shapes())
+    sd32 = O.make_state(shapes, torch.float32)
+    from rel_pose_amd.model import ViTEss
+    import types
+    args = types.SimpleNamespace(noess="", pool_size=60, fc_hidden_size=512, fusion_transformer=True, transformer_depth=6,
+                                 cross_features=False, use_single_softmax=False, no_pos_encoding=False, l1_pos_encoding=False)
+    full = ViTEss(args).state_dict()
+    full.update(sd32)
+    ck = str(tmp_path / "matterport_closed_form.pth")
+    torch.save({"model": {"module." + k: v for k, v in full.items()}, "optimizer": {}, "scheduler": {}}, ck)
+    g = os.path.join(ROOT, "tests", "golden")
+    preds = demo.main(["--img1", os.path.join(g, "demo", "matterport_1.png"), "--img2", os.path.join(g, "demo", "matterport_2.png"),
+                       "--ckpt", ck])
+    ref = np.load(os.path.join(g, "reference_demo.npz"))["demo_matterport_pred7_f32"]
+    err = float(np.abs(preds - ref).max() / np.abs(ref).max())
+    with open(os.path.join(ROOT, "gpurun_out", "test_report.txt"), "a") as f:
+        f.write("demo_vs_reference_demo: rel=%.3e pred=%s\n" % (err, np.array2string(preds, precision=5)))
+    assert err < 1e-4

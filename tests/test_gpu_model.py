@@ -223,6 +223,92 @@ def test_pairs_are_independent_at_full_batch(model):
         assert torch.equal(full[b], full[int((src == src[b]).nonzero()[0])])      # identical pairs -> identical bits
 
 
+def test_full_size_backward_config3(model, states):
+    """BASELINE.json configs[2] (fwd+bwd, 64 pairs per GPU) through the hot path, as a property AND an oracle check.
+    The batch is 4 distinct pairs, each replicated 16 times (interleaved), with one cotangent per distinct pair:
+      * pair independence: the token gradients of the 16 copies of a pair are bit-identical;
+      * linearity in the batch: every parameter gradient equals 16 x the fp64 oracle's gradient on the 4 distinct pairs
+        (<= 1e-3 of max|ref| per tensor -- the split-K / XCD-remap / tile choices all differ from the 4-pair launches)."""
+    _, sd64 = states
+    B, R = 64, 16
+    model.train()
+    try:
+        tok = O.synthetic_tokens(8, key=640)
+        Gs4 = torch.tensor([0, 0, 0, 0, 0, 0, 1.0]).repeat(4, 2, 1)
+        intr4 = torch.tensor([[30.0, 27.0, 12.0, 11.5]]).repeat(4, 2, 1).contiguous()
+        cot4 = O.closed_form((4, 2, 7), 6464, 1.0, dtype=torch.float64)
+        sd, gtok, ref = _oracle_grads(sd64, tok.double(), intr4.double(), cot4, True, Gs4.double())
+        src = torch.arange(B) % 4                                      # pair b is a copy of distinct pair b % 4
+        fm8 = tok.permute(0, 2, 1).contiguous().view(4, 2, 192, 24, 24)
+        fmap = fm8[src].reshape(2 * B, 192, 24, 24).contiguous().cuda().requires_grad_(True)
+        for p in model.parameters():
+            p.grad = None
+        out = model.forward_tokens(fmap, Gs4[src].cuda(), intr4[src].contiguous().cuda())
+        (out * cot4[src].float().cuda()).sum().backward()
+        assert torch.isfinite(out).all()
+        t_err, q_err, ang = O.pose_errors(out[:4].detach().cpu(), ref.detach())
+        g = fmap.grad.view(B, 2, 192, 576)
+        for b in range(4, B):
+            assert torch.equal(g[b], g[b % 4]), "pair %d is a copy of pair %d but its token gradient differs" % (b, b % 4)
+        e_tok = rel(g[:4].reshape(8, 192, 576).permute(0, 2, 1), gtok)
+        worst = {"tokens": e_tok}
+        for name, p in model.named_parameters():
+            if name.startswith("fusion_transformer") or name.startswith("pose_regressor"):
+                assert p.grad is not None, name
+                worst[name] = rel(p.grad, R * sd[name].grad)
+        report("config3_backward_64pairs", t=t_err, q=q_err, max_grad=max(worst.values()), tokens=e_tok)
+        bad = {k: v for k, v in worst.items() if v > 1e-3}
+        assert max(t_err, q_err) < 1e-4 and not bad, bad
+    finally:
+        model.eval()
+
+
+def test_interiornet_shaped_input_fwd_bwd(model):
+    """configs[2] uses InteriorNet frames: 256x256 on disk, resized by the reader to 384x512 (src/data_readers/base.py:20,28,
+    augmentation.py:37) -- a non-square input whose intrinsics rescale differently per axis.  End to end (CNN + hot path +
+    geodesic loss) at that shape: finite loss, finite gradients on every trainable tensor, intrinsics mutated as the
+    reference does (src/model.py:100-109), and the same pairs give the same poses inside a bigger batch."""
+    from rel_pose_amd.losses import geodesic_loss
+    from rel_pose_amd.se3 import SE3
+    B, H, W = 6, 384, 512
+    g = torch.Generator().manual_seed(11)
+    imgs = torch.floor(torch.rand(B, 2, 3, H, W, generator=g) * 255.0).cuda()
+    q = torch.randn(B, 4, generator=g)
+    q = q / q.norm(dim=1, keepdim=True) * torch.sign(q[:, 3:4] + 1e-9)
+    poses = torch.zeros(B, 2, 7)
+    poses[:, :, 6] = 1.0
+    poses[:, 1] = torch.cat([torch.rand(B, 3, generator=g) * 2 - 1, q], 1)
+    intr = (torch.tensor([[600.0, 600.0, 320.0, 240.0]]) * torch.tensor([W / 640.0, H / 480.0, W / 640.0, H / 480.0])).repeat(B, 2, 1)
+    Ps = SE3(poses.cuda())
+    Gs = SE3.IdentityLike(Ps)
+    model.train()
+    try:
+        for p in model.parameters():
+            p.grad = None
+        it = intr.clone().cuda()
+        est = model(imgs, Gs, intrinsics=it)
+        ltr, lrot, _ = geodesic_loss(Ps, est)
+        (10.0 * ltr + 10.0 * lrot).backward()
+        assert torch.isfinite(ltr) and torch.isfinite(lrot)
+        want = intr.clone()
+        want[..., 0] *= 24.0 / W; want[..., 2] *= 24.0 / W; want[..., 1] *= 24.0 / H; want[..., 3] *= 24.0 / H
+        assert torch.equal(it.cpu(), want)                       # caller's tensor rescaled in place, per axis
+        n_grad = 0
+        for name, p in model.named_parameters():
+            if name.startswith("resnet.layer3") or name.startswith("resnet.layer4") or name.startswith("resnet.fc"):
+                continue
+            assert p.grad is not None and torch.isfinite(p.grad).all(), name
+            n_grad += 1
+        assert n_grad > 100
+    finally:
+        model.eval()
+    with torch.no_grad():
+        full = model(imgs, Gs, intrinsics=intr.clone().cuda())[0].data
+        part = model(imgs[:2].contiguous(), SE3(Gs.data[:2].contiguous()), intrinsics=intr[:2].clone().cuda())[0].data
+    report("interiornet_shape", batch_vs_subbatch=rel(full[:2], part))
+    assert rel(full[:2], part) < 1e-4 and full.shape == (B, 2, 7)
+
+
 VARIANTS = {"l1": dict(l1_pos_encoding=True), "single": dict(use_single_softmax=True), "cross": dict(cross_features=True),
             "all3": dict(l1_pos_encoding=True, use_single_softmax=True, cross_features=True)}
 

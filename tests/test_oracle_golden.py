@@ -219,3 +219,50 @@ def test_noess_fp32_and_full_model(golden_noess, states_noess):
         assert rel(pose64, golden_noess["noess_full_sq_pose_f64"]) < 1e-7
         pose32, _ = O.vit_ess_forward(sd32, imgs, Gs, intr.clone(), noess=True)
         assert rel(pose32, golden_noess["noess_full_sq_pose_f32"]) < 1e-3
+
+
+# ---- BASELINE configs[0]: demo.py plumbing, pinned to the reference's own demo.py run on its demo images ----
+DEMO = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _demo_inputs():
+    import demo
+    return demo, [os.path.join(DEMO, "demo", "matterport_%d.png" % i) for i in (1, 2)]
+
+
+def test_demo_png_decode_and_tensor_assembly_bit_exact():
+    """The stdlib PNG reader (cv2 is absent) decodes the reference's 640x480 RGBA demo images to exactly what cv2.imread
+    gives (BGR, alpha dropped), and the [1,2,3,384,512] tensor demo.py assembles from them (demo.py:65-76, nearest resize)
+    equals the one the reference's demo.py built, sample for sample."""
+    from PIL import Image
+    demo, paths = _demo_inputs()
+    for pth in paths:
+        im = Image.open(pth)
+        assert im.mode == "RGBA" and im.size == (640, 480)
+        want = np.asarray(im.convert("RGB"))[:, :, ::-1]
+        assert np.array_equal(demo.read_png_bgr(pth), want)
+    images = demo.load_pair(paths[0], paths[1], matterport=True)
+    ref = np.load(os.path.join(DEMO, "reference_demo.npz"))
+    assert tuple(images.shape) == (1, 2, 3, 384, 512)
+    assert np.array_equal(images[0, :, :, ::29, ::31].numpy(), ref["demo_matterport_images_sub"])
+
+
+def test_demo_pose_matches_reference_demo_run():
+    """Oracle forward on the demo pair with the closed-form checkpoint + demo.py's post-processing (x5 depth scale, quaternion
+    reorder [4,5,3,6]) reproduces the [7] vector printed by the reference's demo.py on the same inputs and weights."""
+    demo, paths = _demo_inputs()
+    ref = np.load(os.path.join(DEMO, "reference_demo.npz"))
+    shapes = dict(O.vit_param_shapes())
+    shapes.update(O.cnn_param_shapes())
+    sd32 = O.make_state(shapes, torch.float32)
+    images = demo.load_pair(paths[0], paths[1], matterport=True)
+    intr = torch.tensor([[[517.97, 517.97, 320, 240]] * 2], dtype=torch.float32)
+    Gs = torch.tensor([[[0, 0, 0, 0, 0, 0, 1.0]] * 2])
+    with torch.no_grad():
+        pose, _ = O.vit_ess_forward(sd32, images, Gs, intr)
+    raw = pose[0, 1].numpy()
+    assert np.abs(raw - ref["demo_matterport_raw7_f32"]).max() < 2e-4 * np.abs(ref["demo_matterport_raw7_f32"]).max()
+    got = demo.postprocess(raw, True)
+    assert np.abs(got - ref["demo_matterport_pred7_f32"]).max() < 2e-4 * np.abs(ref["demo_matterport_pred7_f32"]).max()
+    r = ref["demo_matterport_raw7_f32"]
+    assert np.array_equal(demo.postprocess(r, True), ref["demo_matterport_pred7_f32"])      # the index shuffle itself: exact

@@ -175,8 +175,9 @@ def main():
     graphed = train and args.graph
     if graphed:
         net = model                                                    # the graphs do their own single flat all-reduce
+    # fused=True: the reference's torch.optim.Adam update (train.py:69) as one multi-tensor kernel instead of ~10
     opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=5e-4, weight_decay=1e-5,
-                           capturable=graphed)
+                           capturable=graphed, fused=not graphed)
     images, poses, intr = synthetic_batch(args.batch, args.hw, dev, 1234 + rank)
     Ps = SE3(poses)
     Gs = SE3.IdentityLike(Ps)
@@ -205,6 +206,7 @@ def main():
             return net(images, Gs, intrinsics=intr.clone())[0].data
 
     ops.set_gemm_precision(PRECISIONS[args.precision])
+    ops.set_attention_precision(1 if args.precision == "bf16" else 0)      # configs[4]: bf16 MFMA attention / EMM GEMMs too
     timer = ops.KernelTimer([int(v) for v in args.timer_instance.split(",")])
     ops.TIMER = timer
     eager_step = step
@@ -263,7 +265,10 @@ def main():
         pairs = world * args.batch * args.steps
         traffic, traffic_src = None, None
         nl = PRECISIONS[args.precision]
-        kname = "gemm_kernel<%s, %d>" % (", ".join(args.timer_instance.split(",")), nl)
+        # exact-fp32 launches with whole 32-wide k-tiles run the LDS-DMA-staged kernel (csrc/gemm_dma.hip), the bf16-limb
+        # precisions the register-staged one (csrc/gemm.hip); same tiles, same template arguments
+        kname = ("gemm_dma_kernel<%s>" % ", ".join(args.timer_instance.split(",")) if nl == 0 and not os.environ.get("RP_GEMM_NO_DMA")
+                 else "gemm_kernel<%s, %d>" % (", ".join(args.timer_instance.split(",")), nl))
         # matrix-pipe ceiling of the timed kernel in ALGORITHMIC (2MNK) flops: the exact-fp32 MFMA peak, or the dense
         # bf16 MFMA peak divided by the limb products issued per fp32 product (6 for split3, 1 for bf16)
         peak = {0: FP32_MFMA_PEAK_TFLOPS, 3: BF16_MFMA_PEAK_TFLOPS / 6.0, 1: BF16_MFMA_PEAK_TFLOPS}[nl]
@@ -271,13 +276,13 @@ def main():
                      3: "dense bf16 MFMA peak 2500 TF / 6 limb products per fp32 multiply-add (v_mfma_f32_32x32x16_bf16); "
                         "the same kernel is %.2f of the 157.3 TF fp32-MFMA peak it replaces" % (achieved / FP32_MFMA_PEAK_TFLOPS),
                      1: "dense bf16 MFMA peak"}[nl]
-        tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")      # PMC passes cannot run inside the timed process:
+        tpath = os.path.join(ROOT, "profiles", "r2_traffic.json")      # PMC passes cannot run inside the timed process:
         if os.path.exists(tpath):                                     # tools/pmc_bench.sh measured this command's kernels
             with open(tpath) as f:
                 tj = json.load(f)
             ent = tj["kernels"].get(kname)
             if ent:
-                traffic, traffic_src = round(ent["hbm_bytes_per_launch"]), "profiles/r1_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE)"
+                traffic, traffic_src = round(ent["hbm_bytes_per_launch"]), "profiles/r2_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE)"
         rec = {
             "metric": METRIC, "value": round(pairs / el, 2), "unit": "image-pairs/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 3),
@@ -290,8 +295,9 @@ def main():
                        "parallelism": "dp%d" % world, "finite": finite,
                        "gemm_operand_precision": {0: "exact fp32 MFMA", 3: "fp32 operands split into 3 bf16 limbs, 6 limb "
                                                   "products on the bf16 MFMA pipe, fp32 accumulate (fp32-grade: measured "
-                                                  "error vs fp64 <= the fp32-MFMA kernel's)", 1: "bf16 operands, fp32 accumulate "
-                                                  "(Linear GEMMs only; attention/EMM stay fp32)"}[nl],
+                                                  "error vs fp64 <= the fp32-MFMA kernel's)", 1: "bf16 operands, fp32 accumulate: "
+                                                  "Linear GEMMs (rp_gemm precision 1) and the attention / EMM contractions "
+                                                  "(v_mfma_f32_32x32x16_bf16)"}[nl],
                        "launch": "HIP graph replay (fwd+loss+bwd | flat grad all-reduce | clip+Adam)" if graphed else "eager",
                        "hot_path_share": "ViT+EMM+regressor on HIP kernels; ResNet front-end on MIOpen (SURVEY 8f-1)"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1),

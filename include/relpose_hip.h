@@ -150,31 +150,35 @@ int rp_tokens_bwd(const float* dx, float* dfeat, int Z, int C, int N, void* stre
  * of k_xor for v (k_xor = 3: keys AND values from the partner image of the pair = the --noess cross attention,
  * vision_transformer.py:239-262; k_xor = 1 with stats_only: the EMM's S = q k_partner^T).  lse[z][h][i] = log sum_j exp(s_ij) saved
  * for the backward.  stats_only != 0: only lse is produced (v, o ignored) -- used for the row and
- * column normalisers of the dual softmax (vision_transformer.py:205-206). */
+ * column normalisers of the dual softmax (vision_transformer.py:205-206).
+ * bf16 (every attention / EMM entry point that takes it): 0 = exact fp32 MFMA operands (default, the parity path);
+ * 1 = the QK^T / PV / dS contractions run on v_mfma_f32_32x32x16_bf16 -- operands (q, k, v, P, dS, dO, X, W) rounded to bf16
+ * when they are formed, fp32 accumulation, fp32 softmax state, fp32 inputs and outputs: the "MFMA bf16 attention GEMMs" of
+ * BASELINE.json configs[4]. */
 int rp_attn_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int Z, int H, int ldq, int ldk,
-                int ldv, int ldo, int q_xor, int k_xor, float scale, int stats_only, void* stream);
+                int ldv, int ldo, int q_xor, int k_xor, float scale, int stats_only, int bf16, void* stream);
 /* delta[z][h][i] = sum_e dO[z][i][h*64+e] * O[z][i][h*64+e] */
 int rp_attn_bwd_delta(const float* dout, const float* o, float* delta, int Z, int H, int ld, void* stream);
 /* dq, dk, dv of the above (recompute-based, two deterministic passes) */
 int rp_attn_bwd(const float* q, const float* k, const float* v, const float* dout, const float* lse, const float* delta,
                 float* dq, float* dk, float* dv, int Z, int H, int ldq, int ldk, int ldv, int lddo, int lddq, int lddk,
-                int lddv, float scale, void* stream);
+                int lddv, float scale, int bf16, void* stream);
 /* same with the keys/values of problem z taken from image z ^ kv_xor (dk, dv are written at the rows of the image the
  * keys/values came from): backward of rp_attn_fwd(..., q_xor=0, k_xor=3, ...) when kv_xor = 1 */
 int rp_attn_bwd_cross(const float* q, const float* k, const float* v, const float* dout, const float* lse,
                       const float* delta, float* dq, float* dk, float* dv, int Z, int H, int ldq, int ldk, int ldv, int lddo,
-                      int lddq, int lddk, int lddv, float scale, int kv_xor, void* stream);
+                      int lddq, int lddk, int lddv, float scale, int kv_xor, int bf16, void* stream);
 /* the two passes of rp_attn_bwd separately (they are independent; the host overlaps them on two HIP streams) */
 int rp_attn_bwd_dkdv(const float* q, const float* k, const float* v, const float* dout, const float* lse,
                      const float* delta, float* dk, float* dv, int Z, int H, int ldq, int ldk, int ldv, int lddo, int lddk,
-                     int lddv, float scale, void* stream);
+                     int lddv, float scale, int bf16, void* stream);
 /* dK/dV pass that also stores ds[z][h][i][j] = scale * dS_ij ([Z,H,576,576] floats): dQ = ds K is then one batched rp_gemm per
  * head (M=576, N=64, K=576, b_layout 1) instead of the dQ pass, which would recompute S and dP (5 executed GEMMs instead of 7) */
 int rp_attn_bwd_dkdv_ds(const float* q, const float* k, const float* v, const float* dout, const float* lse,
                         const float* delta, float* dk, float* dv, float* ds, int Z, int H, int ldq, int ldk, int ldv, int lddo,
-                        int lddk, int lddv, float scale, void* stream);
+                        int lddk, int lddv, float scale, int bf16, void* stream);
 int rp_attn_bwd_dq(const float* q, const float* k, const float* v, const float* dout, const float* lse, const float* delta,
-                   float* dq, int Z, int H, int ldq, int ldk, int ldv, int lddo, int lddq, float scale, void* stream);
+                   float* dq, int Z, int H, int ldq, int ldk, int ldv, int lddo, int lddq, float scale, int bf16, void* stream);
 
 /* Quadratic positional features (closed form of get_positional_encodings, vision_transformer.py:90-158):
  * pos[b][n] = (p3^2, p4^2, p3 p4, p3, p4, 1), p3 = lin[n%24]*iy_b, p4 = lin[n/24]*ix_b,
@@ -197,7 +201,7 @@ int rp_emm_build_x_bwd(const float* dx, float* dqkv, int Z, int H, int ldqkv, vo
  *   single != 0 : use_single_softmax (:201-203), A = softmax(S,-1) (clse unused);
  *   x_left != 0 : cross_features (:218-220), F_z = X_left[z^1]^T A_z X_z  (x_left indexed like x). */
 int rp_emm_apply(const float* qkv, int ldqkv, const float* x, const float* x_left, const float* rlse, const float* clse,
-                 float* t_out, float* f_part, int Z, int H, float scale, int swap, int single, void* stream);
+                 float* t_out, float* f_part, int Z, int H, float scale, int swap, int single, int bf16, void* stream);
 int rp_emm_finalize(const float* f_part, float* g, int Z, int H, int ldg, void* stream);
 int rp_emm_finalize_bwd(const float* dg, float* df, int Z, int H, int ldg, void* stream); /* df[z][h][96][96] */
 /* rowdot: out[r] = sum_c a[r][c]*b[r][c], C = 96 */
@@ -207,16 +211,27 @@ int rp_rowdot96(const float* a, const float* b, float* out, long long rows, void
  * writes dqkv q-columns of image z^1 (swap==0) or k-columns of image z (swap!=0). */
 int rp_emm_grad(const float* qkv, int ldqkv, const float* x, const float* w, const float* rlse, const float* clse,
                 const float* rho, const float* gamma, float* dqkv, int Z, int H, float scale, int swap, int single,
-                void* stream);
+                int bf16, void* stream);
 /* the owner = query pass (swap = 0) that also stores ds[z][h][j][i] = scale * dS_ij ([Z,H,576,576] floats, key index major):
  * the key-side gradient dk_z = ds_z q_{z^1} is then a batched rp_gemm per head and pair parity instead of the swap = 1 pass */
 int rp_emm_grad_ds(const float* qkv, int ldqkv, const float* x, const float* w, const float* rlse, const float* clse,
                    const float* rho, const float* gamma, float* dqkv, float* ds, int Z, int H, float scale, int single,
-                   void* stream);
+                   int bf16, void* stream);
 
 /* q / max(|q|, 0.01), slot 0 <- Gs  (normalize_preds, src/model.py:145-159) */
 int rp_pose_normalize_fwd(const float* pred, const float* gs, float* out, int B, void* stream);
 int rp_pose_normalize_bwd(const float* pred, const float* dout, float* dpred, int B, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Essential-matrix auxiliary (BASELINE.json north_star: "per-pair 3x3 SVD as a one-warp Jacobi sweep with no MFMA").
+ * NOT on ViTEss.forward's output path: the reference regresses R,t and never decomposes a matrix (src/model.py:91-98,
+ * 145-159), so parity forbids an SVD there.  Offered for consumers of the predicted pose:
+ *   rp_essential_from_pose: E[n][3][3] = [t]x R(q) from poses [n][7] = (t, q xyzw); q is normalised internally.
+ *   rp_svd3x3: A[n][3][3] = U diag(S) V^T, S descending and non-negative, U and V orthogonal (U completed by cross
+ *     products when A is rank deficient, as an essential matrix is).  One lane per matrix, one-sided Jacobi, registers only.
+ * ------------------------------------------------------------------------------------------- */
+int rp_essential_from_pose(const float* pose, float* E, int n, void* stream);
+int rp_svd3x3(const float* A, float* U, float* S, float* V, int n, void* stream);
 
 #ifdef __cplusplus
 }

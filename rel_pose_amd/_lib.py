@@ -49,24 +49,26 @@ _SIGS = {
     "rp_tokens_fwd": (c_int, [P, P, P, I, I, I, P]),
     "rp_tokens_fwd_nhwc": (c_int, [P, P, P, I, I, I, P]),
     "rp_tokens_bwd": (c_int, [P, P, I, I, I, P]),
-    "rp_attn_fwd": (c_int, [P, P, P, P, P, I, I, I, I, I, I, I, I, F, I, P]),
+    "rp_attn_fwd": (c_int, [P, P, P, P, P, I, I, I, I, I, I, I, I, F, I, I, P]),
     "rp_attn_bwd_delta": (c_int, [P, P, P, I, I, I, P]),
-    "rp_attn_bwd": (c_int, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, P]),
-    "rp_attn_bwd_dkdv_ds": (c_int, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, F, P]),
-    "rp_attn_bwd_cross": (c_int, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, P]),
-    "rp_attn_bwd_dkdv": (c_int, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, F, P]),
-    "rp_attn_bwd_dq": (c_int, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, F, P]),
+    "rp_attn_bwd": (c_int, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, P]),
+    "rp_attn_bwd_dkdv_ds": (c_int, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, F, I, P]),
+    "rp_attn_bwd_cross": (c_int, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, I, P]),
+    "rp_attn_bwd_dkdv": (c_int, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, F, I, P]),
+    "rp_attn_bwd_dq": (c_int, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, F, I, P]),
     "rp_posenc": (c_int, [P, P, P, I, I, P]),
     "rp_emm_build_x": (c_int, [P, P, P, I, I, I, P]),
     "rp_emm_build_x_bwd": (c_int, [P, P, I, I, I, P]),
-    "rp_emm_apply": (c_int, [P, I, P, P, P, P, P, P, I, I, F, I, I, P]),
+    "rp_emm_apply": (c_int, [P, I, P, P, P, P, P, P, I, I, F, I, I, I, P]),
     "rp_emm_finalize": (c_int, [P, P, I, I, I, P]),
     "rp_emm_finalize_bwd": (c_int, [P, P, I, I, I, P]),
     "rp_rowdot96": (c_int, [P, P, P, L, P]),
-    "rp_emm_grad": (c_int, [P, I, P, P, P, P, P, P, P, I, I, F, I, I, P]),
-    "rp_emm_grad_ds": (c_int, [P, I, P, P, P, P, P, P, P, P, I, I, F, I, P]),
+    "rp_emm_grad": (c_int, [P, I, P, P, P, P, P, P, P, I, I, F, I, I, I, P]),
+    "rp_emm_grad_ds": (c_int, [P, I, P, P, P, P, P, P, P, P, I, I, F, I, I, P]),
     "rp_pose_normalize_fwd": (c_int, [P, P, P, I, P]),
     "rp_pose_normalize_bwd": (c_int, [P, P, P, I, P]),
+    "rp_essential_from_pose": (c_int, [P, P, I, P]),
+    "rp_svd3x3": (c_int, [P, P, P, P, I, P]),
 }
 EXPORTS = tuple(_SIGS)
 

@@ -54,10 +54,20 @@ RP_DEV void tile_sstore(float* s, int tid, const float4 (&r)[(512 + NT - 1) / NT
   }
 }
 
-// S^T tile: s[r] = sum_d Ks[kv = acc_row(r,hi)][d] * breg[q = l31][d]; breg[t] holds d = 32*hi + t
-RP_DEV f32x16 score_tile(const float* Ks, int l31, int hi, const float (&breg)[32]) {
+// S^T tile: s[r] = sum_d Ks[kv = acc_row(r,hi)][d] * breg[q = l31][d]; breg[t] holds d = 32*hi + t (fp32 mode) / bpk[c] = the
+// same 32 values as 4 x 8 bf16 (bf16 mode, see common.h)
+template <bool BF>
+RP_DEV f32x16 score_tile(const float* Ks, int l31, int hi, const float (&breg)[32], const bf16x8 (&bpk)[4]) {
   f32x16 s = zero16();
   const float* kr = Ks + l31 * KST + 32 * hi;
+  if (BF) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float4 x = ld4(kr + 8 * c), y = ld4(kr + 8 * c + 4);
+      s = mfma_bf(pack8(x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w), bpk[c], s);
+    }
+    return s;
+  }
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     const float4 kf = ld4(kr + 4 * c);
@@ -70,8 +80,24 @@ RP_DEV f32x16 score_tile(const float* Ks, int l31, int hi, const float (&breg)[3
 }
 
 // acc^T[d][owner] += sum_t Ts[t = acc_row(r,hi)][d] * p[r]   for the two 32-wide d blocks (row-pattern reads)
-template <int STRIDE>
+template <int STRIDE, bool BF>
 RP_DEV void accum_tile(const float* Ts, int l31, int hi, const f32x16& p, f32x16& o0, f32x16& o1) {
+  if (BF) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      float a0[8], a1[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float* vr = Ts + acc_row(8 * g + j, hi) * STRIDE + l31;
+        a0[j] = vr[0];
+        a1[j] = vr[32];
+      }
+      const bf16x8 pb = pack8(p[8 * g], p[8 * g + 1], p[8 * g + 2], p[8 * g + 3], p[8 * g + 4], p[8 * g + 5], p[8 * g + 6], p[8 * g + 7]);
+      o0 = mfma_bf(pack8(a0), pb, o0);
+      o1 = mfma_bf(pack8(a1), pb, o1);
+    }
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const float* vr = Ts + acc_row(r, hi) * STRIDE + l31;
@@ -98,6 +124,11 @@ RP_DEV void load_owner(const float* row_ptr, int hi, float mul, float (&reg)[32]
   }
 }
 
+RP_DEV void pack_owner(const float (&reg)[32], bf16x8 (&pk)[4]) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) pk[c] = pack8(&reg[8 * c]);
+}
+
 // Software-pipelined tile loop (one barrier per tile, two LDS buffers).  MFMA operands are fetched from LDS one phase
 // ahead of the MFMAs that consume them, so the matrix pipe never waits on a ds_read (the first version issued each
 // read right before its MFMA and exposed ~2000 cycles of LDS latency per 4096-cycle tile):
@@ -106,7 +137,7 @@ RP_DEV void load_owner(const float* row_ptr, int hi, float mul, float (&reg)[32]
 //   softmax  : VALU;  LDS reads: V[t] rows 8-15
 //   PV part 1: 16 MFMAs;  tile t+1 VGPRs -> LDS[other];  barrier;  LDS reads: K[t+1] first half
 //   PV part 2: 16 MFMAs (cover the K[t+1] read)
-template <int NW, bool STATS, int WPS>
+template <int NW, bool STATS, int WPS, bool BF>
 __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_kernel(AttnP p) {
   constexpr int NT = NW * 64;
   constexpr int NPF = (512 + NT - 1) / NT;
@@ -123,6 +154,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_kernel(AttnP p) {
 
   float qreg[32];
   load_owner(qb + (long long)(q0 + l31) * p.ldq, hi, p.scale * RP_LOG2E, qreg);   // scores in log2 units
+  bf16x8 qpk[4];
+  if (BF) pack_owner(qreg, qpk);
 
   f32x16 o0 = zero16(), o1 = zero16();
   float m = -INFINITY, l = 0.f;
@@ -160,6 +193,12 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_kernel(AttnP p) {
     }
     __builtin_amdgcn_sched_barrier(0);
     f32x16 s = zero16();
+    if (BF) {
+      s = mfma_bf(pack8(ka[0].x, ka[0].y, ka[0].z, ka[0].w, ka[1].x, ka[1].y, ka[1].z, ka[1].w), qpk[0], s);
+      s = mfma_bf(pack8(ka[2].x, ka[2].y, ka[2].z, ka[2].w, ka[3].x, ka[3].y, ka[3].z, ka[3].w), qpk[1], s);
+      s = mfma_bf(pack8(kb2[0].x, kb2[0].y, kb2[0].z, kb2[0].w, kb2[1].x, kb2[1].y, kb2[1].z, kb2[1].w), qpk[2], s);
+      s = mfma_bf(pack8(kb2[2].x, kb2[2].y, kb2[2].z, kb2[2].w, kb2[3].x, kb2[3].y, kb2[3].z, kb2[3].w), qpk[3], s);
+    } else {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       s = mfma32(ka[c].x, qreg[4 * c + 0], s);
@@ -173,6 +212,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_kernel(AttnP p) {
       s = mfma32(kb2[c].y, qreg[16 + 4 * c + 1], s);
       s = mfma32(kb2[c].z, qreg[16 + 4 * c + 2], s);
       s = mfma32(kb2[c].w, qreg[16 + 4 * c + 3], s);
+    }
     }
     float mx = s[0];
 #pragma unroll
@@ -201,10 +241,16 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_kernel(AttnP p) {
         o1[r] *= alpha;
       }
       __builtin_amdgcn_sched_barrier(0);
+      if (BF) {
+        const bf16x8 pb = pack8(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7]);
+        o0 = mfma_bf(pack8(va[0], va[2], va[4], va[6], va[8], va[10], va[12], va[14]), pb, o0);
+        o1 = mfma_bf(pack8(va[1], va[3], va[5], va[7], va[9], va[11], va[13], va[15]), pb, o1);
+      } else {
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         o0 = mfma32(va[2 * r], s[r], o0);
         o1 = mfma32(va[2 * r + 1], s[r], o1);
+      }
       }
     }
     if (more) {
@@ -222,10 +268,16 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_kernel(AttnP p) {
     }
     if (!STATS) {
       __builtin_amdgcn_sched_barrier(0);
+      if (BF) {
+        const bf16x8 pb = pack8(s[8], s[9], s[10], s[11], s[12], s[13], s[14], s[15]);
+        o0 = mfma_bf(pack8(vb_[0], vb_[2], vb_[4], vb_[6], vb_[8], vb_[10], vb_[12], vb_[14]), pb, o0);
+        o1 = mfma_bf(pack8(vb_[1], vb_[3], vb_[5], vb_[7], vb_[9], vb_[11], vb_[13], vb_[15]), pb, o1);
+      } else {
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         o0 = mfma32(vb_[2 * r], s[8 + r], o0);
         o1 = mfma32(vb_[2 * r + 1], s[8 + r], o1);
+      }
       }
     }
   }
@@ -255,7 +307,7 @@ struct AttnBwdP {
   float* ds;    // optional [Z][H][576 q][576 key]: scale * dS written by the dK/dV pass, so dQ = dS K is a plain batched GEMM
 };
 
-template <int NW, int WPS>
+template <int NW, int WPS, bool BF>
 __global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dkdv_kernel(AttnBwdP p) {
   constexpr int NT = NW * 64;
   constexpr int NPF = (512 + NT - 1) / NT;
@@ -276,6 +328,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dkdv_kernel(AttnBwdP p)
   float kreg[32], vreg[32];
   load_owner(p.k + ((long long)z * NTOK + k0 + l31) * p.ldk + h * 64, hi, p.scale * RP_LOG2E, kreg);   // scale*log2e folded into K
   load_owner(p.v + ((long long)z * NTOK + k0 + l31) * p.ldv + h * 64, hi, 1.0f, vreg);
+  bf16x8 kpk[4], vpk[4];
+  if (BF) { pack_owner(kreg, kpk); pack_owner(vreg, vpk); }
 
   f32x16 dv0 = zero16(), dv1 = zero16(), dk0 = zero16(), dk1 = zero16();
   float4 qpre[NPF], dpre[NPF];
@@ -295,8 +349,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dkdv_kernel(AttnBwdP p)
       tile_gload<NT>(dob + (long long)(t + 1) * 32 * p.lddo, p.lddo, tid, dpre);
       if (tid < 64) lpre = tid < 32 ? lseb[(t + 1) * 32 + tid] * RP_LOG2E : delb[(t + 1) * 32 + tid - 32];
     }
-    f32x16 s = score_tile(Qs[cur], l31, hi, kreg);     // rows = queries acc_row(r,hi), lane = key
-    f32x16 dp = score_tile(Ds[cur], l31, hi, vreg);
+    f32x16 s = score_tile<BF>(Qs[cur], l31, hi, kreg, kpk);     // rows = queries acc_row(r,hi), lane = key
+    f32x16 dp = score_tile<BF>(Ds[cur], l31, hi, vreg, vpk);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int qi = acc_row(r, hi);
@@ -309,8 +363,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dkdv_kernel(AttnBwdP p)
 #pragma unroll
       for (int r = 0; r < 16; ++r) dsb[(long long)acc_row(r, hi) * NTOK] = dp[r] * p.scale;
     }
-    accum_tile<KST>(Ds[cur], l31, hi, s, dv0, dv1);     // dV^T += dO^T P
-    accum_tile<KST>(Qs[cur], l31, hi, dp, dk0, dk1);    // dK^T += Q^T dS
+    accum_tile<KST, BF>(Ds[cur], l31, hi, s, dv0, dv1);     // dV^T += dO^T P
+    accum_tile<KST, BF>(Qs[cur], l31, hi, dp, dk0, dk1);    // dK^T += Q^T dS
     if (t + 1 < NTILE) {
       tile_sstore<NT, KST>(Qs[cur ^ 1], tid, qpre);
       tile_sstore<NT, KST>(Ds[cur ^ 1], tid, dpre);
@@ -322,7 +376,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dkdv_kernel(AttnBwdP p)
   store_ownerT(p.dk + ((long long)z * NTOK + k0 + l31) * p.lddk + h * 64, hi, dk0, dk1, p.scale);
 }
 
-template <int NW, int WPS>
+template <int NW, int WPS, bool BF>
 __global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dq_kernel(AttnBwdP p) {
   constexpr int NT = NW * 64;
   constexpr int NPF = (512 + NT - 1) / NT;
@@ -339,6 +393,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dq_kernel(AttnBwdP p) {
   float qreg[32], dreg[32];
   load_owner(p.q + ((long long)z * NTOK + q0 + l31) * p.ldq + h * 64, hi, p.scale * RP_LOG2E, qreg);
   load_owner(p.dout + ((long long)z * NTOK + q0 + l31) * p.lddo + h * 64, hi, 1.0f, dreg);
+  bf16x8 qpk[4], dpk[4];
+  if (BF) { pack_owner(qreg, qpk); pack_owner(dreg, dpk); }
   const float lse = p.lse[((long long)z * p.H + h) * NTOK + q0 + l31] * RP_LOG2E;
   const float del = p.delta[((long long)z * p.H + h) * NTOK + q0 + l31];
 
@@ -355,11 +411,11 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dq_kernel(AttnBwdP p) {
       tile_gload<NT>(kb + (long long)(t + 1) * 32 * p.ldk, p.ldk, tid, kpre);
       tile_gload<NT>(vb + (long long)(t + 1) * 32 * p.ldv, p.ldv, tid, vpre);
     }
-    f32x16 s = score_tile(Ks[cur], l31, hi, qreg);     // S^T: rows = keys, lane = query
-    f32x16 dp = score_tile(Vs[cur], l31, hi, dreg);    // dP^T
+    f32x16 s = score_tile<BF>(Ks[cur], l31, hi, qreg, qpk);     // S^T: rows = keys, lane = query
+    f32x16 dp = score_tile<BF>(Vs[cur], l31, hi, dreg, dpk);    // dP^T
 #pragma unroll
     for (int r = 0; r < 16; ++r) dp[r] = fast_exp2(s[r] - lse) * (dp[r] - del);
-    accum_tile<KST>(Ks[cur], l31, hi, dp, dq0, dq1);    // dQ^T += K^T dS^T
+    accum_tile<KST, BF>(Ks[cur], l31, hi, dp, dq0, dq1);    // dQ^T += K^T dS^T
     if (t + 1 < NTILE) {
       tile_sstore<NT, KST>(Ks[cur ^ 1], tid, kpre);
       tile_sstore<NT, KST>(Vs[cur ^ 1], tid, vpre);
@@ -372,7 +428,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dq_kernel(AttnBwdP p) {
 }  // namespace
 
 extern "C" int rp_attn_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int Z, int H, int ldq,
-                           int ldk, int ldv, int ldo, int q_xor, int k_xor, float scale, int stats_only, void* stream) {
+                           int ldk, int ldv, int ldo, int q_xor, int k_xor, float scale, int stats_only, int bf16, void* stream) {
   if (Z <= 0 || H <= 0) return RP_EBADSHAPE;
   if ((q_xor & ~1) || (k_xor & ~3)) return RP_EBADSHAPE;   // k_xor: bit 0 = K from the partner image, bit 1 = V
   if ((q_xor || k_xor) && (Z & 1)) return RP_EBADSHAPE;
@@ -382,24 +438,28 @@ extern "C" int rp_attn_fwd(const float* q, const float* k, const float* v, float
   hipStream_t st = (hipStream_t)stream;
   const char* ov = getenv("RP_ATTN_FWD");   // tuning aid: "<NW><WPS>", e.g. "32"
   const int nw = ov ? ov[0] - '0' : 2, wps = ov ? ov[1] - '0' : 2;
-  if (stats_only) hipLaunchKernelGGL((attn_fwd_kernel<3, true, 2>), dim3(xcd_grid(NTILE / 3, Z * H)), dim3(192), 0, st, p);
-  else if (nw == 2) hipLaunchKernelGGL((attn_fwd_kernel<2, false, 2>), dim3(xcd_grid(NTILE / 2, Z * H)), dim3(128), 0, st, p);
-  else if (wps == 3) hipLaunchKernelGGL((attn_fwd_kernel<3, false, 3>), dim3(xcd_grid(NTILE / 3, Z * H)), dim3(192), 0, st, p);
-  else hipLaunchKernelGGL((attn_fwd_kernel<3, false, 2>), dim3(xcd_grid(NTILE / 3, Z * H)), dim3(192), 0, st, p);
+  const dim3 g3(xcd_grid(NTILE / 3, Z * H)), g2(xcd_grid(NTILE / 2, Z * H));
+  if (bf16) {
+    if (stats_only) hipLaunchKernelGGL((attn_fwd_kernel<3, true, 2, true>), g3, dim3(192), 0, st, p);
+    else hipLaunchKernelGGL((attn_fwd_kernel<2, false, 2, true>), g2, dim3(128), 0, st, p);
+  } else if (stats_only) hipLaunchKernelGGL((attn_fwd_kernel<3, true, 2, false>), g3, dim3(192), 0, st, p);
+  else if (nw == 2) hipLaunchKernelGGL((attn_fwd_kernel<2, false, 2, false>), g2, dim3(128), 0, st, p);
+  else if (wps == 3) hipLaunchKernelGGL((attn_fwd_kernel<3, false, 3, false>), g3, dim3(192), 0, st, p);
+  else hipLaunchKernelGGL((attn_fwd_kernel<3, false, 2, false>), g3, dim3(192), 0, st, p);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }
 
 // which: 1 = dK,dV pass, 2 = dQ pass, 3 = both (the passes are independent: callers may put them on different streams)
-template <int NW>
+template <int NW, bool BF>
 static int launch_bwd(const AttnBwdP& p, int Z, int H, int which, hipStream_t st) {
   dim3 grid(xcd_grid(NTILE / NW, Z * H));
   if (which & 1) {
-    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<NW, 2>), grid, dim3(NW * 64), 0, st, p);
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<NW, 2, BF>), grid, dim3(NW * 64), 0, st, p);
     RP_CHECK_LAUNCH();
   }
   if (which & 2) {
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<NW, 2>), grid, dim3(NW * 64), 0, st, p);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<NW, 2, BF>), grid, dim3(NW * 64), 0, st, p);
     RP_CHECK_LAUNCH();
   }
   return RP_OK;
@@ -407,42 +467,43 @@ static int launch_bwd(const AttnBwdP& p, int Z, int H, int which, hipStream_t st
 
 static int attn_bwd_impl(const float* q, const float* k, const float* v, const float* dout, const float* lse,
                          const float* delta, float* dq, float* dk, float* dv, int Z, int H, int ldq, int ldk, int ldv,
-                         int lddo, int lddq, int lddk, int lddv, float scale, int which, void* stream, int kv_xor = 0,
+                         int lddo, int lddq, int lddk, int lddv, float scale, int which, int bf16, void* stream, int kv_xor = 0,
                          float* ds = nullptr) {
   if (Z <= 0 || H <= 0 || (kv_xor & ~1) || (kv_xor && (Z & 1))) return RP_EBADSHAPE;
   if ((ldq | ldk | ldv | lddo | lddq | lddk | lddv) & 3) return RP_EALIGN;
   AttnBwdP p{q, k, v, dout, lse, delta, dq, dk, dv, H, ldq, ldk, ldv, lddo, lddq, lddk, lddv, scale, Z * H, kv_xor, ds};
   // both passes need ~190-240 VGPRs (2 waves/SIMD = 8 wave slots per CU): 2-wave workgroups pack 4 per CU, 3-wave ones only 2
+  if (bf16) return launch_bwd<2, true>(p, Z, H, which, (hipStream_t)stream);
   const char* ov = getenv("RP_ATTN_NW");
-  if (ov && ov[0] == '3') return launch_bwd<3>(p, Z, H, which, (hipStream_t)stream);
-  return launch_bwd<2>(p, Z, H, which, (hipStream_t)stream);
+  if (ov && ov[0] == '3') return launch_bwd<3, false>(p, Z, H, which, (hipStream_t)stream);
+  return launch_bwd<2, false>(p, Z, H, which, (hipStream_t)stream);
 }
 
 extern "C" int rp_attn_bwd(const float* q, const float* k, const float* v, const float* dout, const float* lse,
                            const float* delta, float* dq, float* dk, float* dv, int Z, int H, int ldq, int ldk, int ldv,
-                           int lddo, int lddq, int lddk, int lddv, float scale, void* stream) {
-  return attn_bwd_impl(q, k, v, dout, lse, delta, dq, dk, dv, Z, H, ldq, ldk, ldv, lddo, lddq, lddk, lddv, scale, 3, stream);
+                           int lddo, int lddq, int lddk, int lddv, float scale, int bf16, void* stream) {
+  return attn_bwd_impl(q, k, v, dout, lse, delta, dq, dk, dv, Z, H, ldq, ldk, ldv, lddo, lddq, lddk, lddv, scale, 3, bf16, stream);
 }
 extern "C" int rp_attn_bwd_cross(const float* q, const float* k, const float* v, const float* dout, const float* lse,
                                  const float* delta, float* dq, float* dk, float* dv, int Z, int H, int ldq, int ldk, int ldv,
-                                 int lddo, int lddq, int lddk, int lddv, float scale, int kv_xor, void* stream) {
-  return attn_bwd_impl(q, k, v, dout, lse, delta, dq, dk, dv, Z, H, ldq, ldk, ldv, lddo, lddq, lddk, lddv, scale, 3, stream,
+                                 int lddo, int lddq, int lddk, int lddv, float scale, int kv_xor, int bf16, void* stream) {
+  return attn_bwd_impl(q, k, v, dout, lse, delta, dq, dk, dv, Z, H, ldq, ldk, ldv, lddo, lddq, lddk, lddv, scale, 3, bf16, stream,
                        kv_xor);
 }
 extern "C" int rp_attn_bwd_dkdv(const float* q, const float* k, const float* v, const float* dout, const float* lse,
                                 const float* delta, float* dk, float* dv, int Z, int H, int ldq, int ldk, int ldv, int lddo,
-                                int lddk, int lddv, float scale, void* stream) {
-  return attn_bwd_impl(q, k, v, dout, lse, delta, nullptr, dk, dv, Z, H, ldq, ldk, ldv, lddo, 4, lddk, lddv, scale, 1, stream);
+                                int lddk, int lddv, float scale, int bf16, void* stream) {
+  return attn_bwd_impl(q, k, v, dout, lse, delta, nullptr, dk, dv, Z, H, ldq, ldk, ldv, lddo, 4, lddk, lddv, scale, 1, bf16, stream);
 }
 extern "C" int rp_attn_bwd_dkdv_ds(const float* q, const float* k, const float* v, const float* dout, const float* lse,
                                    const float* delta, float* dk, float* dv, float* ds, int Z, int H, int ldq, int ldk, int ldv,
-                                   int lddo, int lddk, int lddv, float scale, void* stream) {
+                                   int lddo, int lddk, int lddv, float scale, int bf16, void* stream) {
   if (!ds) return RP_EBADSHAPE;
-  return attn_bwd_impl(q, k, v, dout, lse, delta, nullptr, dk, dv, Z, H, ldq, ldk, ldv, lddo, 4, lddk, lddv, scale, 1, stream, 0,
-                       ds);
+  return attn_bwd_impl(q, k, v, dout, lse, delta, nullptr, dk, dv, Z, H, ldq, ldk, ldv, lddo, 4, lddk, lddv, scale, 1, bf16, stream,
+                       0, ds);
 }
 extern "C" int rp_attn_bwd_dq(const float* q, const float* k, const float* v, const float* dout, const float* lse,
                               const float* delta, float* dq, int Z, int H, int ldq, int ldk, int ldv, int lddo, int lddq,
-                              float scale, void* stream) {
-  return attn_bwd_impl(q, k, v, dout, lse, delta, dq, nullptr, nullptr, Z, H, ldq, ldk, ldv, lddo, lddq, 4, 4, scale, 2, stream);
+                              float scale, int bf16, void* stream) {
+  return attn_bwd_impl(q, k, v, dout, lse, delta, dq, nullptr, nullptr, Z, H, ldq, ldk, ldv, lddo, lddq, 4, 4, scale, 2, bf16, stream);
 }

@@ -17,6 +17,28 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 RP_DEV f32x16 mfma32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 
+// bf16 operand mode (BASELINE.json configs[4]: "bf16 with MFMA bf16 attention GEMMs"): v_mfma_f32_32x32x16_bf16, fp32
+// accumulate, SAME 32x32 accumulator layout as above.  A operand: lane l holds A[i = l&31][k-slots 8*(l>>5) .. +7] as 8 bf16,
+// B likewise -- so a run of 8 fp32 MFMA steps whose per-lane operands are a[0..7], b[0..7] (step t pairs a[t] with b[t] in
+// each half-wave) is ONE bf16 MFMA on pack8(a), pack8(b): every kernel keeps its fp32 data layout, LDS tiles and k-step
+// pairing and only regroups its operands.  Values are rounded to nearest-even (v_cvt_pk_bf16_f32).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+RP_DEV unsigned pk_bf16(float a, float b) {
+  bf16x2_t v;
+  v[0] = (__bf16)a;
+  v[1] = (__bf16)b;
+  return __builtin_bit_cast(unsigned, v);
+}
+RP_DEV bf16x8 pack8(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7) {
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  u32x4_t w;
+  w[0] = pk_bf16(a0, a1); w[1] = pk_bf16(a2, a3); w[2] = pk_bf16(a4, a5); w[3] = pk_bf16(a6, a7);
+  return __builtin_bit_cast(bf16x8, w);
+}
+RP_DEV bf16x8 pack8(const float* v) { return pack8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]); }
+RP_DEV f32x16 mfma_bf(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+
 // row of accumulator register r for half-wave hi
 RP_DEV constexpr int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 

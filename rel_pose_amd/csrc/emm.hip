@@ -55,9 +55,18 @@ RP_DEV void kv_sstore(float* s, int tid, const float4 (&r)[(512 + NTH - 1) / NTH
   }
 }
 
-RP_DEV f32x16 score_tile(const float* Ks, int l31, int hi, const float (&breg)[32]) {
+template <bool BF>
+RP_DEV f32x16 score_tile(const float* Ks, int l31, int hi, const float (&breg)[32], const bf16x8 (&bpk)[4]) {
   f32x16 s = zero16();
   const float* kr = Ks + l31 * KST + 32 * hi;
+  if (BF) {      // bf16 operand mode (common.h): 8 consecutive k-steps of a lane = one v_mfma_f32_32x32x16_bf16
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float4 x = ld4(kr + 8 * c), y = ld4(kr + 8 * c + 4);
+      s = mfma_bf(pack8(x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w), bpk[c], s);
+    }
+    return s;
+  }
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     const float4 kf = ld4(kr + 4 * c);
@@ -78,6 +87,7 @@ RP_DEV void load_owner(const float* row_ptr, int hi, float mul, float (&reg)[32]
 }
 
 // ------------------------------------------------------------------------------------------------
+template <bool BF>
 __global__ __launch_bounds__(NT, 3) void emm_apply_kernel(EmmP p) {
   // LDS carve: loop phase  Ks[2][32*68] | Xs[2][32*96] | Cl[2][32]   (10560 floats)
   //            F phase     Ts[96][96]                                   ( 9216 floats, aliases the above)
@@ -101,6 +111,11 @@ __global__ __launch_bounds__(NT, 3) void emm_apply_kernel(EmmP p) {
 
   float oreg[32];
   load_owner(p.qkv + ((long long)own_img * NTOK + o0 + l31) * p.ld + own_col, hi, p.scale * RP_LOG2E, oreg);
+  bf16x8 opk[4];
+  if (BF) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) opk[c] = pack8(&oreg[8 * c]);
+  }
   const float ls_o = own_lse[o0 + l31] * RP_LOG2E;
 
   f32x16 tacc[3] = {zero16(), zero16(), zero16()};
@@ -129,7 +144,7 @@ __global__ __launch_bounds__(NT, 3) void emm_apply_kernel(EmmP p) {
       x_gload(t + 1);
       if (tid < 32) cpre = loop_lse[(t + 1) * 32 + tid] * RP_LOG2E;
     }
-    f32x16 s = score_tile(Ks + cur * 32 * KST, l31, hi, oreg);   // S^T[loop][owner]
+    f32x16 s = score_tile<BF>(Ks + cur * 32 * KST, l31, hi, oreg, opk);   // S^T[loop][owner]
     const float* cl = Cl + cur * 32;
     const float* xs = Xs + cur * 32 * XW;
 #pragma unroll
@@ -139,12 +154,28 @@ __global__ __launch_bounds__(NT, 3) void emm_apply_kernel(EmmP p) {
       s[r] = p.single ? fast_exp2(s[r] - (p.swap ? ll : ls_o)) : fast_exp2(2.0f * s[r] - ls_o - ll);
     }
     // T[owner][c] += sum_loop A[owner][loop] X[loop][c] : A operand = s (lane = owner), B operand = X rows
+    if (BF) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        float b0[8], b1[8], b2[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float* xr = xs + acc_row(8 * g + j, hi) * XW + l31;
+          b0[j] = xr[0]; b1[j] = xr[32]; b2[j] = xr[64];
+        }
+        const bf16x8 ap = pack8(s[8 * g], s[8 * g + 1], s[8 * g + 2], s[8 * g + 3], s[8 * g + 4], s[8 * g + 5], s[8 * g + 6], s[8 * g + 7]);
+        tacc[0] = mfma_bf(ap, pack8(b0), tacc[0]);
+        tacc[1] = mfma_bf(ap, pack8(b1), tacc[1]);
+        tacc[2] = mfma_bf(ap, pack8(b2), tacc[2]);
+      }
+    } else {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float* xr = xs + acc_row(r, hi) * XW + l31;
       tacc[0] = mfma32(s[r], xr[0], tacc[0]);
       tacc[1] = mfma32(s[r], xr[32], tacc[1]);
       tacc[2] = mfma32(s[r], xr[64], tacc[2]);
+    }
     }
     if (t + 1 < NTILE) {
       kv_sstore<NT>(Ks + (cur ^ 1) * 32 * KST, tid, kpre);
@@ -173,6 +204,23 @@ __global__ __launch_bounds__(NT, 3) void emm_apply_kernel(EmmP p) {
   f32x16 facc[3] = {zero16(), zero16(), zero16()};
   const float* xlb = p.x_left ? p.x_left + ((long long)(z ^ 1) * p.H + h) * NTOK * XW : xb;
   const float* xa = xlb + (long long)wg0 * XW + 32 * wave + l31;   // column a = 32*wave + l31 of the LEFT operand's rows
+  if (BF) {
+#pragma unroll 2
+    for (int g = 0; g < 6; ++g) {
+      float av[8], b0[8], b1[8], b2[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = 48 * hi + 8 * g + j;
+        av[j] = xa[(long long)i * XW];
+        const float* tr = Ts + i * XW + l31;
+        b0[j] = tr[0]; b1[j] = tr[32]; b2[j] = tr[64];
+      }
+      const bf16x8 ap = pack8(av);
+      facc[0] = mfma_bf(ap, pack8(b0), facc[0]);
+      facc[1] = mfma_bf(ap, pack8(b1), facc[1]);
+      facc[2] = mfma_bf(ap, pack8(b2), facc[2]);
+    }
+  } else {
 #pragma unroll 4
   for (int t = 0; t < 48; ++t) {
     const int i = 48 * hi + t;
@@ -181,6 +229,7 @@ __global__ __launch_bounds__(NT, 3) void emm_apply_kernel(EmmP p) {
     facc[0] = mfma32(av, tr[0], facc[0]);
     facc[1] = mfma32(av, tr[32], facc[1]);
     facc[2] = mfma32(av, tr[64], facc[2]);
+  }
   }
   float* fb = p.f_part + ((zh * (NTOK / (NW * 32)) + wgi) * XW + 32 * wave) * XW;
 #pragma unroll
@@ -195,6 +244,7 @@ constexpr int XGS = 76;      // LDS row stride for the X tile read along c with 
 
 // 2-wave workgroups: the kernel needs ~250 VGPRs (2 waves/SIMD = 8 wave slots per CU); 4 x 2 waves fill them, 2 x 3 do not
 constexpr int GW = 2, GT = GW * 64;
+template <bool BF>
 __global__ __launch_bounds__(GT, 2) void emm_grad_kernel(EmmP p) {
   __shared__ __attribute__((aligned(16))) float Ks[2][32 * KST];
   __shared__ __attribute__((aligned(16))) float Xs[2][32 * XGS];
@@ -225,6 +275,12 @@ __global__ __launch_bounds__(GT, 2) void emm_grad_kernel(EmmP p) {
     }
   }
   const float ls_o = own_lse[o0 + l31] * RP_LOG2E, g_o = own_g[o0 + l31];
+  bf16x8 opk[4], wpk[5];         // bf16 mode: the 36 W columns of this half-wave as 4 x 8 + (4 live + 4 zero)
+  if (BF) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { opk[c] = pack8(&oreg[8 * c]); wpk[c] = pack8(&wreg[8 * c]); }
+    wpk[4] = pack8(wreg[32], wreg[33], wreg[34], wreg[35], 0.f, 0.f, 0.f, 0.f);
+  }
 
   f32x16 d0 = zero16(), d1 = zero16();
   float4 kpre[(512 + GT - 1) / GT], xpre[(576 + GT - 1) / GT];
@@ -258,10 +314,19 @@ __global__ __launch_bounds__(GT, 2) void emm_grad_kernel(EmmP p) {
       x_gload(t + 1);
       if (tid < 64) lpre = tid < 32 ? loop_lse[(t + 1) * 32 + tid] * RP_LOG2E : loop_g[(t + 1) * 32 + tid - 32];
     }
-    f32x16 s = score_tile(Ks[cur], l31, hi, oreg);      // S^T[loop][owner]
+    f32x16 s = score_tile<BF>(Ks[cur], l31, hi, oreg, opk);      // S^T[loop][owner]
     f32x16 da = zero16();                                // dA^T[loop][owner] = sum_c X[loop][c] W[owner][c]
     {
       const float* xr = Xs[cur] + l31 * XGS + 36 * hi;
+      if (BF) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float4 x = ld4(xr + 8 * c), y = ld4(xr + 8 * c + 4);
+          da = mfma_bf(pack8(x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w), wpk[c], da);
+        }
+        const float4 x = ld4(xr + 32);        // columns 32..35 of this half; the other four k-slots are explicit zeros
+        da = mfma_bf(pack8(x.x, x.y, x.z, x.w, 0.f, 0.f, 0.f, 0.f), wpk[4], da);
+      } else {
 #pragma unroll
       for (int c = 0; c < 9; ++c) {
         const float4 xf = ld4(xr + 4 * c);
@@ -269,6 +334,7 @@ __global__ __launch_bounds__(GT, 2) void emm_grad_kernel(EmmP p) {
         da = mfma32(xf.y, wreg[4 * c + 1], da);
         da = mfma32(xf.z, wreg[4 * c + 2], da);
         da = mfma32(xf.w, wreg[4 * c + 3], da);
+      }
       }
     }
 #pragma unroll
@@ -289,11 +355,27 @@ __global__ __launch_bounds__(GT, 2) void emm_grad_kernel(EmmP p) {
       for (int r = 0; r < 16; ++r) dsb[(long long)acc_row(r, hi) * NTOK] = s[r] * p.scale;
     }
     // d owner^T[d][owner] += sum_loop other[loop][d] dS^T[loop][owner]
+    if (BF) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        float a0[8], a1[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float* kr = Ks[cur] + acc_row(8 * g + j, hi) * KST + l31;
+          a0[j] = kr[0];
+          a1[j] = kr[32];
+        }
+        const bf16x8 pb = pack8(s[8 * g], s[8 * g + 1], s[8 * g + 2], s[8 * g + 3], s[8 * g + 4], s[8 * g + 5], s[8 * g + 6], s[8 * g + 7]);
+        d0 = mfma_bf(pack8(a0), pb, d0);
+        d1 = mfma_bf(pack8(a1), pb, d1);
+      }
+    } else {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float* kr = Ks[cur] + acc_row(r, hi) * KST + l31;
       d0 = mfma32(kr[0], s[r], d0);
       d1 = mfma32(kr[32], s[r], d1);
+    }
     }
     if (t + 1 < NTILE) {
       kv_sstore<GT>(Ks[cur ^ 1], tid, kpre);
@@ -314,39 +396,41 @@ __global__ __launch_bounds__(GT, 2) void emm_grad_kernel(EmmP p) {
 
 extern "C" int rp_emm_apply(const float* qkv, int ldqkv, const float* x, const float* x_left, const float* rlse,
                             const float* clse, float* t_out, float* f_part, int Z, int H, float scale, int swap,
-                            int single, void* stream) {
+                            int single, int bf16, void* stream) {
   if (Z <= 0 || (Z & 1) || H <= 0 || (ldqkv & 3)) return RP_EBADSHAPE;
   if (swap && f_part) return RP_EUNSUPPORTED;
   EmmP p{};
   p.qkv = qkv; p.ld = ldqkv; p.x = x; p.rlse = rlse; p.clse = clse; p.t_out = t_out; p.f_part = f_part;
   p.H = H; p.scale = scale; p.swap = swap ? 1 : 0; p.ZH = Z * H; p.single = single ? 1 : 0; p.x_left = x_left;
-  hipLaunchKernelGGL(emm_apply_kernel, dim3(xcd_grid(NTILE / NW, Z * H)), dim3(NT), 0, (hipStream_t)stream, p);
+  if (bf16) hipLaunchKernelGGL(emm_apply_kernel<true>, dim3(xcd_grid(NTILE / NW, Z * H)), dim3(NT), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(emm_apply_kernel<false>, dim3(xcd_grid(NTILE / NW, Z * H)), dim3(NT), 0, (hipStream_t)stream, p);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }
 
 static int emm_grad_impl(const float* qkv, int ldqkv, const float* x, const float* w, const float* rlse, const float* clse,
                          const float* rho, const float* gamma, float* dqkv, float* ds, int Z, int H, float scale, int swap,
-                         int single, void* stream) {
+                         int single, int bf16, void* stream) {
   if (Z <= 0 || (Z & 1) || H <= 0 || (ldqkv & 3)) return RP_EBADSHAPE;
   if (ds && swap) return RP_EUNSUPPORTED;
   EmmP p{};
   p.qkv = qkv; p.ld = ldqkv; p.x = x; p.w = w; p.rlse = rlse; p.clse = clse; p.rho = rho; p.gamma = gamma;
   p.dqkv = dqkv; p.H = H; p.scale = scale; p.swap = swap ? 1 : 0; p.ZH = Z * H; p.single = single ? 1 : 0; p.ds = ds;
-  hipLaunchKernelGGL(emm_grad_kernel, dim3(xcd_grid(NTILE / GW, Z * H)), dim3(GT), 0, (hipStream_t)stream, p);
+  if (bf16) hipLaunchKernelGGL(emm_grad_kernel<true>, dim3(xcd_grid(NTILE / GW, Z * H)), dim3(GT), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(emm_grad_kernel<false>, dim3(xcd_grid(NTILE / GW, Z * H)), dim3(GT), 0, (hipStream_t)stream, p);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }
 
 extern "C" int rp_emm_grad(const float* qkv, int ldqkv, const float* x, const float* w, const float* rlse,
                            const float* clse, const float* rho, const float* gamma, float* dqkv, int Z, int H,
-                           float scale, int swap, int single, void* stream) {
-  return emm_grad_impl(qkv, ldqkv, x, w, rlse, clse, rho, gamma, dqkv, nullptr, Z, H, scale, swap, single, stream);
+                           float scale, int swap, int single, int bf16, void* stream) {
+  return emm_grad_impl(qkv, ldqkv, x, w, rlse, clse, rho, gamma, dqkv, nullptr, Z, H, scale, swap, single, bf16, stream);
 }
 
 extern "C" int rp_emm_grad_ds(const float* qkv, int ldqkv, const float* x, const float* w, const float* rlse,
                               const float* clse, const float* rho, const float* gamma, float* dqkv, float* ds, int Z, int H,
-                              float scale, int single, void* stream) {
+                              float scale, int single, int bf16, void* stream) {
   if (!ds) return RP_EBADSHAPE;
-  return emm_grad_impl(qkv, ldqkv, x, w, rlse, clse, rho, gamma, dqkv, ds, Z, H, scale, 0, single, stream);
+  return emm_grad_impl(qkv, ldqkv, x, w, rlse, clse, rho, gamma, dqkv, ds, Z, H, scale, 0, single, bf16, stream);
 }

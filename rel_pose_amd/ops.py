@@ -64,6 +64,16 @@ def set_gemm_precision(p):
     GEMM_PRECISION = p
 
 
+# operand precision of the attention / EMM contractions (rp_attn_*, rp_emm_*: the `bf16` argument): 0 exact fp32 MFMA (default,
+# the parity path), 1 bf16 operands on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- BASELINE.json configs[4]
+ATTN_BF16 = 1 if os.environ.get("RP_ATTN_BF16", "0") == "1" else 0
+
+
+def set_attention_precision(bf16):
+    global ATTN_BF16
+    ATTN_BF16 = 1 if bf16 else 0
+
+
 def gemm_tile(M, N, a_layout, b_layout, reads_mn=False, precision=None):
     """(TM, TN) that rp_gemm picks (mirrors csrc/gemm.hip)."""
     precision = GEMM_PRECISION if precision is None else precision
@@ -298,7 +308,7 @@ def attn_fwd(qkv, Z, stats_only=False, q_off=0, k_off=DIM, v_off=2 * DIM, q_xor=
     base = qkv.data_ptr()
     P = ctypes.c_void_p
     _lib.check(lib.rp_attn_fwd(P(base + 4 * q_off), P(base + 4 * k_off), P(base + 4 * v_off), _p(o), _p(lse), Z, HEADS,
-                               ld, ld, ld, DIM, q_xor, k_xor, (DIM // HEADS) ** -0.5, 1 if stats_only else 0, _st()),
+                               ld, ld, ld, DIM, q_xor, k_xor, (DIM // HEADS) ** -0.5, 1 if stats_only else 0, ATTN_BF16, _st()),
                "rp_attn_fwd")
     return o, lse
 
@@ -322,7 +332,7 @@ def attn_bwd(qkv, o, lse, do, Z, fork=None, kv_xor=0):
     sc = (DIM // HEADS) ** -0.5
     if kv_xor:
         _lib.check(lib.rp_attn_bwd_cross(P(b), P(b + 4 * DIM), P(b + 8 * DIM), _p(do), _p(lse), _p(delta), P(d),
-                                         P(d + 4 * DIM), P(d + 8 * DIM), Z, HEADS, ld, ld, ld, DIM, ld, ld, ld, sc, 1, _st()),
+                                         P(d + 4 * DIM), P(d + 8 * DIM), Z, HEADS, ld, ld, ld, DIM, ld, ld, ld, sc, 1, ATTN_BF16, _st()),
                    "rp_attn_bwd_cross")
         return dqkv
     if ATTN_BWD_STORE_DS and (fork is None or not fork.enabled):
@@ -330,7 +340,7 @@ def attn_bwd(qkv, o, lse, do, Z, fork=None, kv_xor=0):
         # instead of 7 (the dQ pass would recompute S and dP) for 2 x 510 MB of extra HBM traffic
         ds = _empty(Z, HEADS, N_TOK, N_TOK, like=qkv)
         _lib.check(lib.rp_attn_bwd_dkdv_ds(P(b), P(b + 4 * DIM), P(b + 8 * DIM), _p(do), _p(lse), _p(delta), P(d + 4 * DIM),
-                                           P(d + 8 * DIM), _p(ds), Z, HEADS, ld, ld, ld, DIM, ld, ld, sc, _st()),
+                                           P(d + 8 * DIM), _p(ds), Z, HEADS, ld, ld, ld, DIM, ld, ld, sc, ATTN_BF16, _st()),
                    "rp_attn_bwd_dkdv_ds")
         dsf, qf, df = ds.view(-1), qkv.view(-1), dqkv.view(-1)
         per = N_TOK * N_TOK
@@ -340,16 +350,16 @@ def attn_bwd(qkv, o, lse, do, Z, fork=None, kv_xor=0):
         return dqkv
     if fork is None or not fork.enabled:
         _lib.check(lib.rp_attn_bwd(P(b), P(b + 4 * DIM), P(b + 8 * DIM), _p(do), _p(lse), _p(delta), P(d), P(d + 4 * DIM),
-                                   P(d + 8 * DIM), Z, HEADS, ld, ld, ld, DIM, ld, ld, ld, sc, _st()), "rp_attn_bwd")
+                                   P(d + 8 * DIM), Z, HEADS, ld, ld, ld, DIM, ld, ld, ld, sc, ATTN_BF16, _st()), "rp_attn_bwd")
         return dqkv
     fork.sync_side()                                   # delta (and do, dqkv allocation) visible to the side stream
 
     def dq_pass():
         _lib.check(lib.rp_attn_bwd_dq(P(b), P(b + 4 * DIM), P(b + 8 * DIM), _p(do), _p(lse), _p(delta), P(d), Z, HEADS,
-                                      ld, ld, ld, DIM, ld, sc, _st()), "rp_attn_bwd_dq")
+                                      ld, ld, ld, DIM, ld, sc, ATTN_BF16, _st()), "rp_attn_bwd_dq")
     fork.on_side(dq_pass)
     _lib.check(lib.rp_attn_bwd_dkdv(P(b), P(b + 4 * DIM), P(b + 8 * DIM), _p(do), _p(lse), _p(delta), P(d + 4 * DIM),
-                                    P(d + 8 * DIM), Z, HEADS, ld, ld, ld, DIM, ld, ld, sc, _st()), "rp_attn_bwd_dkdv")
+                                    P(d + 8 * DIM), Z, HEADS, ld, ld, ld, DIM, ld, ld, sc, ATTN_BF16, _st()), "rp_attn_bwd_dkdv")
     return dqkv
 
 
@@ -412,7 +422,7 @@ def emm_apply(qkv, x, rlse, clse, Z, swap=False, want_t=True, want_f=True, singl
     t = _empty(Z, HEADS, N_TOK, XW, like=qkv) if want_t else None
     f = _empty(Z, HEADS, NWG, XW, XW, like=qkv) if (want_f and not swap) else None
     _lib.check(lib.rp_emm_apply(_p(qkv), qkv.shape[1], _p(x), _p(x_left), _p(rlse), _p(clse), _p(t), _p(f), Z, HEADS,
-                                (DIM // HEADS) ** -0.5, 1 if swap else 0, 1 if single else 0, _st()), "rp_emm_apply")
+                                (DIM // HEADS) ** -0.5, 1 if swap else 0, 1 if single else 0, ATTN_BF16, _st()), "rp_emm_apply")
     return t, f
 
 
@@ -470,7 +480,7 @@ def emm_backward(qkv, x, t, rlse, clse, df, Z, single=False, cross=False):
         # of a second pass that recomputes S and dA (68 of its 100 MFMAs per tile)
         ds = _empty(Z, HEADS, N_TOK, N_TOK, like=qkv)
         _lib.check(lib.rp_emm_grad_ds(_p(qkv), ld, _p(x), _p(w), _p(rlse), _p(clse), _p(rho), _p(gam), _p(dqkv), _p(ds), Z,
-                                      HEADS, scale, sg, _st()), "rp_emm_grad_ds")
+                                      HEADS, scale, sg, ATTN_BF16, _st()), "rp_emm_grad_ds")
         dsf, qf, df = ds.view(-1), qkv.view(-1), dqkv.view(-1)
         per, img = N_TOK * N_TOK, N_TOK * ld
         for h in range(HEADS):
@@ -480,9 +490,9 @@ def emm_backward(qkv, x, t, rlse, clse, df, Z, single=False, cross=False):
                      strides=(2 * HEADS * per, 2 * img, 2 * img))
     else:
         _lib.check(lib.rp_emm_grad(_p(qkv), ld, _p(x), _p(w), _p(rlse), _p(clse), _p(rho), _p(gam), _p(dqkv), Z, HEADS,
-                                   scale, 0, sg, _st()), "rp_emm_grad(q)")
+                                   scale, 0, sg, ATTN_BF16, _st()), "rp_emm_grad(q)")
         _lib.check(lib.rp_emm_grad(_p(qkv), ld, _p(xl), _p(wp), _p(rlse), _p(clse), _p(rho), _p(gam), _p(dqkv), Z, HEADS,
-                                   scale, 1, sg, _st()), "rp_emm_grad(k)")
+                                   scale, 1, sg, ATTN_BF16, _st()), "rp_emm_grad(k)")
     _lib.check(lib.rp_emm_build_x_bwd(_p(dx), _p(dqkv), Z, HEADS, ld, _st()), "rp_emm_build_x_bwd")
     return dqkv
 

@@ -480,3 +480,83 @@ def test_fused_batchnorm_statistics_are_cancellation_safe(ops):
     # x itself only carries ~6e-5 of absolute resolution at 1000, i.e. ~6e-3 of a 0.01 standard deviation
     assert float((y.cpu().double() - ref).abs().max()) < 2e-2
     assert rel(bn.running_var, 0.9 + 0.1 * xd.var((0, 2, 3), unbiased=True)) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ configs[4]: bf16 MFMA mode
+def test_attention_and_emm_bf16_operand_mode(ops):
+    """BASELINE.json configs[4] ("bf16 with MFMA bf16 attention GEMMs"): the `bf16` argument of rp_attn_* / rp_emm_* moves the
+    QK^T / PV / dS contractions to v_mfma_f32_32x32x16_bf16 (operands rounded to bf16, fp32 accumulate and softmax state).
+    Stated tolerance against the fp64 reference: 2e-2 of max|ref| forward, 4e-2 backward (bf16 carries 8 significant bits:
+    2^-9 per operand, ~1e-2 after the 64-term dot products and the exp; 6e-2 for the EMM, whose exponent is 2 S); the fp32 mode on the same inputs stays < 2e-5, and
+    the flag is process state that is switched back."""
+    Z = 4
+    qkv = rnd(Z * 576, 576, seed=1)
+    qkv[:, :384] *= 1.7
+    do = rnd(Z * 576, 192, seed=2)
+    q64 = qkv.double().requires_grad_(True)
+    o_ref, lse_ref, _ = _attn_ref(q64, Z)
+    (o_ref * do.double()).sum().backward()
+    pos = rnd(Z // 2, 576, 6, seed=4)
+    try:
+        ops.set_attention_precision(1)
+        o, lse = ops.attn_fwd(qkv, Z)
+        e_o, e_l = rel(o, o_ref), rel(lse, lse_ref)
+        errs = {}
+        for store_ds in (True, False):
+            keep, ops.ATTN_BWD_STORE_DS = ops.ATTN_BWD_STORE_DS, store_ds
+            try:
+                dqkv = ops.attn_bwd(qkv, o, lse, do, Z)
+            finally:
+                ops.ATTN_BWD_STORE_DS = keep
+            errs[store_ds] = max(rel(dqkv[:, i * 192:(i + 1) * 192], q64.grad[:, i * 192:(i + 1) * 192]) for i in range(3))
+        x = ops.emm_build_x(qkv, pos, Z)
+        rl, cl = ops.emm_stats(qkv, Z)
+        t, fpart = ops.emm_apply(qkv, x, rl, cl, Z)
+    finally:
+        ops.set_attention_precision(0)
+    report("attn_bf16", o=e_o, lse=e_l, bwd_ds=errs[True], bwd_recompute=errs[False])
+    assert 1e-5 < e_o < 2e-2 and e_l < 2e-2
+    assert max(errs.values()) < 4e-2
+    # EMM forward pieces against the fp32 kernels (themselves pinned to fp64 at 2e-6 by test_emm_forward_pieces)
+    t32, f32 = ops.emm_apply(qkv, x, rl, cl, Z)
+    e_t, e_f = rel(t, t32), rel(fpart.sum(2), f32.sum(2))
+    report("emm_bf16", T=e_t, F=e_f)
+    assert 1e-6 < e_t < 6e-2 and e_f < 6e-2            # the dual softmax exponent is 2 S: twice the score error of plain attention
+    o32, _ = ops.attn_fwd(qkv, Z)
+    assert rel(o32, o_ref) < 5e-6                       # back on the exact path
+
+
+# ------------------------------------------------------------------------------------------------ a16: 3x3 SVD auxiliary
+def test_svd3x3_and_essential_matrix_vs_lapack(ops):
+    """SURVEY row a16 / north_star: one-wavefront Jacobi 3x3 SVD, off the model's output path, pinned against LAPACK.
+    E = [t]x R(q) -> SVD round trip: singular values (s, s, 0) and equal to numpy.linalg.svd's (fp64), U S V^T = E,
+    U and V orthogonal; plus generic, rank-1 and zero matrices."""
+    from oracle import svd3x3_oracle as SO
+    from rel_pose_amd import geom
+    g = torch.Generator().manual_seed(3)
+    n = 1000                                               # not a multiple of 64: ragged last wavefront
+    pose = torch.randn(n, 7, generator=g)
+    pose[:, 3:] = pose[:, 3:] / pose[:, 3:].norm(dim=1, keepdim=True)
+    E = geom.essential_from_pose(pose.cuda())
+    E_ref = SO.essential_from_pose(pose.numpy())
+    assert rel(E, torch.from_numpy(E_ref)) < 2e-6
+    generic = torch.randn(n, 3, 3, generator=g)
+    rank1 = torch.randn(n, 3, 1, generator=g) @ torch.randn(n, 1, 3, generator=g)
+    zero = torch.zeros(4, 3, 3)
+    worst = {}
+    for tag, A in (("essential", E.cpu()), ("generic", generic), ("rank1", rank1), ("zero", zero)):
+        U, S, V = geom.svd3x3(A.cuda())
+        U, S, V = U.cpu().double(), S.cpu().double(), V.cpu().double()
+        s_ref = torch.from_numpy(SO.singular_values(A.numpy()))
+        scale = s_ref[:, :1].clamp_min(1e-30)
+        e_s = float(((S - s_ref).abs() / scale).max()) if tag != "zero" else float(S.abs().max())
+        rec = U @ torch.diag_embed(S) @ V.transpose(-1, -2)
+        e_rec = float(((rec - A.double()).abs().amax((1, 2)) / scale[:, 0]).max()) if tag != "zero" else float(rec.abs().max())
+        eye = torch.eye(3, dtype=torch.float64)
+        e_orth = max(float((U.transpose(-1, -2) @ U - eye).abs().max()), float((V.transpose(-1, -2) @ V - eye).abs().max()))
+        assert bool((S[:, 0] >= S[:, 1]).all() and (S[:, 1] >= S[:, 2]).all() and (S >= 0).all())
+        worst[tag] = max(e_s, e_rec, e_orth)
+        assert e_s < 3e-6 and e_rec < 3e-6 and e_orth < 3e-6, (tag, e_s, e_rec, e_orth)
+    U, S, V = geom.svd3x3(E)
+    assert float(((S[:, 0] - S[:, 1]).abs() / S[:, 0]).max()) < 3e-6 and float((S[:, 2] / S[:, 0]).max()) < 3e-6   # (s, s, 0)
+    report("svd3x3", **worst)

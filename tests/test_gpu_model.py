@@ -465,3 +465,44 @@ def test_bf16_operand_mode_is_a_different_precision(model, states):
     report("precision_modes", split3=errs[3], fp32=errs[0], bf16=errs[1])
     assert errs[3] < 1e-4 and errs[0] < 1e-4
     assert 1e-4 < errs[1] < 1e-1
+
+
+def test_bf16_configuration_at_128_pairs_per_gpu(model, states):
+    """BASELINE.json configs[4]: bf16 operands everywhere a GEMM runs -- rp_gemm precision 1 AND the bf16 MFMA mode of the
+    attention / EMM kernels -- at that configuration's per-GPU batch (1024 global / 8 = 128 pairs), forward and backward.
+    128 pairs = 4 distinct pairs x 32 copies.  Stated tolerance vs the fp64 oracle: R,t within 5e-2, token gradients within
+    2e-1 of max|ref| in the max norm (bf16 has 8 significant bits; forward + backward cross 12 block passes -- measured
+    1.4e-2 / 1.8e-2 / 1.1e-1); copies of a pair stay bit-identical
+    (the kernels are deterministic in this mode too)."""
+    from rel_pose_amd import ops
+    _, sd64 = states
+    B = 128
+    tok = O.synthetic_tokens(8, key=1280)
+    Gs4 = torch.tensor([0, 0, 0, 0, 0, 0, 1.0]).repeat(4, 2, 1)
+    intr4 = torch.tensor([[30.0, 27.0, 12.0, 11.5]]).repeat(4, 2, 1).contiguous()
+    cot4 = O.closed_form((4, 2, 7), 12800, 1.0, dtype=torch.float64)
+    sd, gtok, ref = _oracle_grads(sd64, tok.double(), intr4.double(), cot4, True, Gs4.double())
+    src = torch.arange(B) % 4
+    fm8 = tok.permute(0, 2, 1).contiguous().view(4, 2, 192, 24, 24)
+    fmap = fm8[src].reshape(2 * B, 192, 24, 24).contiguous().cuda().requires_grad_(True)
+    prev = ops.GEMM_PRECISION
+    model.train()
+    try:
+        ops.set_gemm_precision(1)
+        ops.set_attention_precision(1)
+        for p in model.parameters():
+            p.grad = None
+        out = model.forward_tokens(fmap, Gs4[src].cuda(), intr4[src].contiguous().cuda())
+        (out * cot4[src].float().cuda()).sum().backward()
+    finally:
+        ops.set_gemm_precision(prev)
+        ops.set_attention_precision(0)
+        model.eval()
+    assert torch.isfinite(out).all() and torch.isfinite(fmap.grad).all()
+    t_err, q_err, _ = O.pose_errors(out[:4].detach().cpu(), ref.detach())
+    g = fmap.grad.view(B, 2, 192, 576)
+    for b in range(4, B):
+        assert torch.equal(out[b], out[b % 4]) and torch.equal(g[b], g[b % 4])
+    e_tok = rel(g[:4].reshape(8, 192, 576).permute(0, 2, 1), gtok)
+    report("config5_bf16_128pairs", t=t_err, q=q_err, grad_tokens=e_tok)
+    assert 1e-5 < max(t_err, q_err) < 5e-2 and e_tok < 2e-1

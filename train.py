@@ -103,7 +103,7 @@ def run(args):
     for p in list(model.resnet.layer3.parameters()) + list(model.resnet.layer4.parameters()):
         p.requires_grad = False
     net = parallel.wrap(model, [local]) if ddp else model
-    opt = torch.optim.Adam(net.parameters(), lr=args.lr, weight_decay=args.weight_decay)
+    opt = torch.optim.Adam(net.parameters(), lr=args.lr, weight_decay=args.weight_decay, fused=True)    # same update, one kernel
     sched = torch.optim.lr_scheduler.OneCycleLR(opt, args.lr, args.steps, pct_start=min(0.99, args.warmup / args.steps),
                                                 div_factor=25, cycle_momentum=False)
     resume = args.ckpt or find_resume(args.name)

@@ -41,6 +41,94 @@ RP_DEV float epilogue(float v, int m, int n, const GemmP& p) {
 }
 
 
+// LDS-staged epilogue of one mode.  The accumulators (lane = column, register = row) are transposed through the wave's own LDS
+// region so that every global access -- C, bias, residual, GELU'/ReLU' aux, pre-activation copy -- is a 16-byte row segment
+// per lane (global_load/store_dwordx4) instead of 16*TM*TN dword accesses per lane (the dword store tail alone was 11 % of the
+// kernel).  Straight-line per mode: the bias segment and ALL [M,N] operand segments (residual / aux) of the lane's rows are
+// requested up front -- before the accumulators go to LDS -- and the stores then issue back to back.  (The first version
+// tested the mode per element group and waited vmcnt(0) after each operand load, i.e. also for the previous store: one
+// store -> load -> store round trip per row group, 8-12 per tile.)  Out-of-range rows / columns load from clamped addresses
+// and are masked at the store only, so edge tiles run the same code.
+template <int TM, int TN, int MODE>
+RP_DEV void staged_epilogue(const GemmP& p, f32x16 (&acc)[TM][TN], float* lds, int m0, int n0, int mt, float* C, int ldc,
+                            const float* bias, float* pre_out, const float* aux, const float* res, bool partial) {
+  constexpr int CST = 32 * TN + 4;
+  constexpr int C4 = 8 * TN;             // float4 per staged row
+  constexpr int NIT = (32 * TM * C4) / 64;
+  constexpr bool HAS_BIAS = MODE == EPI_BIAS || MODE == EPI_BIAS_RES || MODE == EPI_BIAS_GELU || MODE == EPI_BIAS_GELU_PRE ||
+                            MODE == EPI_BIAS_RELU;
+  constexpr bool HAS_RES = MODE == EPI_BIAS_RES || MODE == EPI_RES;
+  constexpr bool HAS_AUX = MODE == EPI_DGELU || MODE == EPI_DRELU;
+  constexpr bool LANE_COL = (64 % C4) == 0;          // a lane keeps its column group through the loop
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wm0 = (wave >> 1) * 32 * TM, wn0 = (wave & 1) * 32 * TN;
+  const float* mn = HAS_RES ? res : aux;
+  float4 b4[LANE_COL ? 1 : NIT], o4[(HAS_RES || HAS_AUX) ? NIT : 1];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int idx = lane + 64 * it;
+    const int row = idx / C4, c4 = idx % C4;
+    const int mc = min(m0 + wm0 + row, p.M - 1), nc = min(n0 + wn0 + 4 * c4, p.N - 4);
+    if (HAS_BIAS && (it == 0 || !LANE_COL)) b4[LANE_COL ? 0 : it] = ld4(bias + nc);
+    if (HAS_RES || HAS_AUX) o4[it] = ld4(mn + (long long)mc * ldc + nc);
+  }
+  float* cs = lds + wave * (32 * TM * CST);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cs[(32 * i + acc_row(r, hi)) * CST + 32 * j + l31] = acc[i][j][r];
+  __syncthreads();
+  float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);   // this lane's column sums of the final values (colsum_part != nullptr)
+  const bool want_cs = LANE_COL && p.colsum_part != nullptr && !partial;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int idx = lane + 64 * it;
+    const int row = idx / C4, c4 = idx % C4;
+    const int m = m0 + wm0 + row, n = n0 + wn0 + 4 * c4;
+    const bool ok = m < p.M && n < p.N;
+    float4 v = ld4(cs + row * CST + 4 * c4);
+    const long long off = (long long)m * ldc + n;
+    if (HAS_BIAS) {
+      const float4 b = b4[LANE_COL ? 0 : it];
+      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    }
+    if (MODE == EPI_BIAS_GELU_PRE && ok) st4(pre_out + off, v);
+    if (MODE == EPI_BIAS_GELU || MODE == EPI_BIAS_GELU_PRE) {
+      v.x = gelu_exact(v.x); v.y = gelu_exact(v.y); v.z = gelu_exact(v.z); v.w = gelu_exact(v.w);
+    } else if (MODE == EPI_BIAS_RELU) {
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    } else if (MODE == EPI_DGELU) {
+      const float4 a4 = o4[it];
+      v.x *= gelu_grad(a4.x); v.y *= gelu_grad(a4.y); v.z *= gelu_grad(a4.z); v.w *= gelu_grad(a4.w);
+    } else if (MODE == EPI_DRELU) {
+      const float4 a4 = o4[it];
+      v.x = a4.x > 0.f ? v.x : 0.f; v.y = a4.y > 0.f ? v.y : 0.f; v.z = a4.z > 0.f ? v.z : 0.f; v.w = a4.w > 0.f ? v.w : 0.f;
+    }
+    if (HAS_RES) {
+      const float4 r4 = o4[it];
+      v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+    }
+    if (ok) {
+      st4(C + off, v);
+      if (want_cs) { csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w; }
+    }
+  }
+  if (want_cs) {
+    // a lane keeps the same column group c4 = lane % C4 through the loop: fold the 64 / C4 lanes of each group, then lanes
+    // 0..C4-1 store one row of per-(tile, wave-row) column sums; a small rp_colsum over them finishes the bias gradient
+#pragma unroll
+    for (int o = 32; o >= C4; o >>= 1) {
+      csum.x += __shfl_xor(csum.x, o, 64); csum.y += __shfl_xor(csum.y, o, 64);
+      csum.z += __shfl_xor(csum.z, o, 64); csum.w += __shfl_xor(csum.w, o, 64);
+    }
+    const int n = n0 + wn0 + 4 * lane;
+    if (lane < C4 && n < p.N) st4(p.colsum_part + (long long)(2 * mt + (wave >> 1)) * p.N + n, csum);
+  }
+}
+
 // Tile epilogue.  acc: the wave's (32 TM) x (32 TN) accumulators (lane = column, register = row); lds: the workgroup's LDS
 // (>= 4 * 32 * TM * (32 TN + 4) floats when STAGED), free to overwrite; (m0, n0) tile origin, (mt) row-panel index,
 // zb / zid batch / split indices as in the kernels.
@@ -64,64 +152,17 @@ RP_DEV void tile_epilogue(const GemmP& p, f32x16 (&acc)[TM][TN], float* lds, int
   const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N);
 
   if (STAGED && (p.N & 3) == 0 && mode != EPI_GENERIC) {
-    // LDS-staged epilogue: the accumulators (lane = column, register = row) are transposed through the wave's own LDS
-    // region so that every global access of the epilogue -- C, bias, residual, GELU'/ReLU' aux, pre-activation copy -- is a
-    // 16-byte row segment per lane (global_load/store_dwordx4) instead of 16*TM*TN dword accesses per lane.  Ablation:
-    // the dword store tail alone was 11 % of the kernel; dword aux/residual loads serialised at 96 per lane.
-    float* cs = lds + wave * (32 * TM * CST);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) cs[(32 * i + acc_row(r, hi)) * CST + 32 * j + l31] = acc[i][j][r];
-    __syncthreads();
-    constexpr int C4 = 8 * TN;             // float4 per staged row
-    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);   // this lane's column sums of the final values (colsum_part != nullptr)
-    const bool want_cs = (64 % C4) == 0 && p.colsum_part != nullptr && !partial;
-#pragma unroll
-    for (int it = 0; it < (32 * TM * C4) / 64; ++it) {
-      const int idx = lane + 64 * it;
-      const int row = idx / C4, c4 = idx % C4;
-      const int m = m0 + wm0 + row, n = n0 + wn0 + 4 * c4;
-      if ((interior || (m < p.M && n < p.N))) {
-        float4 v = ld4(cs + row * CST + 4 * c4);
-        const long long off = (long long)m * ldc + n;
-        if (mode == EPI_BIAS || mode == EPI_BIAS_RES || mode == EPI_BIAS_GELU || mode == EPI_BIAS_GELU_PRE ||
-            mode == EPI_BIAS_RELU) {
-          const float4 b4 = ld4(bias + n);
-          v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
-        }
-        if (mode == EPI_BIAS_GELU_PRE) st4(pre_out + off, v);
-        if (mode == EPI_BIAS_GELU || mode == EPI_BIAS_GELU_PRE) {
-          v.x = gelu_exact(v.x); v.y = gelu_exact(v.y); v.z = gelu_exact(v.z); v.w = gelu_exact(v.w);
-        } else if (mode == EPI_BIAS_RELU) {
-          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-        } else if (mode == EPI_DGELU) {
-          const float4 a4 = ld4(aux + off);
-          v.x *= gelu_grad(a4.x); v.y *= gelu_grad(a4.y); v.z *= gelu_grad(a4.z); v.w *= gelu_grad(a4.w);
-        } else if (mode == EPI_DRELU) {
-          const float4 a4 = ld4(aux + off);
-          v.x = a4.x > 0.f ? v.x : 0.f; v.y = a4.y > 0.f ? v.y : 0.f; v.z = a4.z > 0.f ? v.z : 0.f; v.w = a4.w > 0.f ? v.w : 0.f;
-        }
-        if (mode == EPI_BIAS_RES || mode == EPI_RES) {
-          const float4 r4 = ld4(res + off);
-          v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
-        }
-        st4(C + off, v);
-        if (want_cs) { csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w; }
-      }
-    }
-    if (want_cs) {
-      // a lane keeps the same column group c4 = lane % C4 through the loop: fold the 64 / C4 lanes of each group, then lanes
-      // 0..C4-1 store one row of per-(tile, wave-row) column sums; a small rp_colsum over them finishes the bias gradient
-#pragma unroll
-      for (int o = 32; o >= C4; o >>= 1) {
-        csum.x += __shfl_xor(csum.x, o, 64); csum.y += __shfl_xor(csum.y, o, 64);
-        csum.z += __shfl_xor(csum.z, o, 64); csum.w += __shfl_xor(csum.w, o, 64);
-      }
-      const int n = n0 + wn0 + 4 * lane;
-      if (lane < C4 && n < p.N) st4(p.colsum_part + (long long)(2 * mt + (wave >> 1)) * p.N + n, csum);
+    // LDS-staged epilogue, one straight-line instance per mode (wave-uniform switch outside every loop): see staged_epilogue
+    switch (mode) {
+      case EPI_RAW: staged_epilogue<TM, TN, EPI_RAW>(p, acc, lds, m0, n0, mt, C, ldc, bias, pre_out, aux, res, partial); break;
+      case EPI_BIAS: staged_epilogue<TM, TN, EPI_BIAS>(p, acc, lds, m0, n0, mt, C, ldc, bias, pre_out, aux, res, partial); break;
+      case EPI_BIAS_RES: staged_epilogue<TM, TN, EPI_BIAS_RES>(p, acc, lds, m0, n0, mt, C, ldc, bias, pre_out, aux, res, partial); break;
+      case EPI_RES: staged_epilogue<TM, TN, EPI_RES>(p, acc, lds, m0, n0, mt, C, ldc, bias, pre_out, aux, res, partial); break;
+      case EPI_BIAS_GELU: staged_epilogue<TM, TN, EPI_BIAS_GELU>(p, acc, lds, m0, n0, mt, C, ldc, bias, pre_out, aux, res, partial); break;
+      case EPI_BIAS_GELU_PRE: staged_epilogue<TM, TN, EPI_BIAS_GELU_PRE>(p, acc, lds, m0, n0, mt, C, ldc, bias, pre_out, aux, res, partial); break;
+      case EPI_BIAS_RELU: staged_epilogue<TM, TN, EPI_BIAS_RELU>(p, acc, lds, m0, n0, mt, C, ldc, bias, pre_out, aux, res, partial); break;
+      case EPI_DGELU: staged_epilogue<TM, TN, EPI_DGELU>(p, acc, lds, m0, n0, mt, C, ldc, bias, pre_out, aux, res, partial); break;
+      default: staged_epilogue<TM, TN, EPI_DRELU>(p, acc, lds, m0, n0, mt, C, ldc, bias, pre_out, aux, res, partial); break;
     }
   } else {
 #define RP_EPI_LOOP(BODY)                                                              \

@@ -32,6 +32,13 @@ RP_DEV void glds16(const float* sbase, unsigned voff, unsigned lds_byte_addr) {
                : "=&s"(keep) : "v"(voff), "s"(lds_byte_addr), "s"(sbase) : "memory");
 }
 
+// the DMA's scalar base must sit in SGPRs: tell the compiler so where its divergence analysis cannot prove it
+RP_DEV const float* uniform_ptr(const float* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (const float*)(((unsigned long long)hi << 32) | lo);
+}
+
 // per-lane source offsets (bytes from the tile's first row / first k) of the NI DMA instructions a wave issues per k-tile
 // for one operand tile of EXT rows.  LAY 0 ([EXT][K], K contiguous): instruction i covers rows (4 i + wave) * 8 .. + 7,
 // lane -> (row = lane / 8, LDS chunk = lane % 8) fetches chunk ^ ((row >> 1) & 7).  LAY 1 ([K][EXT], EXT contiguous): the
@@ -106,8 +113,8 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmP p) {
   const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)(lds);
   auto issue = [&](int kt, int st) {
     const unsigned as = lds0 + (st * STAGE + wave * 256) * 4, bs = as + A_FL * 4;       // 256 floats = 1 KB per wave instruction
-    const float* a = Ab + kt * a_step;
-    const float* b = Bb + kt * b_step;
+    const float* a = uniform_ptr(Ab + kt * a_step);
+    const float* b = uniform_ptr(Bb + kt * b_step);
 #pragma unroll
     for (int i = 0; i < NA; ++i) glds16(a, va[i], as + i * 4096);
 #pragma unroll

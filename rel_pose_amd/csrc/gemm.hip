@@ -441,6 +441,8 @@ extern "C" int rp_gemm(const RpGemm* g, void* stream) {
     if (g->a_layout == 1 && g->b_layout == 1 && g->N % 192 == 0 && !reads_mn) { tm = 1; tn = 3; }
     else { tm = 2; tn = 1; }
   }
+  // (64-row tiles for the ragged batched 576-row products -- dQ = dS K, the EMM's 576x96 blocks -- were measured and are
+  // NOT faster: those launches are bound by the 170 MB dS read (4.9 TB/s), the half-empty fifth row panel is free)
   if (const char* ov = getenv("RP_GEMM_TILE")) {   // tuning aid only: "TM,TN"
     if (ov[0] >= '1' && ov[0] <= '2' && ov[1] == ',' && ov[2] >= '1' && ov[2] <= '3') { tm = ov[0] - '0'; tn = ov[2] - '0'; }
   }

@@ -8,6 +8,10 @@ issued eagerly the GPU idles ~15-20 % of the step waiting for the host.  `Graphe
 and replays them.  Gradients of all trainable parameters are views into ONE flat buffer, so the data-parallel exchange is a
 single collective with no packing copies.  Semantics match the reference trainer (train.py:152-165): same loss weights,
 clip value, Adam hyper-parameters; DDP's bucketed overlap is traded for launch-free replay (the exchange is ~1 ms).
+BatchNorm running statistics: DDP broadcasts rank 0's buffers before every forward (broadcast_buffers=True, what the
+reference runs with); this class bypasses DDP, so it does the same broadcast itself, as one flat collective next to the
+gradient exchange -- otherwise the per-rank running means / variances drift apart and a checkpoint saved by rank 0 would not
+describe the other replicas.
 """
 import torch
 import torch.distributed as dist
@@ -35,6 +39,7 @@ class GraphedTrainStep:
             o += p.numel()
         self.loss = torch.zeros((), device=images.device)
         self.gA = self.gB = None
+        self.buffers = [b for b in model.buffers() if b.is_floating_point()]        # BatchNorm running_mean / running_var
 
     # -- the two halves, written once and used both eagerly (warm-up) and under capture ---------------------------
     def _fwd_bwd(self):
@@ -57,6 +62,13 @@ class GraphedTrainStep:
     def _exchange(self):
         if self.world > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            if self.buffers:                               # rank 0's BatchNorm statistics everywhere, like DDP's buffer broadcast
+                flat = torch.cat([b.reshape(-1) for b in self.buffers])
+                dist.broadcast(flat, 0)
+                o = 0
+                for b in self.buffers:
+                    b.copy_(flat[o:o + b.numel()].view_as(b))
+                    o += b.numel()
 
     def capture(self, warmup=3):
         s = torch.cuda.Stream()

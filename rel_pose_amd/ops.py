@@ -82,10 +82,12 @@ def gemm_tile(M, N, a_layout, b_layout, reads_mn=False, precision=None):
     if precision:
         return (1, 3) if (a_layout == 1 and b_layout == 1 and N % 192 == 0 and not reads_mn) else (2, 1)
     if a_layout == 0 and b_layout == 0:
-        return 2, 1
-    if N % 192 == 0 and not reads_mn:
-        return 1, 3
-    return 2, 1
+        tm, tn = 2, 1
+    elif N % 192 == 0 and not reads_mn:
+        tm, tn = 1, 3
+    else:
+        tm, tn = 2, 1
+    return tm, tn
 
 
 # ------------------------------------------------------------------------------------------------

@@ -106,6 +106,7 @@ def test_gemm_tile_and_splitk_selection():
     assert ops.gemm_tile(73728, 768, 0, 1, precision=3) == (2, 1)
     assert ops.gemm_tile(576, 192, 1, 1, precision=3) == (1, 3)
     assert ops.gemm_instance(64, 512, 0, 0) == (0, 0, 1, 2)
+    assert ops.gemm_tile(576, 64, 0, 1) == (2, 1)              # batched dQ = dS K: HBM-bound on dS, the ragged fifth panel is free
     with pytest.raises(ValueError):
         ops.set_gemm_precision(2)
     assert ops.pick_split_k(73728, 768, 192) == 1               # plenty of tiles

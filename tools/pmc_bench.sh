@@ -15,8 +15,8 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     n = collections.Counter()
     for f in glob.glob('/tmp/pmc_%s/**/*counter_collection.csv' % c, recursive=True):
         for r in csv.DictReader(open(f)):
-            k = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
-            if not any(s in k for s in ('gemm_kernel', 'attn_', 'emm_', 'colsum', 'ln_', 'splitk', 'tokens', 'rowdot')):
+            k = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('rpgemm::', '').replace('void ', '').split('(')[0]
+            if not any(s in k for s in ('gemm_', 'attn_', 'emm_', 'colsum', 'ln_', 'splitk', 'tokens', 'rowdot')):
                 continue
             acc[k][c] += float(r['Counter_Value']); n[k] += 1
     for k, v in n.items():

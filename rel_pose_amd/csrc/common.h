@@ -82,6 +82,22 @@ RP_DEV bool xcd_problem(int nq, int ZH, int& zh, int& qb) {
 }
 inline int xcd_grid(int nq, int ZH) { return nq * ((ZH + 7) / 8) * 8; }
 
+// ---- LDS-DMA (global_load_lds_dwordx4): LDS[lds_byte_addr + 16 * lane] <- *(sbase + voff bytes); sbase wave-uniform.
+// Inline asm: hipcc drains vmcnt(0) before the next ds_read when it sees the builtin form in flight (the LDS write sits on
+// the VM counter); completion is counted by hand -- s_waitcnt vmcnt(N) by every wave, then s_barrier, then the reads.
+typedef __attribute__((address_space(3))) void* rp_lds_ptr_t;
+RP_DEV void glds16(const float* sbase, unsigned voff, unsigned lds_byte_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(lds_byte_addr), "s"(sbase) : "memory");
+}
+RP_DEV unsigned lds_byte_addr(const float* p) { return (unsigned)(size_t)(rp_lds_ptr_t)(p); }
+RP_DEV const float* uniform_ptr(const float* p) {      // SGPR pair for the DMA base where hipcc cannot prove uniformity
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (const float*)(((unsigned long long)hi << 32) | lo);
+}
+
 RP_DEV float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 RP_DEV void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 

@@ -23,22 +23,6 @@
 namespace rpgemm {
 namespace {
 
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-
-// 16 bytes per lane: LDS[lds_byte_addr + 16 * lane] <- *(sbase + voff bytes).  M0 carries the LDS address and is restored.
-RP_DEV void glds16(const float* sbase, unsigned voff, unsigned lds_byte_addr) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(voff), "s"(lds_byte_addr), "s"(sbase) : "memory");
-}
-
-// the DMA's scalar base must sit in SGPRs: tell the compiler so where its divergence analysis cannot prove it
-RP_DEV const float* uniform_ptr(const float* p) {
-  const unsigned long long v = (unsigned long long)p;
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-  return (const float*)(((unsigned long long)hi << 32) | lo);
-}
-
 // per-lane source offsets (bytes from the tile's first row / first k) of the NI DMA instructions a wave issues per k-tile
 // for one operand tile of EXT rows.  LAY 0 ([EXT][K], K contiguous): instruction i covers rows (4 i + wave) * 8 .. + 7,
 // lane -> (row = lane / 8, LDS chunk = lane % 8) fetches chunk ^ ((row >> 1) & 7).  LAY 1 ([K][EXT], EXT contiguous): the
@@ -110,7 +94,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmP p) {
   unsigned va[NA], vb[NB];
   dma_offsets<ALAY, BM>(va, wave, lane, p.lda, m0, p.M);
   dma_offsets<BLAY, BN>(vb, wave, lane, p.ldb, n0, p.N);
-  const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)(lds);
+  const unsigned lds0 = lds_byte_addr(lds);
   auto issue = [&](int kt, int st) {
     const unsigned as = lds0 + (st * STAGE + wave * 256) * 4, bs = as + A_FL * 4;       // 256 floats = 1 KB per wave instruction
     const float* a = uniform_ptr(Ab + kt * a_step);

@@ -195,16 +195,24 @@ __global__ __launch_bounds__(256) void posenc_kernel(const float* __restrict__ i
   if (idx >= B * 576) return;
   const int b = idx / 576, n = idx % 576;
   float ix = 1.f, iy = 1.f;
+  bool bad = false;
   if (intr) {
     const float fx = intr[b * 8 + 0], fy = intr[b * 8 + 1], cx = intr[b * 8 + 2], cy = intr[b * 8 + 3];
     ix = 1.0f / ((fx / (cx * 2.0f)) * 2.0f);
     iy = 1.0f / ((fy / (cy * 2.0f)) * 2.0f);
+    // The reference stops here on inputs it does not support: an assert that the two images of a pair share their intrinsics
+    // (vision_transformer.py:117) and a pdb trap when the first pair's principal point lies on an image axis (:124-126).
+    // A host-side check would cost a device sync per step, so the condition is evaluated here and a violating pair's
+    // encodings become NaN: its pose and the batch loss turn NaN instead of silently using image 0's intrinsics.
+    bad = intr[b * 8 + 4] != fx || intr[b * 8 + 5] != fy || intr[b * 8 + 6] != cx || intr[b * 8 + 7] != cy ||
+          intr[2] * intr[3] == 0.0f;
   }
   float p3 = lin[n % 24], p4 = lin[n / 24];
   if (intr) {
     p3 = p3 * iy;
     p4 = p4 * ix;
   }
+  if (bad) p3 = p4 = __builtin_nanf("");
   float* o = pos + (long long)idx * 6;
   o[0] = l1 ? 1.0f : p3 * p3;     // l1: get_l1_positional_encodings (vision_transformer.py:37-87) = (1,1,1,p3,p4,1)
   o[1] = l1 ? 1.0f : p4 * p4;

@@ -103,7 +103,10 @@ class CrossBlock(nn.Module):
         B = x.shape[0] // 2
         if intrinsics is not None:
             intrinsics = intrinsics.to(device=x.device, dtype=torch.float32).contiguous()
-            if self.strict_intrinsics:   # the reference's host-side asserts (vision_transformer.py:117,124); sync!
+            # unsupported intrinsics (unequal within a pair, principal point on an axis) are caught on the device without a
+            # sync: rp_posenc turns the offending pair's encodings -- hence its pose and the loss -- into NaN.  strict_intrinsics
+            # additionally raises on the host like the reference does (vision_transformer.py:117,124), at the price of a sync.
+            if self.strict_intrinsics:
                 assert bool(torch.all(intrinsics[:, 0] == intrinsics[:, 1])), "intrinsics differ within a pair"
                 assert float(intrinsics[0, 0, 2] * intrinsics[0, 0, 3]) != 0.0, "principal point at the origin"
         a, m = self.cross_attn, self.mlp

@@ -482,6 +482,22 @@ def test_fused_batchnorm_statistics_are_cancellation_safe(ops):
     assert rel(bn.running_var, 0.9 + 0.1 * xd.var((0, 2, 3), unbiased=True)) < 1e-6
 
 
+def test_unsupported_intrinsics_fail_loudly_without_a_sync(ops):
+    """The reference asserts that both images of a pair share their intrinsics (vision_transformer.py:117) and traps when the
+    first pair's principal point lies on an axis (:124-126).  Here the check runs inside rp_posenc (no host sync): an offending
+    pair's positional encodings are NaN -- which poisons its pose and the batch loss -- while well-formed pairs are untouched."""
+    good = torch.tensor([[30.0, 26.0, 12.0, 11.0]]).repeat(3, 2, 1).contiguous().cuda()
+    ref = ops.posenc(good, 3, good.device)
+    assert torch.isfinite(ref).all()
+    bad = good.clone()
+    bad[1, 1, 0] = 31.0                                       # pair 1: fx differs between its two images
+    pos = ops.posenc(bad, 3, bad.device)
+    assert torch.isnan(pos[1, :, 3:5]).all() and torch.equal(pos[0], ref[0]) and torch.equal(pos[2], ref[2])
+    origin = good.clone()
+    origin[0, :, 2] = 0.0                                     # first pair's cx = 0: the reference drops into pdb for the whole batch
+    assert torch.isnan(ops.posenc(origin, 3, origin.device)[..., 3:5]).all()
+
+
 # ------------------------------------------------------------------------------------------------ configs[4]: bf16 MFMA mode
 def test_attention_and_emm_bf16_operand_mode(ops):
     """BASELINE.json configs[4] ("bf16 with MFMA bf16 attention GEMMs"): the `bf16` argument of rp_attn_* / rp_emm_* moves the

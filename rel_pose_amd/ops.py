@@ -8,7 +8,8 @@ Granularity: one autograd Function per reference module on the hot path --
   HeadFn          src/model.py:178,189,91-98,145-159    (final LN, regressor, quaternion normalise)
 so every residual add, bias, GELU/ReLU and their derivatives is fused into a kernel epilogue and autograd never
 inserts an elementwise kernel of its own.  PyTorch is used for memory, streams and the autograd graph only.
-All tensors are fp32, contiguous, on the GPU; anything else raises (there is no CPU path).
+All tensors are fp32, contiguous, on the GPU; anything else raises (there is no CPU path for the hot-path ops; only the CNN
+front-end's bn_act / maxpool3x3s2 wrappers hand CPU tensors to the stock torch modules, for the fixture generator).
 """
 import ctypes
 import math

@@ -144,8 +144,12 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # RP_BENCH_FORCE_DIST: run the N>1 code path (process group on RCCL, DDP wrapper, bucketed gradient all-reduce, barrier +
+    # max-over-ranks timing) with a single rank -- the only way to put RCCL under this code on a 1-GPU box
+    force_dist = bool(os.environ.get("RP_BENCH_FORCE_DIST"))
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group(backend=os.environ.get("RP_DIST_BACKEND", "nccl"), init_method="env://",
                                 world_size=world, rank=rank)
 
@@ -166,7 +170,7 @@ def main():
     train = args.mode == "train"
     model.train(train)
     net = model
-    if world > 1 and train and not args.graph:
+    if (world > 1 or force_dist) and train and not args.graph:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], find_unused_parameters=False)
         # (reference train.py:66-67; bucketed all-reduce of the 19.26 M trainable grads overlaps the backward)
     elif world > 1:
@@ -221,7 +225,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -242,7 +246,7 @@ def main():
     if roctx is not None:
         roctx.roctxProfilerPause(0)
     timer.enabled = False
-    if world > 1:
+    if world > 1 or force_dist:
         tt = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
@@ -312,7 +316,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             rec["cpu_baseline"] = cpu_baseline(args.hw)
         print(json.dumps(rec), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

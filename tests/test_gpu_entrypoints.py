@@ -194,3 +194,18 @@ def test_demo_reproduces_reference_demo_output(tmp_path):
     with open(os.path.join(ROOT, "gpurun_out", "test_report.txt"), "a") as f:
         f.write("demo_vs_reference_demo: rel=%.3e pred=%s\n" % (err, np.array2string(preds, precision=5)))
     assert err < 1e-4
+
+
+def test_bench_distributed_path_on_rccl_single_rank():
+    """The N>1 code path of bench.py -- process group on backend "nccl" (= RCCL), DistributedDataParallel around the product
+    model with its bucketed gradient all-reduce overlapping the backward, barrier + max-over-ranks timing -- run with ONE rank
+    (RP_BENCH_FORCE_DIST), which is all a 1-GPU box can give RCCL.  Multi-rank RCCL remains unexercised."""
+    import json
+    env = dict(os.environ, PYTHONPATH=ROOT, RP_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29543",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "8",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 1 and rec["config"]["finite"] and rec["roofline"]["launches_timed"] > 0

@@ -3,9 +3,18 @@ arithmetic is unpinned (see se3.py).
 
 The reference indexes with ii=[0,1], jj=[1,0] (tensor indices -> host-to-device copies every call); here the same
 selection is ``flip(1)``, which keeps the step free of host syncs and capturable in a HIP graph."""
+import os
+
 import torch
 
-from .se3 import SE3
+from .se3 import SE3, with_tangent_gradient
+
+# What flows back from the loss into the predicted poses [B,2,7]:
+#   "euclidean" (default): the plain derivative w.r.t. the seven stored numbers (t, q);
+#   "tangent": the embedded tangent-space gradient [dL/dtau, dL/dphi, 0] of a left perturbation Exp(xi) * G, which is what
+#              lietorch's SE3 backward is recalled to return (SURVEY.md 8c) -- the definition is verified against finite
+#              differences (tests/test_host_cpu.py), lietorch's use of it is NOT verifiable offline: parity stays unpinned.
+GRADIENT_CONVENTION = os.environ.get("RP_LIE_GRADIENT", "euclidean")
 
 
 def _pair_swap(G):
@@ -16,6 +25,10 @@ def _pair_swap(G):
 def geodesic_loss_tensors(Ps, Gs):
     """(translation, rotation) geodesic losses as device scalars -- no .item(), no host sync.  fp32 GPU poses take the fused
     kernel (ops.GeodesicLossFn: same formulas, one launch, exact derivatives); anything else the PyTorch formulation below."""
+    if GRADIENT_CONVENTION == "tangent":
+        Gs = [with_tangent_gradient(Gs[0])]
+    elif GRADIENT_CONVENTION != "euclidean":
+        raise ValueError("RP_LIE_GRADIENT must be 'euclidean' or 'tangent'")
     g = Gs[0].data
     if g.is_cuda and g.dtype == torch.float32 and g.dim() == 3 and Ps.data.dtype == torch.float32:
         from . import ops

@@ -97,3 +97,42 @@ class SE3:
         Vinv = eye - 0.5 * K + c[..., None, None] * (K @ K)
         tau = (Vinv @ t.unsqueeze(-1)).squeeze(-1)
         return torch.cat([tau, phi], dim=-1)
+
+
+def tangent_gradient(data, grad):
+    """Euclidean gradient of a scalar w.r.t. the 7-vector (t, q xyzw) -> the tangent-space gradient in lietorch's storage
+    convention: [dL/dtau (3), dL/dphi (3), 0] with X <- Exp((tau, phi)) * X (left perturbation), evaluated at 0:
+        t' = t + tau + phi x t,   q' = q + 1/2 (phi, 0) (x) q      (first order)
+    =>  dL/dtau = g_t,   dL/dphi = t x g_t + 1/2 M(q)^T g_q.
+    lietorch (the reference's SE3, un-vendored) returns gradients of group elements in this embedded-tangent form
+    [recalled, not verifiable here: SURVEY.md 8c]; this function is the exact chain rule for THAT definition and is
+    checked against finite differences of Exp(xi) * X in tests/test_host_cpu.py.  Used only when
+    rel_pose_amd.losses.GRADIENT_CONVENTION == "tangent" (default: "euclidean", plain autograd of the 7-vector)."""
+    t, q = data[..., :3], data[..., 3:]
+    gt, gq = grad[..., :3], grad[..., 3:]
+    bx, by, bz, bw = q.unbind(-1)
+    gx, gy, gz, gw = gq.unbind(-1)
+    gphi_q = 0.5 * torch.stack([bw * gx - bz * gy + by * gz - bx * gw,
+                                bz * gx + bw * gy - bx * gz - by * gw,
+                                -by * gx + bx * gy + bw * gz - bz * gw], dim=-1)
+    gphi = torch.cross(t, gt, dim=-1) + gphi_q
+    return torch.cat([gt, gphi, torch.zeros_like(gw).unsqueeze(-1)], dim=-1)
+
+
+class _TangentGrad(torch.autograd.Function):
+    """identity in the forward; converts the incoming Euclidean gradient to the embedded-tangent form in the backward"""
+
+    @staticmethod
+    def forward(ctx, data):
+        ctx.save_for_backward(data)
+        return data.view_as(data)
+
+    @staticmethod
+    def backward(ctx, grad):
+        (data,) = ctx.saved_tensors
+        return tangent_gradient(data, grad)
+
+
+def with_tangent_gradient(G):
+    """SE3 whose data back-propagates tangent-space gradients (see tangent_gradient)"""
+    return SE3(_TangentGrad.apply(G.data))

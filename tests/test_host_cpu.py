@@ -239,3 +239,64 @@ def test_pretrained_trunk_loads_from_a_local_state_dict(tmp_path, monkeypatch):
     torch.save({"not_a_resnet": torch.zeros(1)}, p)
     with pytest.raises(RuntimeError):
         resnet.resnet18(pretrained=True)
+
+
+def test_tangent_space_gradient_matches_finite_differences_of_left_perturbation():
+    """losses.GRADIENT_CONVENTION = "tangent": the gradient reaching the predicted pose is [dL/dtau, dL/dphi, 0] for
+    G <- Exp(xi) * G.  Checked against central finite differences of the fp64 loss along Exp(xi) (scipy.linalg.expm on the
+    4x4 twist), for both slots of random pose pairs.  (That lietorch uses this convention is recalled, not verifiable here.)"""
+    import scipy.linalg
+    import torch
+    from rel_pose_amd import losses, se3
+
+    def to_mat(d):
+        x, y, z, w = d[3:]
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                      [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        T = np.eye(4); T[:3, :3] = R; T[:3, 3] = d[:3]
+        return T
+
+    def from_mat(T, q_like):
+        from scipy.spatial.transform import Rotation
+        q = Rotation.from_matrix(T[:3, :3]).as_quat()          # xyzw
+        if np.dot(q, q_like) < 0:
+            q = -q
+        return np.concatenate([T[:3, 3], q])
+
+    def twist(xi):
+        tau, phi = xi[:3], xi[3:]
+        M = np.zeros((4, 4))
+        M[:3, :3] = np.array([[0, -phi[2], phi[1]], [phi[2], 0, -phi[0]], [-phi[1], phi[0], 0]])
+        M[:3, 3] = tau
+        return scipy.linalg.expm(M)
+
+    g = torch.Generator().manual_seed(5)
+    B = 3
+    def rand_pose():
+        q = torch.randn(B, 2, 4, generator=g, dtype=torch.float64)
+        q = q / q.norm(dim=-1, keepdim=True)
+        return torch.cat([torch.randn(B, 2, 3, generator=g, dtype=torch.float64), q], -1)
+    P, G = rand_pose(), rand_pose()
+
+    def loss_np(Gd):
+        ltr, lrot = losses.geodesic_loss_tensors_torch(se3.SE3(P), [se3.SE3(torch.as_tensor(Gd))])
+        return float(10.0 * ltr + 3.0 * lrot)
+
+    Gt = G.clone().requires_grad_(True)
+    ltr, lrot = losses.geodesic_loss_tensors_torch(se3.SE3(P), [se3.with_tangent_gradient(se3.SE3(Gt))])
+    (10.0 * ltr + 3.0 * lrot).backward()
+    got = Gt.grad.numpy()
+    assert np.all(got[..., 6] == 0.0)
+    eps = 1e-6
+    for b in range(B):
+        for s in range(2):
+            for k in range(6):
+                xi = np.zeros(6); xi[k] = eps
+                Gp, Gm = G.numpy().copy(), G.numpy().copy()
+                Gp[b, s] = from_mat(twist(xi) @ to_mat(G[b, s].numpy()), G[b, s, 3:].numpy())
+                Gm[b, s] = from_mat(twist(-xi) @ to_mat(G[b, s].numpy()), G[b, s, 3:].numpy())
+                fd = (loss_np(Gp) - loss_np(Gm)) / (2 * eps)
+                assert abs(fd - got[b, s, k]) < 1e-5 * max(1.0, abs(fd)), (b, s, k, fd, got[b, s, k])
+    # the switch: default euclidean; "tangent" routes through with_tangent_gradient
+    assert losses.GRADIENT_CONVENTION == "euclidean"

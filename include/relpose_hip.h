@@ -78,6 +78,18 @@ typedef struct RpGemm {
                        * values that tile stored over its 32*TM rows -- one small rp_colsum over it yields sum_m C[m][n] (the bias
                        * gradient when C is a pre-activation gradient) without re-reading C.  split_k = batch = 1, N % 4 == 0,
                        * not the [K,M]x[K,N] layout, and the tile must be TN <= 2 (true whenever aux / residual is given). */
+  /* LayerNorm backward fused into the epilogue (all NULL = off).  With ln_x set, the product op(A) op(B) is taken as the
+   * gradient of a LayerNorm OUTPUT (eps / affine as rp_layernorm_fwd) and C receives the gradient of the LayerNorm INPUT:
+   *   xhat = (ln_x - ln_mean) * ln_rstd ;  g = P * ln_gamma ;  C = ln_rstd * (g - mean_n(g) - xhat * mean_n(g * xhat)) + residual
+   * ln_part [ceil(M/64)][np*192] (np = 3 with a residual, else 2) receives per-64-row-tile column sums of
+   * P * xhat (-> d gamma), P (-> d beta) and residual (-> the bias gradient of the Linear that produced that branch); one
+   * rp_colsum over it finishes them.  Requirements: N == 192 == ldc, ln_x / residual contiguous [M,192], no bias / act / aux,
+   * split_k = batch = 1, precision 0.  Replaces reference autograd of vision_transformer.py:352-353 (LayerNorm backward). */
+  const float* ln_x;
+  const float* ln_mean;
+  const float* ln_rstd;
+  const float* ln_gamma;
+  float* ln_part;
 } RpGemm;
 int rp_gemm(const RpGemm* g, void* stream);
 size_t rp_gemm_workspace_bytes(int M, int N, int split_k);

@@ -24,7 +24,8 @@ class RpGemm(Structure):
                 ("split_k", c_int), ("workspace", c_void_p), ("workspace_bytes", c_size_t),
                 ("bias", c_void_p), ("pre_out", c_void_p), ("act", c_int), ("dact", c_int),
                 ("aux", c_void_p), ("residual", c_void_p), ("trans_c", c_int), ("precision", c_int),
-                ("colsum_part", c_void_p)]
+                ("colsum_part", c_void_p),
+                ("ln_x", c_void_p), ("ln_mean", c_void_p), ("ln_rstd", c_void_p), ("ln_gamma", c_void_p), ("ln_part", c_void_p)]
 
 
 P, I, F, L = c_void_p, c_int, c_float, c_longlong

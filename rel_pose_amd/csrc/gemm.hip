@@ -438,6 +438,15 @@ extern "C" int rp_gemm(const RpGemm* g, void* stream) {
   p.trans_c = g->trans_c;
   p.limbs = g->precision;
   p.colsum_part = g->colsum_part;
+  p.ln_x = g->ln_x; p.ln_mean = g->ln_mean; p.ln_rstd = g->ln_rstd; p.ln_gamma = g->ln_gamma; p.ln_part = g->ln_part;
+  const bool lnbwd = g->ln_x != nullptr;
+  if (lnbwd) {
+    if (!g->ln_mean || !g->ln_rstd || !g->ln_gamma || !g->ln_part) return RP_EBADSHAPE;
+    if (g->N != 192 || g->ldc != 192 || split > 1 || batch > 1 || g->bias || g->pre_out || g->act || g->dact || g->aux ||
+        g->colsum_part || g->trans_c || g->precision != 0 || (g->a_layout == 1 && g->b_layout == 1))
+      return RP_EUNSUPPORTED;
+    p.epi_mode = EPI_LNBWD;
+  }
   if (g->colsum_part && (split > 1 || batch > 1 || (g->N & 3) || (g->a_layout == 1 && g->b_layout == 1))) return RP_EUNSUPPORTED;
   if (p.limbs != 0 && p.limbs != 1 && p.limbs != 3) return RP_EUNSUPPORTED;
   if (g->trans_c && (split == 1 || g->bias || g->pre_out || g->aux || g->residual)) return RP_EUNSUPPORTED;
@@ -461,7 +470,8 @@ extern "C" int rp_gemm(const RpGemm* g, void* stream) {
   }
   // (64-row tiles for the ragged batched 576-row products -- dQ = dS K, the EMM's 576x96 blocks -- were measured and are
   // NOT faster: those launches are bound by the 170 MB dS read (4.9 TB/s), the half-empty fifth row panel is free)
-  if (const char* ov = getenv("RP_GEMM_TILE")) {   // tuning aid only: "TM,TN"
+  if (lnbwd) { tm = 1; tn = 3; }                   // whole 192-wide rows in one workgroup
+  else if (const char* ov = getenv("RP_GEMM_TILE")) {   // tuning aid only: "TM,TN"
     if (ov[0] >= '1' && ov[0] <= '2' && ov[1] == ',' && ov[2] >= '1' && ov[2] <= '3') { tm = ov[0] - '0'; tn = ov[2] - '0'; }
   }
   if (p.colsum_part && (tn == 3 || p.epi_mode == EPI_GENERIC)) return RP_EUNSUPPORTED;   // needs the staged epilogue, 64 % (8 TN) == 0

@@ -6,7 +6,7 @@
 namespace rpgemm {
 
 enum { EPI_RAW = 0, EPI_BIAS, EPI_BIAS_RES, EPI_RES, EPI_BIAS_GELU, EPI_BIAS_GELU_PRE, EPI_BIAS_RELU, EPI_DGELU,
-       EPI_DRELU, EPI_GENERIC };
+       EPI_DRELU, EPI_GENERIC, EPI_LNBWD };
 
 struct GemmP {
   const float* A;
@@ -26,6 +26,10 @@ struct GemmP {
   int trans_c;
   int limbs;
   float* colsum_part;
+  // EPI_LNBWD (RpGemm.ln_x != NULL): the product is the gradient of a LayerNorm OUTPUT; the epilogue applies the LayerNorm
+  // backward and stores the gradient of its INPUT (+ residual) -- see lnbwd_epilogue
+  const float* ln_x; const float* ln_mean; const float* ln_rstd; const float* ln_gamma;
+  float* ln_part;
 };
 
 RP_DEV float epilogue(float v, int m, int n, const GemmP& p) {
@@ -129,6 +133,108 @@ RP_DEV void staged_epilogue(const GemmP& p, f32x16 (&acc)[TM][TN], float* lds, i
   }
 }
 
+// LayerNorm backward as a GEMM epilogue (tile 64 x 192 = whole rows of the 192-wide model dimension, N == 192).
+// The dX GEMM of the Linear that follows a LayerNorm (qkv, fc1) produces dY_n = d loss / d LN(x); reference autograd then
+// runs the LayerNorm backward as its own pass: read dY_n, x and the residual-branch gradient, write dx (226 MB per call at
+// 64 pairs).  Fused here, dY_n never leaves the chip: the accumulators are staged in LDS, then every wave walks 16 rows with
+// lane = column (3 columns per lane), exactly like ln_bwd_kernel in rowwise.hip -- row sums by wave reduction, dx = rstd *
+// (dY gamma - mean(dY gamma) - xhat * mean(dY gamma xhat)) (+ add), per-lane column sums of dY xhat (dgamma), dY (dbeta) and
+// add (the bias gradient of the Linear that produced the residual branch), combined over the four waves in a fixed order
+// and written as one partial row [np * 192] per tile; a column sum over the tiles finishes them (deterministic).
+RP_DEV void lnbwd_epilogue(const GemmP& p, f32x16 (&acc)[1][3], float* lds, int m0, int mt, int zb) {
+  constexpr int CST = 100, C = 192;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const float* add = p.residual;
+  const int rbase = m0 + 16 * wave;
+  const int nrows = max(0, min(16, p.M - rbase));            // valid rows of this wave (ragged last tile)
+  const int mrow = min(rbase + (lane & 15), p.M - 1);
+  const float mu_l = p.ln_mean[mrow], rs_l = p.ln_rstd[mrow];   // row statistics: first 16 lanes, broadcast by shuffle
+  float g[3], dg[3] = {0.f, 0.f, 0.f}, db[3] = {0.f, 0.f, 0.f}, da[3] = {0.f, 0.f, 0.f};
+  int coff[3];                          // column lane + 64 j inside the staged tile: (column half) * 3200 + column % 96
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int c = lane + 64 * j;
+    g[j] = p.ln_gamma[c];
+    coff[j] = c < 96 ? c : 32 * CST + (c - 96);
+  }
+  // The wave's 16 rows go in two batches of 8: all global operands of a batch (LayerNorm input, residual-branch gradient:
+  // 48 dwords per lane) are requested together, then the batch is reduced and stored -- one exposed memory latency per batch
+  // instead of one per row, at a register cost that keeps two waves per SIMD (all 16 rows at once: 260+ registers).
+  // Rows past M re-read the last valid row (no stride) and are masked.
+  float xv[8][3], av[8][3];
+  auto fetch = [&](int b) {
+    const int r0 = 8 * b;
+    const float* xrow = p.ln_x + (long long)min(rbase + r0, p.M - 1) * C + lane;
+    const float* arow = add ? add + (long long)min(rbase + r0, p.M - 1) * C + lane : nullptr;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        xv[q][j] = xrow[64 * j];
+        av[q][j] = add ? arow[64 * j] : 0.f;
+      }
+      if (r0 + q + 1 < nrows) { xrow += C; if (add) arow += C; }
+    }
+  };
+  auto reduce = [&](int b) {
+    float* crow = p.C + (long long)min(rbase + 8 * b, p.M - 1) * C + lane;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int rr = 8 * b + q, r = 16 * wave + rr;
+      const bool ok = rr < nrows;
+      const float mu = __shfl(mu_l, rr, 64), rs = __shfl(rs_l, rr, 64);
+      const float* drow = lds + (r >> 5) * (2 * 32 * CST) + (r & 31) * CST;
+      float xh[3], dxh[3];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const float d = ok ? drow[coff[j]] : 0.f;
+        xh[j] = (xv[q][j] - mu) * rs;
+        dxh[j] = d * g[j];
+        s1 += dxh[j];
+        s2 += dxh[j] * xh[j];
+        dg[j] += d * xh[j];
+        db[j] += d;
+      }
+      const float c1 = wave_sum(s1) * (1.0f / C), c2 = wave_sum(s2) * (1.0f / C);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const float a = ok ? av[q][j] : 0.f;
+        da[j] += a;
+        if (ok) crow[64 * j] = rs * (dxh[j] - c1 - xh[j] * c2) + a;
+      }
+      crow += C;
+    }
+  };
+  fetch(0);                             // in flight while the accumulators are staged
+  float* cs = lds + wave * (32 * CST);
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cs[acc_row(r, hi) * CST + 32 * j + l31] = acc[0][j][r];
+  __syncthreads();
+  reduce(0);
+  __builtin_amdgcn_sched_barrier(0);    // keep the second batch's loads behind the first batch's arithmetic (register budget)
+  fetch(1);
+  reduce(1);
+  __syncthreads();                      // every wave is done with the staged tile: reuse it for the column partials
+  float* red = lds;                     // [3][4][192]
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    red[(0 * 4 + wave) * C + lane + 64 * j] = dg[j];
+    red[(1 * 4 + wave) * C + lane + 64 * j] = db[j];
+    red[(2 * 4 + wave) * C + lane + 64 * j] = da[j];
+  }
+  __syncthreads();
+  const int np = add ? 3 : 2;
+  float* part = p.ln_part + (long long)mt * np * C;
+  for (int c = tid; c < np * C; c += 256) {
+    const int q = c / C, cc = c % C;
+    part[c] = (red[(q * 4 + 0) * C + cc] + red[(q * 4 + 1) * C + cc]) + (red[(q * 4 + 2) * C + cc] + red[(q * 4 + 3) * C + cc]);
+  }
+}
+
 // Tile epilogue.  acc: the wave's (32 TM) x (32 TN) accumulators (lane = column, register = row); lds: the workgroup's LDS
 // (>= 4 * 32 * TM * (32 TN + 4) floats when STAGED), free to overwrite; (m0, n0) tile origin, (mt) row-panel index,
 // zb / zid batch / split indices as in the kernels.
@@ -150,6 +256,10 @@ RP_DEV void tile_epilogue(const GemmP& p, f32x16 (&acc)[TM][TN], float* lds, int
   const float* res = p.residual ? p.residual + zb * p.sc : nullptr;
   const int mode = partial ? EPI_RAW : p.epi_mode;
   const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+  if (mode == EPI_LNBWD) {               // rp_gemm only selects it with the 64 x 192 tile (N == 192, one column tile)
+    if constexpr (TM == 1 && TN == 3 && STAGED) lnbwd_epilogue(p, acc, lds, m0, mt, zb);
+    return;
+  }
 
   if (STAGED && (p.N & 3) == 0 && mode != EPI_GENERIC) {
     // LDS-staged epilogue, one straight-line instance per mode (wave-uniform switch outside every loop): see staged_epilogue

@@ -175,8 +175,9 @@ def gemm_instance(M, N, a_layout, b_layout, reads_mn=False):
 
 def gemm(A, B, M, N, K, *, a_layout=0, b_layout=0, lda=None, ldb=None, out=None, ldc=None, bias=None, act=0,
          pre_out=None, dact=0, aux=None, residual=None, split_k=None, batch=1, strides=(0, 0, 0), trans_c=False,
-         precision=None, want_colsum=False):
-    """C[M,N] = epilogue(op(A) op(B)); see RpGemm in include/relpose_hip.h."""
+         precision=None, want_colsum=False, ln=None):
+    """C[M,N] = epilogue(op(A) op(B)); see RpGemm in include/relpose_hip.h.
+    ln = (x, mean, rstd, gamma, part): LayerNorm backward fused into the epilogue (RpGemm.ln_*)."""
     lib = _lib.load()
     _chk(A, B, out, bias, pre_out, aux, residual)
     if lda is None:
@@ -208,6 +209,10 @@ def gemm(A, B, M, N, K, *, a_layout=0, b_layout=0, lda=None, ldb=None, out=None,
     g.residual = None if residual is None else residual.data_ptr()
     g.trans_c = 1 if trans_c else 0
     g.precision = GEMM_PRECISION if precision is None else precision
+    if ln is not None:
+        _chk(*ln)
+        g.ln_x, g.ln_mean, g.ln_rstd, g.ln_gamma, g.ln_part = (t.data_ptr() for t in ln)
+        split_k = g.split_k = 1
     cpart = None
     if want_colsum:      # column sums of the stored values, folded into the epilogue (see RpGemm.colsum_part)
         tm_, tn_ = gemm_tile(M, N, a_layout, b_layout, aux is not None or residual is not None, g.precision)
@@ -245,6 +250,25 @@ def linear_dx(dy, W, dact=0, aux=None, want_colsum=False):
     M, N = dy.shape
     K = W.shape[1]
     return gemm(dy, W, M, K, N, b_layout=1, dact=dact, aux=aux, want_colsum=want_colsum)
+
+
+# LayerNorm backward fused into the epilogue of the input-gradient GEMM that feeds it (RpGemm.ln_*): the exact-fp32 GEMM only
+FUSE_LN_BWD = os.environ.get("RP_FUSE_LN_BWD", "1") == "1"
+
+
+def linear_dx_lnbwd(dy, W, x, gamma, mean, rstd, add=None):
+    """The pair  dxn = dy W ; (dx, dgamma, dbeta[, colsum(add)]) = layernorm_bwd(dxn, x, gamma, mean, rstd, add)  as ONE
+    GEMM: dxn (the gradient of the LayerNorm output, [M,192]) never goes to memory.  dy [M,N], W [N,192]."""
+    if not FUSE_LN_BWD or GEMM_PRECISION != 0 or W.shape[1] != DIM:
+        return layernorm_bwd(linear_dx(dy, W), x, gamma, mean, rstd, add=add)
+    M, N = dy.shape
+    np_ = 3 if add is not None else 2
+    part = _empty(-(-M // 64), np_ * DIM, like=dy)
+    dx = gemm(dy, W, M, DIM, N, b_layout=1, residual=add, ln=(x, mean, rstd, gamma, part))
+    sums = colsum(part)
+    if add is None:
+        return dx, sums[:DIM], sums[DIM:]
+    return dx, sums[:DIM], sums[DIM:2 * DIM], sums[2 * DIM:]
 
 
 def linear_dw(dy, x):
@@ -559,7 +583,7 @@ def _param_grads(fork, dy, x):
     return fork.on_side(lambda: linear_dw_db(dy, x))
 
 
-def _mlp_bwd(fork, dy, xn, h, hpre, w1, w2, want_db2=True):
+def _mlp_bwd(fork, dy, xn, h, hpre, w1, w2, want_db2=True, ln=None):
     fork.sync_side()
     if want_db2:
         dw2, db2 = _param_grads(fork, dy, h)
@@ -569,6 +593,8 @@ def _mlp_bwd(fork, dy, xn, h, hpre, w1, w2, want_db2=True):
     dh, db1 = linear_dx(dy, w2, dact=1, aux=hpre, want_colsum=True)
     fork.sync_side()
     dw1 = fork.on_side(lambda: linear_dw(dh, xn))
+    if ln is not None:      # (x, gamma, mean, rstd, add): LayerNorm backward fused into the fc1 input-gradient GEMM
+        return linear_dx_lnbwd(dh, w1, *ln), dw1, db1, dw2, db2
     dxn = linear_dx(dh, w1)
     return dxn, dw1, db1, dw2, db2
 
@@ -606,8 +632,8 @@ class BlockFn(torch.autograd.Function):
         fork = _Fork(dy.device)
         # the two LayerNorm backwards read dy / dx1 as their residual-branch operand anyway: they also return its column
         # sums, which ARE the fc2 / proj bias gradients (two 57 MB column-sum passes per block saved)
-        dxn2, dfc1w, dfc1b, dfc2w, _ = _mlp_bwd(fork, dy, xn2, h, hpre, fc1_w, fc2_w, want_db2=False)
-        dx1, dn2w, dn2b, dfc2b = layernorm_bwd(dxn2, x1, n2w, m2, r2, add=dy)
+        (dx1, dn2w, dn2b, dfc2b), dfc1w, dfc1b, dfc2w, _ = _mlp_bwd(fork, dy, xn2, h, hpre, fc1_w, fc2_w, want_db2=False,
+                                                                     ln=(x1, n2w, m2, r2, dy))
         fork.sync_side()
         dprojw = fork.on_side(lambda: linear_dw(dx1, o))
         do = linear_dx(dx1, proj_w)
@@ -615,8 +641,7 @@ class BlockFn(torch.autograd.Function):
         fork.sync_main()                                  # dQ pass (side) done before dqkv is consumed
         fork.sync_side()
         dqkvw, dqkvb = _param_grads(fork, dqkv, xn1)
-        dxn1 = linear_dx(dqkv, qkv_w)
-        dx, dn1w, dn1b, dprojb = layernorm_bwd(dxn1, x2, n1w, m1, r1, add=dx1)
+        dx, dn1w, dn1b, dprojb = linear_dx_lnbwd(dqkv, qkv_w, x2, n1w, m1, r1, add=dx1)
         fork.sync_main()
         return (dx.view(Z, N_TOK, DIM), dn1w, dn1b, dqkvw, dqkvb, dprojw, dprojb, dn2w, dn2b, dfc1w, dfc1b, dfc2w,
                 dfc2b, None)
@@ -667,8 +692,7 @@ class CrossBlockFn(torch.autograd.Function):
         dqkv = emm_backward(qkv, xa, t, rlse, clse, dF, Z, single=ctx.single, cross=ctx.cross)
         fork.sync_side()
         dqkvw, dqkvb = _param_grads(fork, dqkv, xn)
-        dxn = linear_dx(dqkv, qkv_w)
-        dx, dn1w, dn1b = layernorm_bwd(dxn, x2, n1w, m1, r1)
+        dx, dn1w, dn1b = linear_dx_lnbwd(dqkv, qkv_w, x2, n1w, m1, r1)
         fork.sync_main()
         dpfw = dpfw_full[:, :ctx.pf_cols].contiguous()
         return (dx.view(Z, N_TOK, DIM), None, dn1w, dn1b, dqkvw, dqkvb, dpfw, dpfb, dn2w, dn2b, dfc1w, dfc1b, dfc2w,

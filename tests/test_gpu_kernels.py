@@ -172,6 +172,38 @@ def test_gemm_errors_are_loud(ops):
 
 
 # ------------------------------------------------------------------------------------------------ rowwise
+@pytest.mark.parametrize("M,with_add", [(576 * 4, True), (576 * 4, False), (1000, True)])
+def test_gemm_with_fused_layernorm_backward(ops, M, with_add):
+    """RpGemm.ln_*: the input-gradient GEMM of the Linear behind a LayerNorm applies the LayerNorm backward in its epilogue
+    (reference autograd of vision_transformer.py:352-353).  Against fp64 autograd of  LN(x) @ W^T  and against the unfused
+    pair of kernels; M = 1000 leaves a ragged last 64-row tile."""
+    N = 576
+    x, dy, W = rnd(M, 192, seed=31), rnd(M, N, seed=32), rnd(N, 192, seed=33) * 0.07
+    gamma, beta = rnd(192, seed=34) * 0.3 + 1.0, rnd(192, seed=35) * 0.1
+    add = rnd(M, 192, seed=36) if with_add else None
+    xn, mean, rstd = ops.layernorm_fwd(x, gamma, beta)
+    x64 = x.double().requires_grad_(True)
+    g64 = gamma.double().requires_grad_(True)
+    b64 = beta.double().requires_grad_(True)
+    y = torch.nn.functional.layer_norm(x64, (192,), g64, b64, 1e-6) @ W.double().t()
+    (y * dy.double()).sum().backward()
+    ref_dx = x64.grad + (add.double() if with_add else 0.0)
+    keep = ops.FUSE_LN_BWD
+    try:
+        ops.FUSE_LN_BWD = True
+        fused = ops.linear_dx_lnbwd(dy, W, x, gamma, mean, rstd, add=add)
+        ops.FUSE_LN_BWD = False
+        plain = ops.linear_dx_lnbwd(dy, W, x, gamma, mean, rstd, add=add)
+    finally:
+        ops.FUSE_LN_BWD = keep
+    e = [rel(fused[0], ref_dx), rel(fused[1], g64.grad), rel(fused[2], b64.grad)]
+    if with_add:
+        e.append(rel(fused[3], add.double().sum(0)))
+    report("gemm_lnbwd[M=%d,add=%d]" % (M, with_add), dx=e[0], dgamma=e[1], dbeta=e[2], vs_unfused=rel(fused[0], plain[0]))
+    assert max(e) < 5e-6
+    assert rel(fused[0], plain[0]) < 2e-6 and rel(fused[1], plain[1]) < 2e-6 and rel(fused[2], plain[2]) < 2e-6
+
+
 def test_layernorm_fwd_bwd(ops):
     rows, C = 1000, 192
     x, g, b, dy, add = rnd(rows, C, seed=1), rnd(C, seed=2) * 0.2 + 1, rnd(C, seed=3), rnd(rows, C, seed=4), rnd(rows, C, seed=5)

@@ -46,7 +46,7 @@ RP_DEV void dma_offsets(unsigned (&v)[EXT / 32], int wave, int lane, int ld, int
 }
 
 template <int ALAY, int BLAY, int TM, int TN>
-__global__ __launch_bounds__(256, 2) void gemm_dma_kernel(GemmP p) {
+__global__ __launch_bounds__(256, (TM == 1 && TN == 3) ? 2 : 1) void gemm_dma_kernel(GemmP p) {
   constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32;
   constexpr int A_FL = BM * BK, B_FL = BN * BK, STAGE = A_FL + B_FL;
   constexpr int CST = 32 * TN + 4;

@@ -144,6 +144,17 @@ int rp_layernorm_bwd(const float* dy, const float* x, const float* gamma, const 
 /* out[c] = sum_r in[r][c]  (two-stage, fixed order).  workspace: rp_colsum_workspace_bytes(rows, cols). */
 size_t rp_colsum_workspace_bytes(int rows, int cols);
 int rp_colsum(const float* in, int rows, int cols, int ld, float* out, float* workspace, size_t workspace_bytes, void* stream);
+/* up to RP_COLSUM_MAX independent column sums in ONE stage-1 and ONE stage-2 launch (same arithmetic and order per task as
+ * rp_colsum): the bias / LayerNorm-affine gradients that end the backward of one reference module (autograd of
+ * vision_transformer.py:349-354 produces them one reduction at a time) */
+#define RP_COLSUM_MAX 8
+typedef struct RpColsumTask {
+  const float* in;
+  int rows, cols, ld;
+  float* out;
+} RpColsumTask;
+size_t rp_colsum_multi_workspace_bytes(const RpColsumTask* tasks, int n);
+int rp_colsum_multi(const RpColsumTask* tasks, int n, float* workspace, size_t workspace_bytes, void* stream);
 
 /* Image preprocessing (reference src/model.py:115-118,124-125; bit-exact): BGR->RGB, /255, ImageNet mean/std, nearest
  * resize to 224x224.  images [Z,3,H,W] fp32 0..255 -> out: channels-last memory [Z,224,224,3] of a [Z,3,224,224] tensor. */

@@ -28,6 +28,11 @@ class RpGemm(Structure):
                 ("ln_x", c_void_p), ("ln_mean", c_void_p), ("ln_rstd", c_void_p), ("ln_gamma", c_void_p), ("ln_part", c_void_p)]
 
 
+class RpColsumTask(Structure):
+    _fields_ = [("in_", c_void_p), ("rows", c_int), ("cols", c_int), ("ld", c_int), ("out", c_void_p)]
+
+
+RP_COLSUM_MAX = 8
 P, I, F, L = c_void_p, c_int, c_float, c_longlong
 _SIGS = {
     "rp_abi_version": (c_int, []),
@@ -46,6 +51,8 @@ _SIGS = {
     "rp_layernorm_bwd": (c_int, [P, P, P, P, P, P, P, P, P, I, I, P]),
     "rp_colsum_workspace_bytes": (c_size_t, [I, I]),
     "rp_colsum": (c_int, [P, I, I, I, P, P, c_size_t, P]),
+    "rp_colsum_multi_workspace_bytes": (c_size_t, [POINTER(RpColsumTask), I]),
+    "rp_colsum_multi": (c_int, [POINTER(RpColsumTask), I, P, c_size_t, P]),
     "rp_preprocess": (c_int, [P, P, I, I, I, P]),
     "rp_tokens_fwd": (c_int, [P, P, P, I, I, I, P]),
     "rp_tokens_fwd_nhwc": (c_int, [P, P, P, I, I, I, P]),

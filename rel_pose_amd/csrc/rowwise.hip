@@ -435,6 +435,86 @@ extern "C" int rp_colsum(const float* in, int rows, int cols, int ld, float* out
   return RP_OK;
 }
 
+// ---- several column sums in one pair of launches ------------------------------------------------------------------
+// The backward of one reference module ends with 3-4 independent column sums (bias gradients, LayerNorm gamma / beta
+// partials): each was two ~8 us launches of its own.  rp_colsum_multi runs up to RP_COLSUM_MAX of them as ONE stage-1 launch
+// (every task's (column group, row block) workgroups, flattened) and ONE stage-2 launch; arithmetic and summation order per
+// task are exactly rp_colsum's.
+struct ColsumMultiP {
+  const float* in[RP_COLSUM_MAX];
+  float* dst[RP_COLSUM_MAX];          // stage 1: workspace slab (or the output when the task has a single row block)
+  int rows[RP_COLSUM_MAX], cols[RP_COLSUM_MAX], ld[RP_COLSUM_MAX], rpb[RP_COLSUM_MAX], gx[RP_COLSUM_MAX];
+  int blk_end[RP_COLSUM_MAX];         // exclusive prefix sums of the tasks' workgroup counts
+  int n;
+};
+
+__global__ __launch_bounds__(256) void colsum_multi_kernel(ColsumMultiP p) {
+  __shared__ float red[4][64];
+  int t = 0;
+  while (t + 1 < p.n && (int)blockIdx.x >= p.blk_end[t]) ++t;
+  const int local = blockIdx.x - (t ? p.blk_end[t - 1] : 0);
+  const int bx = local % p.gx[t], by = local / p.gx[t];
+  const float* in = p.in[t];
+  const int rows = p.rows[t], cols = p.cols[t], ld = p.ld[t], rpb = p.rpb[t];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = bx * 64 + cl;
+  const int r0 = by * rpb, r1 = min(rows, r0 + rpb);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < cols) {
+    const float* base = in + c;
+    int r = r0 + rl;
+    for (; r + 12 < r1; r += 16) {
+      s0 += base[(long long)r * ld];
+      s1 += base[(long long)(r + 4) * ld];
+      s2 += base[(long long)(r + 8) * ld];
+      s3 += base[(long long)(r + 12) * ld];
+    }
+    for (; r < r1; r += 4) s0 += base[(long long)r * ld];
+  }
+  red[rl][cl] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (rl == 0 && c < cols) p.dst[t][(long long)by * cols + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+}
+
+extern "C" size_t rp_colsum_multi_workspace_bytes(const RpColsumTask* tasks, int n) {
+  size_t tot = 0;
+  for (int i = 0; i < n; ++i) tot += rp_colsum_workspace_bytes(tasks[i].rows, tasks[i].cols);
+  return tot;
+}
+
+extern "C" int rp_colsum_multi(const RpColsumTask* tasks, int n, float* workspace, size_t workspace_bytes, void* stream) {
+  if (!tasks || n <= 0 || n > RP_COLSUM_MAX) return RP_EBADSHAPE;
+  if (workspace_bytes < rp_colsum_multi_workspace_bytes(tasks, n)) return RP_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  ColsumMultiP p1{}, p2{};
+  int blocks1 = 0, blocks2 = 0;
+  float* ws = workspace;
+  for (int i = 0; i < n; ++i) {
+    const RpColsumTask& t = tasks[i];
+    if (t.rows <= 0 || t.cols <= 0 || !t.in || !t.out) return RP_EBADSHAPE;
+    const int rpb = colsum_stage1_rows(t.rows), nb = (t.rows + rpb - 1) / rpb, gx = (t.cols + 63) / 64;
+    p1.in[i] = t.in; p1.rows[i] = t.rows; p1.cols[i] = t.cols; p1.ld[i] = t.ld; p1.rpb[i] = rpb; p1.gx[i] = gx;
+    p1.dst[i] = nb == 1 ? t.out : ws;
+    blocks1 += gx * nb;
+    p1.blk_end[i] = blocks1;
+    if (nb > 1) {                        // second stage over the nb partial rows, exactly as rp_colsum does
+      const int j = p2.n++;
+      p2.in[j] = ws; p2.rows[j] = nb; p2.cols[j] = t.cols; p2.ld[j] = t.cols; p2.rpb[j] = nb; p2.gx[j] = gx; p2.dst[j] = t.out;
+      blocks2 += gx;
+      p2.blk_end[j] = blocks2;
+      ws += (size_t)nb * t.cols;
+    }
+  }
+  p1.n = n;
+  hipLaunchKernelGGL(colsum_multi_kernel, dim3(blocks1), dim3(256), 0, st, p1);
+  RP_CHECK_LAUNCH();
+  if (p2.n > 0) {
+    hipLaunchKernelGGL(colsum_multi_kernel, dim3(blocks2), dim3(256), 0, st, p2);
+    RP_CHECK_LAUNCH();
+  }
+  return RP_OK;
+}
+
 extern "C" int rp_tokens_fwd(const float* feat, const float* pos_embed, float* x, int Z, int C, int N, void* stream) {
   if (Z <= 0 || (C & 31) || (N & 31)) return RP_EBADSHAPE;
   hipLaunchKernelGGL(tokens_fwd_kernel, dim3(N / 32, C / 32, Z), dim3(256), 0, (hipStream_t)stream, feat, pos_embed, x,

@@ -284,11 +284,47 @@ def linear_dw(dy, x):
     return gemm(dy, x, N, K, M, a_layout=1, b_layout=1)
 
 
+COLSUM_BATCHING = os.environ.get("RP_COLSUM_BATCH", "1") == "1"      # A/B aid
+_COLSUM_BATCH = None      # inside `with colsum_batch():` the (input, output) pairs collected so far
+
+
+class colsum_batch:
+    """Collect the column sums requested inside the block and run them as one rp_colsum_multi (two launches for all of them
+    instead of two each) when the block exits.  The tensors colsum() returns inside the block are only FILLED at exit: return
+    them (or views of them), do not compute with them inside the block."""
+
+    def __enter__(self):
+        global _COLSUM_BATCH
+        self.prev, _COLSUM_BATCH = _COLSUM_BATCH, ([] if COLSUM_BATCHING else None)
+        return self
+
+    def __exit__(self, et, ev, tb):
+        global _COLSUM_BATCH
+        tasks, _COLSUM_BATCH = _COLSUM_BATCH, self.prev
+        if et is None and tasks:
+            for i in range(0, len(tasks), _lib.RP_COLSUM_MAX):
+                _colsum_multi(tasks[i:i + _lib.RP_COLSUM_MAX])
+        return False
+
+
+def _colsum_multi(pairs):
+    lib = _lib.load()
+    arr = (_lib.RpColsumTask * len(pairs))()
+    for a, (t, o) in zip(arr, pairs):
+        a.in_, a.rows, a.cols, a.ld, a.out = t.data_ptr(), t.shape[0], t.shape[1], t.shape[1], o.data_ptr()
+    nbytes = lib.rp_colsum_multi_workspace_bytes(arr, len(pairs))
+    ws = torch.empty(max(nbytes // 4, 1), device=pairs[0][0].device, dtype=torch.float32)
+    _lib.check(lib.rp_colsum_multi(arr, len(pairs), _p(ws), nbytes, _st()), "rp_colsum_multi")
+
+
 def colsum(t2d):
     lib = _lib.load()
     _chk(t2d)
     rows, cols = t2d.shape
     out = _empty(cols, like=t2d)
+    if _COLSUM_BATCH is not None:
+        _COLSUM_BATCH.append((t2d, out))          # filled when the enclosing colsum_batch exits
+        return out
     nbytes = lib.rp_colsum_workspace_bytes(rows, cols)
     ws = torch.empty(max(nbytes // 4, 1), device=t2d.device, dtype=torch.float32)
     _lib.check(lib.rp_colsum(_p(t2d), rows, cols, cols, _p(out), _p(ws), nbytes, _st()), "rp_colsum")
@@ -631,18 +667,20 @@ class BlockFn(torch.autograd.Function):
         dy = dy.contiguous().view(Z * N_TOK, DIM)
         fork = _Fork(dy.device)
         # the two LayerNorm backwards read dy / dx1 as their residual-branch operand anyway: they also return its column
-        # sums, which ARE the fc2 / proj bias gradients (two 57 MB column-sum passes per block saved)
-        (dx1, dn2w, dn2b, dfc2b), dfc1w, dfc1b, dfc2w, _ = _mlp_bwd(fork, dy, xn2, h, hpre, fc1_w, fc2_w, want_db2=False,
-                                                                     ln=(x1, n2w, m2, r2, dy))
-        fork.sync_side()
-        dprojw = fork.on_side(lambda: linear_dw(dx1, o))
-        do = linear_dx(dx1, proj_w)
-        dqkv = attn_bwd(qkv, o, lse, do, Z, fork, kv_xor=1 if ctx.cross else 0)
-        fork.sync_main()                                  # dQ pass (side) done before dqkv is consumed
-        fork.sync_side()
-        dqkvw, dqkvb = _param_grads(fork, dqkv, xn1)
-        dx, dn1w, dn1b, dprojb = linear_dx_lnbwd(dqkv, qkv_w, x2, n1w, m1, r1, add=dx1)
-        fork.sync_main()
+        # sums, which ARE the fc2 / proj bias gradients (two 57 MB column-sum passes per block saved).  The block's four column
+        # sums (LayerNorm partials x 2, fc1 and qkv bias gradients) run as one batched pair of launches at the end.
+        with colsum_batch():
+            (dx1, dn2w, dn2b, dfc2b), dfc1w, dfc1b, dfc2w, _ = _mlp_bwd(fork, dy, xn2, h, hpre, fc1_w, fc2_w, want_db2=False,
+                                                                         ln=(x1, n2w, m2, r2, dy))
+            fork.sync_side()
+            dprojw = fork.on_side(lambda: linear_dw(dx1, o))
+            do = linear_dx(dx1, proj_w)
+            dqkv = attn_bwd(qkv, o, lse, do, Z, fork, kv_xor=1 if ctx.cross else 0)
+            fork.sync_main()                                  # dQ pass (side) done before dqkv is consumed
+            fork.sync_side()
+            dqkvw, dqkvb = _param_grads(fork, dqkv, xn1)
+            dx, dn1w, dn1b, dprojb = linear_dx_lnbwd(dqkv, qkv_w, x2, n1w, m1, r1, add=dx1)
+            fork.sync_main()
         return (dx.view(Z, N_TOK, DIM), dn1w, dn1b, dqkvw, dqkvb, dprojw, dprojb, dn2w, dn2b, dfc1w, dfc1b, dfc2w,
                 dfc2b, None)
 
@@ -683,17 +721,18 @@ class CrossBlockFn(torch.autograd.Function):
         Z = ctx.Z
         dy = dy.contiguous().view(Z * 70, DIM)
         fork = _Fork(dy.device)
-        dfn, dfc1w, dfc1b, dfc2w, _ = _mlp_bwd(fork, dy, fn, h, hpre, fc1_w, fc2_w, want_db2=False)
-        df_, dn2w, dn2b, dfc2b = layernorm_bwd(dfn, f, n2w, m2, r2, add=dy)       # 4th: colsum(dy) = fc2 bias gradient
-        fork.sync_side()
-        dpfw_full, dpfb = _param_grads(fork, df_, g)
-        dg = linear_dx(df_, pf_wp)                                      # [Z*70, 224]
-        dF = emm_finalize_bwd(dg, Z)
-        dqkv = emm_backward(qkv, xa, t, rlse, clse, dF, Z, single=ctx.single, cross=ctx.cross)
-        fork.sync_side()
-        dqkvw, dqkvb = _param_grads(fork, dqkv, xn)
-        dx, dn1w, dn1b = linear_dx_lnbwd(dqkv, qkv_w, x2, n1w, m1, r1)
-        fork.sync_main()
+        with colsum_batch():
+            dfn, dfc1w, dfc1b, dfc2w, _ = _mlp_bwd(fork, dy, fn, h, hpre, fc1_w, fc2_w, want_db2=False)
+            df_, dn2w, dn2b, dfc2b = layernorm_bwd(dfn, f, n2w, m2, r2, add=dy)       # 4th: colsum(dy) = fc2 bias gradient
+            fork.sync_side()
+            dpfw_full, dpfb = _param_grads(fork, df_, g)
+            dg = linear_dx(df_, pf_wp)                                      # [Z*70, 224]
+            dF = emm_finalize_bwd(dg, Z)
+            dqkv = emm_backward(qkv, xa, t, rlse, clse, dF, Z, single=ctx.single, cross=ctx.cross)
+            fork.sync_side()
+            dqkvw, dqkvb = _param_grads(fork, dqkv, xn)
+            dx, dn1w, dn1b = linear_dx_lnbwd(dqkv, qkv_w, x2, n1w, m1, r1)
+            fork.sync_main()
         dpfw = dpfw_full[:, :ctx.pf_cols].contiguous()
         return (dx.view(Z, N_TOK, DIM), None, dn1w, dn1b, dqkvw, dqkvb, dpfw, dpfb, dn2w, dn2b, dfc1w, dfc1b, dfc2w,
                 dfc2b, None, None)
@@ -753,8 +792,9 @@ class HeadFn(torch.autograd.Function):
     def backward(ctx, dout):
         y2, m, r, fn, h1, h2, pred, nw, w0, w2, w4p = ctx.saved_tensors
         B = ctx.B
-        dfeats, dw0, db0, dw2, db2, dw4, db4 = _regress_bwd(dout, fn.view(B, -1), h1, h2, pred, w0, w2, w4p)
-        dy, dnw, dnb = layernorm_bwd(dfeats.view(-1, DIM), y2, nw, m, r)
+        with colsum_batch():
+            dfeats, dw0, db0, dw2, db2, dw4, db4 = _regress_bwd(dout, fn.view(B, -1), h1, h2, pred, w0, w2, w4p)
+            dy, dnw, dnb = layernorm_bwd(dfeats.view(-1, DIM), y2, nw, m, r)
         return dy.view(2 * B, 70, DIM), None, dnw, dnb, dw0, db0, dw2, db2, dw4, db4
 
 
@@ -774,7 +814,8 @@ class RegressFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         feats, h1, h2, pred, w0, w2, w4p = ctx.saved_tensors
-        dfeats, dw0, db0, dw2, db2, dw4, db4 = _regress_bwd(dout, feats, h1, h2, pred, w0, w2, w4p)
+        with colsum_batch():
+            dfeats, dw0, db0, dw2, db2, dw4, db4 = _regress_bwd(dout, feats, h1, h2, pred, w0, w2, w4p)
         return dfeats, None, dw0, db0, dw2, db2, dw4, db4
 
 

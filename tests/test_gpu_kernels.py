@@ -608,3 +608,16 @@ def test_svd3x3_and_essential_matrix_vs_lapack(ops):
     U, S, V = geom.svd3x3(E)
     assert float(((S[:, 0] - S[:, 1]).abs() / S[:, 0]).max()) < 3e-6 and float((S[:, 2] / S[:, 0]).max()) < 3e-6   # (s, s, 0)
     report("svd3x3", **worst)
+
+
+def test_batched_column_sums_equal_individual_ones(ops):
+    """rp_colsum_multi: several column sums in one pair of launches give bit-identical results to rp_colsum one by one
+    (same stage split, same summation order), incl. a single-stage task, a ragged column count and more than 8 tasks."""
+    shapes = [(73728, 576), (1152, 768), (1152, 576), (300, 14), (64, 192), (5000, 100), (1152, 384), (2, 512), (9000, 64), (1, 8)]
+    ins = [rnd(r, c, seed=100 + i) for i, (r, c) in enumerate(shapes)]
+    ref = [ops.colsum(t) for t in ins]
+    with ops.colsum_batch():
+        got = [ops.colsum(t) for t in ins]
+    for a, b, t in zip(got, ref, ins):
+        assert torch.equal(a, b)
+        assert rel(a, t.double().sum(0)) < 1e-5

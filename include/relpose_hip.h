@@ -246,6 +246,17 @@ int rp_pose_normalize_fwd(const float* pred, const float* gs, float* out, int B,
 int rp_pose_normalize_bwd(const float* pred, const float* dout, float* dpred, int B, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Training-time augmentation of a resident batch (RGBDAugmentor, src/data_readers/augmentation.py:7-37):
+ * ColorJitter(brightness, contrast, saturation, hue; per-pair order) + RandomGrayscale + nearest resize, one parameter row
+ * per pair: params[b] = {order[4] (0 brightness, 1 contrast, 2 saturation, 3 hue), b, c, s, h, gray (0/1)} as 9 floats.
+ * images: uint8 [B,2,H,W,3] BGR as decoded (cv2 / PIL convention of the readers); out: fp32 [B,2,3,Ho,Wo] BGR 0..255 = the
+ * input layout of ViTEss.forward.  workspace: B * rp_augment_blocks() doubles.
+ * ------------------------------------------------------------------------------------------- */
+int rp_augment_blocks(void);
+int rp_augment_pairs(const unsigned char* images, const float* params, float* out, double* workspace, int B, int H, int W,
+                     int Ho, int Wo, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Essential-matrix auxiliary (BASELINE.json north_star: "per-pair 3x3 SVD as a one-warp Jacobi sweep with no MFMA").
  * NOT on ViTEss.forward's output path: the reference regresses R,t and never decomposes a matrix (src/model.py:91-98,
  * 145-159), so parity forbids an SVD there.  Offered for consumers of the predicted pose:

@@ -128,6 +128,33 @@ class RGBDAugmentor:
         images = F.interpolate(images, size=self.reshape_size)          # nearest, like the reference (:36)
         return images, poses, intrinsics
 
+    def draw_batch(self, B):
+        """B parameter rows for rp_augment_pairs: [order0..3, b, c, s, h, gray] (fp32, CPU)"""
+        order = torch.argsort(torch.rand(B, 4, generator=self.generator), dim=1).float()      # a uniform random permutation per row
+        u = torch.rand(B, 5, generator=self.generator)
+        lo = torch.tensor([1 - self.brightness, 1 - self.contrast, 1 - self.saturation, -self.hue])
+        span = 2 * torch.tensor([self.brightness, self.contrast, self.saturation, self.hue])
+        return torch.cat((order, lo + span * u[:, :4], (u[:, 4:] < self.p_gray).float()), dim=1)
+
+    @staticmethod
+    def params_to_dict(row):
+        """one draw_batch row as the dict `apply` takes (the checker of the HIP kernel in tests/)"""
+        r = row.tolist()
+        return dict(order=[int(v) for v in r[:4]], b=r[4], c=r[5], s=r[6], h=r[7], gray=bool(r[8]))
+
+    def augment_batch_hip(self, images_u8, intrinsics, params=None):
+        """the GPU-rate path: images_u8 [B,2,H,W,3] uint8 BGR as decoded (what the readers return with
+        raw=True), resident on the GPU; one fused HIP pass does the BGR->RGB conversion, the four jitter ops in each pair's
+        order, the greyscale draw and the nearest resize (csrc/augment.hip).  intrinsics [B,2,4] are rescaled in place."""
+        from .. import ops
+        B, _, H, W, _ = images_u8.shape
+        sizey, sizex = self.reshape_size
+        prm = self.draw_batch(B) if params is None else params
+        out = ops.augment_pairs(images_u8, prm.to(images_u8.device, non_blocking=True), sizey, sizex)
+        sc = torch.tensor([sizex / W, sizey / H] * 2, dtype=intrinsics.dtype, device=intrinsics.device)
+        intrinsics.mul_(sc)
+        return out, intrinsics
+
     def augment_batch(self, images, intrinsics):
         """device-side variant for a resident batch: images [B,2,3,H,W], intrinsics [B,2,4] (modified in place);
         per-pair parameter draws, all arithmetic on images.device"""

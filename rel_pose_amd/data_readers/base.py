@@ -15,7 +15,11 @@ def imread_bgr(path):
 
 class RGBDDataset(data.Dataset):
     def __init__(self, name, datapath, reshape_size=[384, 512], subepoch=None, is_training=True, gpu=0,
-                 streetlearn_interiornet_type=None, use_mini_dataset=False):
+                 streetlearn_interiornet_type=None, use_mini_dataset=False, raw=False):
+        # raw=True (not in the reference): samples are (uint8 [2,H,W,3] BGR as decoded, poses, UNSCALED intrinsics); the colour
+        # jitter + resize + intrinsics rescale then run once per batch on the GPU (RGBDAugmentor.augment_batch_hip).  The
+        # reference's per-sample CPU augmentation feeds ~26 pairs/s per core (profiles/r2_loader_bench.txt).
+        self.raw = raw
         self.root = datapath
         self.name = name
         self.streetlearn_interiornet_type = streetlearn_interiornet_type
@@ -35,6 +39,11 @@ class RGBDDataset(data.Dataset):
 
     def _load(self, index):
         files = self.scene_info["images"][index]
+        if self.raw:
+            images = torch.from_numpy(np.stack([self.__class__.image_read(f) for f in files]))
+            poses = torch.from_numpy(np.stack(self.scene_info["poses"][index]).astype(np.float32))
+            intrinsics = torch.from_numpy(np.stack(self.scene_info["intrinsics"][index]).astype(np.float32))
+            return images, poses, intrinsics
         images = np.stack([self.__class__.image_read(f) for f in files]).astype(np.float32)
         images = torch.from_numpy(images).permute(0, 3, 1, 2)
         poses = torch.from_numpy(np.stack(self.scene_info["poses"][index]).astype(np.float32))

@@ -973,3 +973,21 @@ def maxpool3x3s2(pool, x):
     if not x.is_cuda:
         return pool(x)
     return MaxPool3x3s2Fn.apply(x)
+
+
+def augment_pairs(images_u8, params, out_h, out_w):
+    """rp_augment_pairs: uint8 [B,2,H,W,3] BGR + params [B,9] -> fp32 [B,2,3,out_h,out_w] BGR 0..255 (csrc/augment.hip)."""
+    lib = _lib.load()
+    if images_u8.dtype != torch.uint8 or images_u8.dim() != 5 or images_u8.shape[1] != 2 or images_u8.shape[4] != 3:
+        raise ValueError("augment_pairs wants uint8 [B,2,H,W,3], got %s %s" % (images_u8.dtype, tuple(images_u8.shape)))
+    if not images_u8.is_cuda:
+        raise RuntimeError("augment_pairs: HIP kernel, the batch must be resident on the GPU")
+    images_u8 = images_u8.contiguous()
+    params = params.to(torch.float32).contiguous()
+    B, _, H, W, _ = images_u8.shape
+    if tuple(params.shape) != (B, 9):
+        raise ValueError("augment_pairs params must be [B,9]")
+    out = torch.empty(B, 2, 3, out_h, out_w, device=images_u8.device, dtype=torch.float32)
+    ws = torch.empty(B * lib.rp_augment_blocks(), device=images_u8.device, dtype=torch.float64)
+    _lib.check(lib.rp_augment_pairs(_p(images_u8), _p(params), _p(out), _p(ws), B, H, W, out_h, out_w, _st()), "rp_augment_pairs")
+    return out

@@ -67,6 +67,32 @@ def test_matterport_reader_conventions(matterport_root):
     assert alias.dataset_factory is dataset_factory
 
 
+def test_raw_reader_mode_and_batched_parameter_draws(matterport_root):
+    """raw=True (decode-only workers for the GPU augmentation path): uint8 BGR as decoded, unscaled intrinsics, same poses;
+    draw_batch rows are valid rp_augment_pairs parameter rows inside ColorJitter's ranges (augmentation.py:12-16)."""
+    from rel_pose_amd.data_readers.augmentation import RGBDAugmentor
+    from rel_pose_amd.data_readers.base import imread_bgr
+    from rel_pose_amd.data_readers.matterport import Matterport
+    root, data = matterport_root
+    db = Matterport(datapath=root, subepoch=0, reshape_size=[96, 128], raw=True)
+    ref = Matterport(datapath=root, subepoch=0, reshape_size=[96, 128])
+    images, poses, intr = db[2]
+    assert images.dtype == torch.uint8 and images.shape == (2, 48, 64, 3)
+    assert np.array_equal(images[1].numpy(), imread_bgr(ref.scene_info["images"][2][1]))
+    assert torch.equal(poses, ref[2][1]) and torch.allclose(intr[0], torch.tensor([517.97, 517.97, 320.0, 240.0]))
+    bi, bp, bk = next(iter(torch.utils.data.DataLoader(db, batch_size=3)))
+    assert bi.shape == (3, 2, 48, 64, 3) and bi.dtype == torch.uint8
+    aug = RGBDAugmentor(reshape_size=[96, 128], generator=torch.Generator().manual_seed(0))
+    prm = aug.draw_batch(4000)
+    assert prm.shape == (4000, 9) and torch.equal(prm[:, :4].sort(dim=1).values, torch.arange(4.0).expand(4000, 4))
+    assert len({tuple(r) for r in prm[:, :4].int().tolist()}) == 24                         # every order occurs
+    for col, lo, hi in ((4, .75, 1.25), (5, .75, 1.25), (6, .75, 1.25), (7, -.4 / 3.14, .4 / 3.14)):
+        assert lo <= float(prm[:, col].min()) and float(prm[:, col].max()) <= hi and float(prm[:, col].std()) > 0.25 * (hi - lo)
+    assert 0.07 < float(prm[:, 8].mean()) < 0.13                                            # RandomGrayscale(p=0.1)
+    d = RGBDAugmentor.params_to_dict(prm[0])
+    assert sorted(d["order"]) == [0, 1, 2, 3] and isinstance(d["gray"], bool)
+
+
 def test_panorama_readers_and_viewpoint_rotation(tmp_path):
     from rel_pose_amd.data_readers.interiornet import InteriorNet
     from rel_pose_amd.data_readers.streetlearn import StreetLearn

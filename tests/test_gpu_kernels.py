@@ -621,3 +621,42 @@ def test_batched_column_sums_equal_individual_ones(ops):
     for a, b, t in zip(got, ref, ins):
         assert torch.equal(a, b)
         assert rel(a, t.double().sum(0)) < 1e-5
+
+
+def test_fused_augmentation_matches_the_tensor_implementation(ops):
+    """rp_augment_pairs (uint8 BGR pairs -> jittered, resized fp32 model input) against RGBDAugmentor.apply + F.interpolate,
+    the plain-tensor statement of the reference's ColorJitter / RandomGrayscale / nearest-resize chain
+    (src/data_readers/augmentation.py:7-37), with the SAME parameter rows: every op order class, grey on and off, identity.
+    Tolerance 0.02 grey levels on the 0..255 scale (fp32 arithmetic in a different association; the pair-mean luma is
+    accumulated in fp64 by the kernel and in fp32 by torch)."""
+    import itertools
+    import torch.nn.functional as F
+    from rel_pose_amd.data_readers.augmentation import RGBDAugmentor
+    g = torch.Generator().manual_seed(5)
+    aug = RGBDAugmentor(reshape_size=[96, 128], generator=g)
+    perms = list(itertools.permutations(range(4)))
+    B, H, W = len(perms) + 2, 120, 160
+    img = torch.randint(0, 256, (B, 2, H, W, 3), generator=g, dtype=torch.uint8)
+    img[3, :, :, :40] = img[3, :, :, :1, :1]                      # flat regions: max == min (hue of a grey pixel), saturated colours
+    img[4, 0] = 255
+    img[4, 1] = 0
+    prm = aug.draw_batch(B)
+    prm[:len(perms), :4] = torch.tensor(perms, dtype=torch.float32)
+    prm[:, 8] = (torch.arange(B) % 5 == 0).float()
+    prm[-1] = torch.tensor([0, 1, 2, 3, 1.0, 1.0, 1.0, 0.0, 0.0])  # identity jitter: the output must be the resized input exactly
+    prm[-2, 4:8] = torch.tensor([1.25, 0.75, 1.25, 0.4 / 3.14])  # corner of the parameter box
+    intr = torch.tensor([[517.97, 517.97, 320.0, 240.0]]).repeat(B, 2, 1).cuda()
+    out, intr2 = aug.augment_batch_hip(img.cuda(), intr, params=prm)
+    assert out.shape == (B, 2, 3, 96, 128) and out.dtype == torch.float32
+    assert torch.allclose(intr2[0, 0].cpu(), torch.tensor([517.97 * 128 / 160, 517.97 * 96 / 120, 320.0 * 128 / 160, 240.0 * 96 / 120]))
+    worst = 0.0
+    for b in range(B):
+        x = img[b].permute(0, 3, 1, 2).float().cuda()
+        ref = F.interpolate(RGBDAugmentor.apply(x, RGBDAugmentor.params_to_dict(prm[b])), size=[96, 128])
+        worst = max(worst, float((out[b] - ref).abs().max()))
+    ident = F.interpolate(img[-1].permute(0, 3, 1, 2).float(), size=[96, 128]).cuda()
+    assert float((out[-1] - ident).abs().max()) < 1e-3
+    report("augment_pairs", max_abs_grey_levels=worst)
+    assert worst < 0.02
+    with pytest.raises(ValueError):
+        ops.augment_pairs(img.float().cuda(), prm.cuda(), 96, 128)

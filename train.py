@@ -135,12 +135,22 @@ def run(args):
             from rel_pose_amd.data_readers.factory import dataset_factory
             db = dataset_factory([args.dataset], datapath=args.datapath, subepoch=subepoch, is_training=is_training, gpu=local,
                                  streetlearn_interiornet_type=args.streetlearn_interiornet_type,
-                                 use_mini_dataset=args.use_mini_dataset, reshape_size=list(args.image_size))
+                                 use_mini_dataset=args.use_mini_dataset, reshape_size=list(args.image_size),
+                                 raw=device_augment)
         smp = (torch.utils.data.distributed.DistributedSampler(db, num_replicas=world, rank=rank, shuffle=is_training)
                if ddp else None)
         ld = torch.utils.data.DataLoader(db, batch_size=args.batch, sampler=smp, shuffle=(smp is None and is_training),
                                          num_workers=args.num_workers, pin_memory=True, drop_last=is_training)
         return ld, smp, is_training
+
+    # Input pipeline: with --device_augment (default on a GPU) the workers only decode; colour jitter, resize
+    # and the intrinsics rescale run once per batch in rp_augment_pairs.  --no_device_augment = the reference's per-sample
+    # CPU augmentation inside the workers (26 pairs/s per core here, profiles/r2_loader_bench.txt).
+    device_augment = args.device_augment and dev.type == "cuda" and args.dataset != "synthetic"
+    augmentor = None
+    if device_augment:
+        from rel_pose_amd.data_readers.augmentation import RGBDAugmentor
+        augmentor = RGBDAugmentor(reshape_size=list(args.image_size))
 
     os.makedirs("output/%s/checkpoints" % args.name, exist_ok=True)
     step, t0 = (resumed_step if resume else 0), time.time()
@@ -153,6 +163,8 @@ def run(args):
         val = []
         for images, poses, intr in loader:
             images, poses, intr = images.to(dev, non_blocking=True), poses.to(dev), intr.to(dev)
+            if augmentor is not None:
+                images, intr = augmentor.augment_batch_hip(images, intr)
             Ps = SE3(poses)
             Gs = SE3.IdentityLike(Ps)
             if not is_training:                       # validation pass (reference train.py:147-150)
@@ -195,6 +207,10 @@ def parser():
     ap.add_argument("--clip", type=float, default=2.5)
     ap.add_argument("--weight_decay", type=float, default=1e-5)
     ap.add_argument("--num_workers", type=int, default=4)
+    ap.add_argument("--device_augment", dest="device_augment", action="store_true", default=True,
+                    help="decode-only workers + fused colour jitter / resize on the GPU (default)")
+    ap.add_argument("--no_device_augment", dest="device_augment", action="store_false",
+                    help="the reference's per-sample CPU augmentation inside the DataLoader workers")
     ap.add_argument("--no_ddp", action="store_true", default=False)
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--ckpt", help="checkpoint to restore")

@@ -246,6 +246,28 @@ int rp_pose_normalize_fwd(const float* pred, const float* gs, float* out, int B,
 int rp_pose_normalize_bwd(const float* pred, const float* dout, float* dpred, int B, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Row-resident Linear for K = 192 (qkv, attention proj, fc1; vision_transformer.py:323,330,352-353, mlp.py:22-23), with the
+ * LayerNorm that precedes it optionally fused in:
+ *   y = act(LN?(x) W^T + bias) (+ residual),  x [M,192], W [N,192] (nn.Linear layout), N % 32 == 0, N <= 1024.
+ * ln_gamma/ln_beta non-NULL: x is layer-normalised (eps) on the way into the MFMA operand registers; xn_out [M,192], mean_out
+ * [M], rstd_out [M] (each optional) receive what the backward needs.  y_pre (optional) receives the pre-activation.
+ * act: 0 none, 1 GELU.  No workspace.
+ * ------------------------------------------------------------------------------------------- */
+int rp_linear_rows192(const float* x, const float* w, const float* bias, const float* residual, const float* ln_gamma,
+                      const float* ln_beta, float eps, float* y, float* y_pre, float* xn_out, float* mean_out, float* rstd_out,
+                      int M, int N, int K, int act, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused transformer MLP, inference path (vision_transformer.py:353 + vit_layers/mlp.py:20-26):
+ *   y = x + fc2(GELU(fc1(LayerNorm(x; gamma, beta, eps)) + b1)) + b2,   x, y [M, dim], w1 [hidden, dim], w2 [dim, hidden]
+ * (nn.Linear layouts).  The normalised rows and the hidden activation stay in registers / LDS.  dim = 192, hidden = 768 only
+ * (RP_EBADSHAPE otherwise).  workspace: rp_mlp_fused_workspace_bytes(M) bytes (partial tiles of the stream-K split).
+ * ------------------------------------------------------------------------------------------- */
+size_t rp_mlp_fused_workspace_bytes(int M);
+int rp_mlp_fused_fwd(const float* x, const float* gamma, const float* beta, const float* w1, const float* b1, const float* w2,
+                     const float* b2, float* y, void* workspace, int M, int dim, int hidden, float eps, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Training-time augmentation of a resident batch (RGBDAugmentor, src/data_readers/augmentation.py:7-37):
  * ColorJitter(brightness, contrast, saturation, hue; per-pair order) + RandomGrayscale + nearest resize, one parameter row
  * per pair: params[b] = {order[4] (0 brightness, 1 contrast, 2 saturation, 3 hue), b, c, s, h, gray (0/1)} as 9 floats.

@@ -75,6 +75,9 @@ _SIGS = {
     "rp_emm_grad_ds": (c_int, [P, I, P, P, P, P, P, P, P, P, I, I, F, I, I, P]),
     "rp_pose_normalize_fwd": (c_int, [P, P, P, I, P]),
     "rp_pose_normalize_bwd": (c_int, [P, P, P, I, P]),
+    "rp_linear_rows192": (c_int, [P, P, P, P, P, P, F, P, P, P, P, P, I, I, I, I, P]),
+    "rp_mlp_fused_workspace_bytes": (ctypes.c_size_t, [I]),
+    "rp_mlp_fused_fwd": (c_int, [P, P, P, P, P, P, P, P, P, I, I, I, ctypes.c_float, P]),
     "rp_augment_blocks": (c_int, []),
     "rp_augment_pairs": (c_int, [P, P, P, P, I, I, I, I, I, P]),
     "rp_essential_from_pose": (c_int, [P, P, I, P]),

@@ -1,0 +1,320 @@
+// mlp_fused.hip -- the transformer MLP of a Block as ONE kernel with the hidden activation kept on chip:
+//     y = x + fc2(GELU(fc1(LayerNorm(x)) + b1)) + b2          reference vision_transformer.py:353, vit_layers/mlp.py:20-26
+// for the ViT of rel_pose (C = 192, hidden = 768).  Inference path (no activations are saved): x is read once, y written
+// once; the normalised rows, the [rows, 768] hidden activation and its pre-activation never exist in HBM (the unfused
+// chain moves 3 x 226 MB per Block at 64 pairs for them).
+//
+// Work decomposition.  A wave owns 16 token rows for the whole kernel; the hidden dimension is streamed in chunks of 32
+// units.  Everything is computed TRANSPOSED with v_mfma_f32_16x16x4_f32 (exact fp32; the one fp32 MFMA that sustains its
+// datasheet rate at every occupancy on gfx950, profiles/r2_mfma_ceiling.txt):
+//     A operand: lane l holds A[i = l&15][k = l>>4]     B operand: lane l holds B[k = l>>4][j = l&15]
+//     D        : reg r of lane l is D[i = 4*(l>>4) + r][j = l&15]
+//   GEMM1   H^T[unit, row] = sum_k W1[unit, k] * Xn[row, k]      A = W1 rows from LDS, B = the wave's normalised rows, RESIDENT
+//                                                                 in 48 VGPRs (lane (j, q) holds Xn[row j][16t + 4q + 0..3])
+//   bias + GELU (branch-free erfc form, <= 1 ulp of the exact-erf value: common.h gelu_fast) on the 8 accumulator registers
+//   GEMM2   Y^T[col, row] += sum_unit W2[col, unit] * H[unit, row]   A = W2 rows from LDS, B = THE GEMM1 ACCUMULATORS: reg r of
+//                                                                 lane (j, q) is H[unit 4q + r][row j] = the B operand of k-step r,
+//                                                                 so the hidden activation never leaves the register file.
+// The contraction order inside a k-group is free, so both A operands are read as one ds_read_b128 per 4 k-steps.
+// Weights: W1 chunk [32 x 192] and W2 chunk [192 x 32] (24 KB each) are staged by LDS-DMA (global_load_lds_dwordx4, lane-linear
+// -> unpadded tiles, XOR-swizzled 16-byte chunks so that the 16 rows one read group touches fall into 16 distinct bank groups);
+// single-buffered, two barriers per chunk: W2(c) streams in under GEMM1(c), W1(c+1) under GEMM2(c).
+//
+// Balance (stream-K).  The work list is (row tile of 16*NW rows) x (24 chunks), cut into gridDim.x equal contiguous ranges, one per
+// resident workgroup: 576 row tiles on 512 workgroup slots would otherwise run as 1 + 1/8 rounds.  A workgroup that owns all 24
+// chunks of a tile finishes it (bias, residual, store); otherwise it writes its partial Y tile to the workspace and
+// mlp_fixup_kernel adds the (at most few) partials of that tile in chunk order -- fixed order, no atomics, deterministic.
+#include <stdlib.h>
+#include "common.h"
+#include "../../include/relpose_hip.h"
+
+namespace {
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+RP_DEV f32x4v mfma16(float a, float b, f32x4v c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+constexpr int C = 192, HID = 768, CH = 32, NCHUNK = HID / CH;
+constexpr int W1T = CH * C, W2T = C * CH;                      // floats per staged tile (6144 each = 24 KB)
+
+struct MlpP {
+  const float *x, *gamma, *beta, *w1, *b1, *w2, *b2;
+  float* y;
+  float* part;       // [gridDim.x * P][rows per tile][C] partial tiles
+  int M;
+  float eps;
+  int tiles, base, rem, P;
+};
+
+RP_DEV void item_range(const MlpP& p, int b, int& start, int& count) {
+  start = b * p.base + min(b, p.rem);
+  count = p.base + (b < p.rem ? 1 : 0);
+}
+
+template <int NW, int WPS>
+__global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
+  constexpr int NT = NW * 64, ROWS = NW * 16;
+  constexpr int DMA = (W1T / 4) / NT;                           // 16-byte chunks per thread per tile (3 for NW = 8)
+  static_assert((W1T / 4) % NT == 0, "tile must be a whole number of DMA rounds");
+  __shared__ __attribute__((aligned(16))) float w1t[W1T];
+  __shared__ __attribute__((aligned(16))) float w2t[W2T];
+  __shared__ __attribute__((aligned(16))) float b1s[HID];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, q = lane >> 4;
+  for (int i = tid; i < HID; i += NT) b1s[i] = p.b1[i];
+
+  // DMA source offsets (bytes) of this thread's LDS positions; LDS position pp (16-byte units) = round * NT + tid
+  unsigned off1[DMA], off2[DMA];
+#pragma unroll
+  for (int r = 0; r < DMA; ++r) {
+    const int pp = r * NT + tid;
+    const int row1 = pp / 48, ch1 = (pp % 48) ^ (row1 & 15);
+    off1[r] = (unsigned)((row1 * C + ch1 * 4) * 4);
+    const int row2 = pp >> 3, ch2 = (pp & 7) ^ ((row2 >> 1) & 7);
+    off2[r] = (unsigned)((row2 * HID + ch2 * 4) * 4);
+  }
+  const unsigned l1 = lds_byte_addr(w1t) + wave * 1024, l2 = lds_byte_addr(w2t) + wave * 1024;
+  auto issue_w1 = [&](int c) {
+    const float* src = uniform_ptr(p.w1 + (long long)c * CH * C);
+#pragma unroll
+    for (int r = 0; r < DMA; ++r) glds16(src, off1[r], l1 + r * NT * 16);
+  };
+  auto issue_w2 = [&](int c) {
+    const float* src = uniform_ptr(p.w2 + c * CH);
+#pragma unroll
+    for (int r = 0; r < DMA; ++r) glds16(src, off2[r], l2 + r * NT * 16);
+  };
+
+  int it, cnt;
+  item_range(p, blockIdx.x, it, cnt);
+  const int end = it + cnt;
+  if (cnt > 0) issue_w1(it % NCHUNK);
+  int seg = 0;
+  while (it < end) {
+    const int tile = it / NCHUNK, c0 = it % NCHUNK, c1 = min(NCHUNK, c0 + end - it);
+    const int row = tile * ROWS + wave * 16 + j;
+    const bool live = row < p.M;
+    const float* xr = p.x + (long long)min(row, p.M - 1) * C + 4 * q;
+    // ---- LayerNorm of the wave's 16 rows straight into the B-operand registers (lane (j, q): columns 16t + 4q + 0..3)
+    float xn[48];
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 12; ++t) {
+      const float4 v = ld4(xr + 16 * t);
+      xn[4 * t] = v.x; xn[4 * t + 1] = v.y; xn[4 * t + 2] = v.z; xn[4 * t + 3] = v.w;
+      s += (v.x + v.y) + (v.z + v.w);
+    }
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    const float mu = s * (1.0f / C);
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < 48; ++i) {
+      const float d = xn[i] - mu;
+      var += d * d;
+    }
+    var += __shfl_xor(var, 16, 64);
+    var += __shfl_xor(var, 32, 64);
+    const float rs = 1.0f / sqrtf(var * (1.0f / C) + p.eps);
+#pragma unroll
+    for (int t = 0; t < 12; ++t) {
+      const float4 g = ld4(p.gamma + 16 * t + 4 * q), bb = ld4(p.beta + 16 * t + 4 * q);
+      xn[4 * t] = (xn[4 * t] - mu) * rs * g.x + bb.x;
+      xn[4 * t + 1] = (xn[4 * t + 1] - mu) * rs * g.y + bb.y;
+      xn[4 * t + 2] = (xn[4 * t + 2] - mu) * rs * g.z + bb.z;
+      xn[4 * t + 3] = (xn[4 * t + 3] - mu) * rs * g.w + bb.w;
+    }
+    f32x4v acc[12];
+#pragma unroll
+    for (int ob = 0; ob < 12; ++ob) acc[ob] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+    for (int c = c0; c < c1; ++c, ++it) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // W1(c) landed everywhere; W2 tile free
+      issue_w2(c);
+      // ---- GEMM1: two 16-unit blocks, K = 192
+      f32x4v h0 = {0.f, 0.f, 0.f, 0.f}, h1 = {0.f, 0.f, 0.f, 0.f};
+      const float* a0p = w1t + j * C;
+      const float* a1p = w1t + (16 + j) * C;
+      float4 a0 = ld4(a0p + ((q ^ j) * 4)), a1 = ld4(a1p + ((q ^ j) * 4));
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);            // group 0's reads; the loop keeps one group of reads in flight
+#pragma unroll
+      for (int t = 0; t < 12; ++t) {
+        float4 n0 = a0, n1 = a1;
+        if (t + 1 < 12) {                                           // next k-group's operands are in flight under these MFMAs
+          const int ch = ((4 * (t + 1) + q) ^ j) * 4;
+          n0 = ld4(a0p + ch);
+          n1 = ld4(a1p + ch);
+        }
+        h0 = mfma16(a0.x, xn[4 * t], h0);
+        h1 = mfma16(a1.x, xn[4 * t], h1);
+        h0 = mfma16(a0.y, xn[4 * t + 1], h0);
+        h1 = mfma16(a1.y, xn[4 * t + 1], h1);
+        h0 = mfma16(a0.z, xn[4 * t + 2], h0);
+        h1 = mfma16(a1.z, xn[4 * t + 2], h1);
+        h0 = mfma16(a0.w, xn[4 * t + 3], h0);
+        h1 = mfma16(a1.w, xn[4 * t + 3], h1);
+        a0 = n0;
+        a1 = n1;
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);          // the two ds_read_b128 of the NEXT group first ...
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);          // ... then this group's eight MFMAs
+      }
+      {
+        const float4 ba = ld4(b1s + c * CH + 4 * q), bb = ld4(b1s + c * CH + 16 + 4 * q);
+        h0[0] = gelu_fast(h0[0] + ba.x); h0[1] = gelu_fast(h0[1] + ba.y);
+        h0[2] = gelu_fast(h0[2] + ba.z); h0[3] = gelu_fast(h0[3] + ba.w);
+        h1[0] = gelu_fast(h1[0] + bb.x); h1[1] = gelu_fast(h1[1] + bb.y);
+        h1[2] = gelu_fast(h1[2] + bb.z); h1[3] = gelu_fast(h1[3] + bb.w);
+      }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // W2(c) landed everywhere; W1 tile free
+      if (it + 1 < end) issue_w1((it + 1) % NCHUNK);
+      // ---- GEMM2: 12 column blocks of 16, K = the 32 units of this chunk
+      auto w2frag = [&](int ob, float4& f0, float4& f1) {
+        const int r2 = 16 * ob + j, sw = (r2 >> 1) & 7;
+        const float* ap = w2t + r2 * CH;
+        f0 = ld4(ap + ((q ^ sw) * 4));
+        f1 = ld4(ap + (((4 + q) ^ sw) * 4));
+      };
+      float4 g0, g1;
+      w2frag(0, g0, g1);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+      for (int ob = 0; ob < 12; ++ob) {
+        float4 n0 = g0, n1 = g1;
+        if (ob + 1 < 12) w2frag(ob + 1, n0, n1);
+        acc[ob] = mfma16(g0.x, h0[0], acc[ob]);
+        acc[ob] = mfma16(g0.y, h0[1], acc[ob]);
+        acc[ob] = mfma16(g0.z, h0[2], acc[ob]);
+        acc[ob] = mfma16(g0.w, h0[3], acc[ob]);
+        acc[ob] = mfma16(g1.x, h1[0], acc[ob]);
+        acc[ob] = mfma16(g1.y, h1[1], acc[ob]);
+        acc[ob] = mfma16(g1.z, h1[2], acc[ob]);
+        acc[ob] = mfma16(g1.w, h1[3], acc[ob]);
+        g0 = n0;
+        g1 = n1;
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+      }
+    }
+    // ---- epilogue: lane (j, q) holds Y[row j][16 ob + 4q + 0..3]
+    if (c0 == 0 && c1 == NCHUNK) {
+      if (live) {
+        float* yr = p.y + (long long)row * C + 4 * q;
+#pragma unroll
+        for (int ob = 0; ob < 12; ++ob) {
+          const float4 r = ld4(xr + 16 * ob), b2 = ld4(p.b2 + 16 * ob + 4 * q);
+          st4(yr + 16 * ob, make_float4(acc[ob][0] + b2.x + r.x, acc[ob][1] + b2.y + r.y, acc[ob][2] + b2.z + r.z,
+                                        acc[ob][3] + b2.w + r.w));
+        }
+      }
+    } else {
+      float* pr = p.part + (((long long)blockIdx.x * p.P + seg) * ROWS + wave * 16 + j) * C + 4 * q;
+#pragma unroll
+      for (int ob = 0; ob < 12; ++ob) st4(pr + 16 * ob, make_float4(acc[ob][0], acc[ob][1], acc[ob][2], acc[ob][3]));
+    }
+    ++seg;
+  }
+}
+
+// y[tile] = x + b2 + sum of the tile's partials in chunk order, for the tiles that no single workgroup finished
+template <int ROWS>
+__global__ __launch_bounds__(256) void mlp_fixup_kernel(MlpP p, int G) {
+  const int tile = blockIdx.y;
+  const int first = tile * NCHUNK, last = first + NCHUNK - 1;
+  auto owner = [&](int item) {
+    const int big = p.rem * (p.base + 1);
+    return item < big ? item / (p.base + 1) : p.rem + (item - big) / p.base;
+  };
+  const int w0 = owner(first), w1 = owner(last);
+  if (w0 == w1) return;                                          // finished by its owner
+  const int e = (blockIdx.x * 256 + threadIdx.x) * 4;            // element of the [ROWS, C] tile
+  if (e >= ROWS * C) return;
+  const long long row = (long long)tile * ROWS + e / C;
+  if (row >= p.M) return;
+  const int col = e % C;
+  const float4 xv = ld4(p.x + row * C + col), bv = ld4(p.b2 + col);
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int w = w0; w <= w1; ++w) {
+    int st, cn;
+    item_range(p, w, st, cn);
+    const int seg = tile - st / NCHUNK;
+    const float4 v = ld4(p.part + ((long long)w * p.P + seg) * ROWS * C + e);
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  st4(p.y + row * C + col, make_float4(a.x + bv.x + xv.x, a.y + bv.y + xv.y, a.z + bv.z + xv.z, a.w + bv.w + xv.w));
+}
+
+// NW waves per workgroup (16 rows each), WPS waves per SIMD the register allocation is held to
+template <int NW, int WPS>
+struct Variant {
+  static constexpr int ROWS = NW * 16;
+  static int grid(int tiles) {
+    static int slots = 0;
+    if (!slots) {
+      int dev = 0, cus = 256, per_cu = 1;
+      (void)hipGetDevice(&dev);
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mlp_fused_kernel<NW, WPS>, NW * 64, 0);
+      slots = cus * (per_cu > 0 ? per_cu : 1);
+    }
+    const long long items = (long long)tiles * NCHUNK;
+    return (int)(items < slots ? items : slots);
+  }
+  static int partition(MlpP& p) {
+    p.tiles = (p.M + ROWS - 1) / ROWS;
+    const int G = grid(p.tiles), items = p.tiles * NCHUNK;
+    p.base = items / G;
+    p.rem = items % G;
+    p.P = (p.base + 1 + NCHUNK - 1) / NCHUNK + 1;                 // row tiles one range can touch
+    return G;
+  }
+  static size_t workspace(int M) {
+    MlpP p{};
+    p.M = M;
+    const int G = partition(p);
+    return (size_t)G * p.P * ROWS * C * sizeof(float);
+  }
+  static int launch(MlpP p, hipStream_t st) {
+    const int G = partition(p);
+    hipLaunchKernelGGL((mlp_fused_kernel<NW, WPS>), dim3(G), dim3(NW * 64), 0, st, p);
+    RP_CHECK_LAUNCH();
+    if (p.rem != 0 || p.base % NCHUNK != 0) {                     // some tile is shared between workgroups
+      hipLaunchKernelGGL(mlp_fixup_kernel<ROWS>, dim3((ROWS * C / 4 + 255) / 256, p.tiles), dim3(256), 0, st, p, G);
+      RP_CHECK_LAUNCH();
+    }
+    return RP_OK;
+  }
+};
+
+int mlp_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("RP_MLP_VARIANT");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+
+}  // namespace
+
+extern "C" size_t rp_mlp_fused_workspace_bytes(int M) {
+  if (M <= 0) return 0;
+  switch (mlp_variant()) {
+    case 1: return Variant<4, 3>::workspace(M);
+    case 2: return Variant<12, 3>::workspace(M);
+    case 3: return Variant<8, 4>::workspace(M);
+    default: return Variant<8, 2>::workspace(M);
+  }
+}
+
+extern "C" int rp_mlp_fused_fwd(const float* x, const float* gamma, const float* beta, const float* w1, const float* b1,
+                                const float* w2, const float* b2, float* y, void* workspace, int M, int dim, int hidden, float eps,
+                                void* stream) {
+  if (M <= 0 || dim != C || hidden != HID || !x || !gamma || !beta || !w1 || !b1 || !w2 || !b2 || !y || !workspace)
+    return RP_EBADSHAPE;
+  MlpP p{x, gamma, beta, w1, b1, w2, b2, y, (float*)workspace, M, eps, 0, 0, 0, 0};
+  hipStream_t st = (hipStream_t)stream;
+  switch (mlp_variant()) {
+    case 1: return Variant<4, 3>::launch(p, st);
+    case 2: return Variant<12, 3>::launch(p, st);
+    case 3: return Variant<8, 4>::launch(p, st);
+    default: return Variant<8, 2>::launch(p, st);
+  }
+}

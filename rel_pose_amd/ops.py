@@ -235,8 +235,53 @@ def gemm(A, B, M, N, K, *, a_layout=0, b_layout=0, lda=None, ldb=None, out=None,
     return (out, colsum(cpart)) if want_colsum else out
 
 
+# K = 192 Linear layers on the row-resident kernel (csrc/linear_rows.hip) instead of the generic LDS-DMA GEMM: exact fp32 only
+ROWS_LINEAR = os.environ.get("RP_ROWS_LINEAR", "1") != "0"
+
+
+def _rows_ok(x, W):
+    return (ROWS_LINEAR and GEMM_PRECISION == 0 and x.shape[1] == DIM and W.shape[1] == DIM and W.shape[0] % 32 == 0
+            and W.shape[0] <= 1024 and x.is_contiguous() and W.is_contiguous())
+
+
+def linear_rows(x, W, b=None, act=0, want_pre=False, residual=None, ln=None, want_ln_out=False):
+    """rp_linear_rows192: y = act(LN?(x) W^T + b) (+ residual) for K = 192.  ln = (gamma, beta) fuses the LayerNorm;
+    want_ln_out additionally returns (xn, mean, rstd).  Returns y [, pre] [, xn, mean, rstd]."""
+    lib = _lib.load()
+    _chk(x, W, b, residual)
+    M, K = x.shape
+    N = W.shape[0]
+    y = _empty(M, N, like=x)
+    pre = _empty(M, N, like=x) if want_pre else None
+    xn = mean = rstd = None
+    g = be = None
+    if ln is not None:
+        g, be = ln
+        _chk(g, be)
+        if want_ln_out:
+            xn, mean, rstd = torch.empty_like(x), _empty(M, like=x), _empty(M, like=x)
+    _lib.check(lib.rp_linear_rows192(_p(x), _p(W), _p(b), _p(residual), _p(g), _p(be), LN_EPS, _p(y), _p(pre), _p(xn), _p(mean),
+                                     _p(rstd), M, N, K, act, _st()), "rp_linear_rows192")
+    out = (y,) + ((pre,) if want_pre else ()) + ((xn, mean, rstd) if (ln is not None and want_ln_out) else ())
+    return out[0] if len(out) == 1 else out
+
+
+def ln_linear(x, gamma, beta, W, b, act=0, want_pre=False, train=True):
+    """(y [, pre], xn, mean, rstd) of  act(LayerNorm(x) W^T + b): one kernel when the row-resident path applies (xn / stats are
+    None at inference), LayerNorm kernel + GEMM otherwise."""
+    if _rows_ok(x, W):
+        r = linear_rows(x, W, b, act=act, want_pre=want_pre, ln=(gamma, beta), want_ln_out=train)
+        r = r if isinstance(r, tuple) else (r,)
+        return r if train else r + (None, None, None)
+    xn, m, rs = layernorm_fwd(x, gamma, beta)
+    r = linear(xn, W, b, act=act, want_pre=want_pre)
+    return (r if isinstance(r, tuple) else (r,)) + (xn, m, rs)
+
+
 def linear(x, W, b=None, act=0, want_pre=False, residual=None):
     """y = act(x W^T + b) (+ residual); x [M,K], W [N,K]."""
+    if _rows_ok(x, W) and (residual is None or residual.is_contiguous()):
+        return linear_rows(x, W, b, act=act, want_pre=want_pre, residual=residual)
     M, K = x.shape
     N = W.shape[0]
     pre = _empty(M, N, like=x) if want_pre else None
@@ -599,6 +644,41 @@ class TokensFn(torch.autograd.Function):
         return dfeat, dpe
 
 
+# Inference path of the transformer MLP: LayerNorm + fc1 + GELU + fc2 + residual as ONE kernel, hidden activation on chip
+# (csrc/mlp_fused.hip).  Training keeps the GEMM chain: its backward needs xn, h and h_pre in HBM anyway.
+FUSE_MLP = os.environ.get("RP_FUSE_MLP", "1") != "0"
+_mlp_ws = {}
+
+
+def mlp_fused(x2d, gamma, beta, w1, b1, w2, b2, eps=LN_EPS):
+    """y = x + fc2(GELU(fc1(LayerNorm(x)) + b1)) + b2 for x [M,192], w1 [768,192], w2 [192,768] (rp_mlp_fused_fwd)."""
+    lib = _lib.load()
+    _chk(x2d, gamma, beta, w1, b1, w2, b2)
+    M = x2d.shape[0]
+    y = torch.empty_like(x2d)
+    key = (x2d.device, M)
+    ws = _mlp_ws.get(key)
+    if ws is None:
+        ws = _mlp_ws[key] = torch.empty(max(1, lib.rp_mlp_fused_workspace_bytes(M)) // 4 + 1, device=x2d.device, dtype=torch.float32)
+    _lib.check(lib.rp_mlp_fused_fwd(_p(x2d), _p(gamma), _p(beta), _p(w1), _p(b1), _p(w2), _p(b2), _p(y), _p(ws), M, x2d.shape[1],
+                                    w1.shape[0], eps, _st()), "rp_mlp_fused_fwd")
+    return y
+
+
+def _mlp_block_fwd(x1, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b, train):
+    """(y, xn2, m2, r2, h, hpre) of `x1 + Mlp(norm2(x1))`; the inference path returns y only (rest None)."""
+    if (not train and FUSE_MLP and GEMM_PRECISION == 0 and x1.shape[1] == DIM and tuple(fc1_w.shape) == (4 * DIM, DIM)
+            and tuple(fc2_w.shape) == (DIM, 4 * DIM)):
+        return mlp_fused(x1, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b), None, None, None, None, None
+    if train:
+        h, hpre, xn2, m2, r2 = ln_linear(x1, n2w, n2b, fc1_w, fc1_b, act=1, want_pre=True, train=True)
+    else:
+        h, xn2, m2, r2 = ln_linear(x1, n2w, n2b, fc1_w, fc1_b, act=1, train=False)
+        hpre = None
+    y = linear(h, fc2_w, fc2_b, residual=x1)
+    return y, xn2, m2, r2, h, hpre
+
+
 def _mlp_fwd(xn, w1, b1, w2, b2, residual, train):
     if train:
         h, hpre = linear(xn, w1, b1, act=1, want_pre=True)
@@ -646,13 +726,11 @@ class BlockFn(torch.autograd.Function):
         x = x.contiguous()
         Z = x.shape[0]
         x2 = x.view(Z * N_TOK, DIM)
-        xn1, m1, r1 = layernorm_fwd(x2, n1w, n1b)
-        qkv = linear(xn1, qkv_w, qkv_b)
+        qkv, xn1, m1, r1 = ln_linear(x2, n1w, n1b, qkv_w, qkv_b, train=train)
         o, lse = attn_fwd(qkv, Z, k_xor=3 if cross else 0)
         ctx.cross = cross
         x1 = linear(o, proj_w, proj_b, residual=x2)
-        xn2, m2, r2 = layernorm_fwd(x1, n2w, n2b)
-        y, h, hpre = _mlp_fwd(xn2, fc1_w, fc1_b, fc2_w, fc2_b, x1, train)
+        y, xn2, m2, r2, h, hpre = _mlp_block_fwd(x1, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b, train)
         if train:
             ctx.save_for_backward(x2, m1, r1, xn1, qkv, o, lse, x1, m2, r2, xn2, h, hpre, n1w, qkv_w, proj_w, n2w,
                                   fc1_w, fc2_w)
@@ -695,8 +773,7 @@ class CrossBlockFn(torch.autograd.Function):
         x = x.contiguous()
         Z = x.shape[0]
         x2 = x.view(Z * N_TOK, DIM)
-        xn, m1, r1 = layernorm_fwd(x2, n1w, n1b)
-        qkv = linear(xn, qkv_w, qkv_b)
+        qkv, xn, m1, r1 = ln_linear(x2, n1w, n1b, qkv_w, qkv_b, train=train)
         rlse, clse = emm_stats(qkv, Z, single)
         xa = emm_build_x(qkv, pos, Z)
         t, fpart = emm_apply(qkv, xa, rlse, clse, Z, swap=False, want_t=train, single=single,
@@ -705,8 +782,7 @@ class CrossBlockFn(torch.autograd.Function):
         g = emm_finalize(fpart, Z)                                     # [Z*70, 224]
         pf_wp = torch.nn.functional.pad(pf_w, (0, GW - pf_w.shape[1])).contiguous()
         f = linear(g, pf_wp, pf_b)                                     # [Z*70, 192]
-        fn, m2, r2 = layernorm_fwd(f, n2w, n2b)
-        y, h, hpre = _mlp_fwd(fn, fc1_w, fc1_b, fc2_w, fc2_b, f, train)
+        y, fn, m2, r2, h, hpre = _mlp_block_fwd(f, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b, train)
         if train:
             ctx.save_for_backward(x2, m1, r1, xn, qkv, rlse, clse, xa, t, g, f, m2, r2, fn, h, hpre, n1w, qkv_w, pf_wp,
                                   n2w, fc1_w, fc2_w)

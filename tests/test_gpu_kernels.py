@@ -660,3 +660,72 @@ def test_fused_augmentation_matches_the_tensor_implementation(ops):
     assert worst < 0.02
     with pytest.raises(ValueError):
         ops.augment_pairs(img.float().cuda(), prm.cuda(), 96, 128)
+
+
+@pytest.mark.parametrize("M", [140, 1152, 8960, 73728 + 48])
+def test_fused_mlp_inference_kernel(ops, M):
+    """rp_mlp_fused_fwd: y = x + fc2(GELU(fc1(LN(x)))) with the hidden activation on chip (vision_transformer.py:353,
+    vit_layers/mlp.py:20-26) against fp64 PyTorch and against the unfused kernel chain it replaces at inference; row counts
+    that are not multiples of the 128-row tile (the CrossBlock's 70-token output: 140 rows per pair) and that exercise the
+    stream-K split with shared tiles.  Tolerance 2e-6 relative to max|y| (fp32 MFMA accumulation over K = 192 / 768)."""
+    import torch.nn.functional as F
+    x = rnd(M, 192, seed=1, scale=2.0)
+    x[3] = x[3] * 30 + 100                                         # a row with a large mean: centred variance
+    g, b = 1 + 0.1 * rnd(192, seed=2), 0.1 * rnd(192, seed=3)
+    w1, b1 = rnd(768, 192, seed=4, scale=192 ** -0.5), 0.1 * rnd(768, seed=5)
+    w2, b2 = rnd(192, 768, seed=6, scale=768 ** -0.5), 0.1 * rnd(192, seed=7)
+    y = ops.mlp_fused(x, g, b, w1, b1, w2, b2)
+    xd = x.double()
+    ref = xd + F.linear(F.gelu(F.linear(F.layer_norm(xd, (192,), g.double(), b.double(), 1e-6), w1.double(), b1.double())),
+                        w2.double(), b2.double())
+    e = rel(y, ref)
+    xn, _, _ = ops.layernorm_fwd(x, g, b)
+    chain = ops.linear(ops.linear(xn, w1, b1, act=1), w2, b2, residual=x)
+    e2 = rel(y, chain)
+    report("mlp_fused_M%d" % M, vs_fp64=e, vs_unfused_chain=e2, chain_vs_fp64=rel(chain, ref))
+    assert e < 2e-6 and e2 < 2e-6
+    assert torch.equal(y, ops.mlp_fused(x, g, b, w1, b1, w2, b2))                  # deterministic (fixed-order fix-up)
+    with pytest.raises(RuntimeError):
+        ops.mlp_fused(x[:, :128].contiguous(), g[:128], b[:128], w1[:, :128].contiguous(), b1, w2, b2)
+
+
+@pytest.mark.parametrize("M", [140, 1152, 9216 + 48])
+def test_row_resident_linear_with_fused_layernorm(ops, M):
+    """rp_linear_rows192 -- the K = 192 Linear layers (qkv, proj, fc1: vision_transformer.py:323,330,352-353, mlp.py:22-23) with the
+    preceding LayerNorm fused in -- against fp64 PyTorch: y, pre-activation, normalised rows, mean, rstd; and
+    against the generic rp_gemm path it replaces.  Tolerance 2e-6 of max|y| (fp32 accumulation over K = 192)."""
+    import torch.nn.functional as F
+    x = rnd(M, 192, seed=11, scale=2.0)
+    x[5] = x[5] * 20 - 50
+    g, b = 1 + 0.1 * rnd(192, seed=12), 0.1 * rnd(192, seed=13)
+    xd = x.double()
+    xnd = F.layer_norm(xd, (192,), g.double(), b.double(), 1e-6)
+    worst = {}
+    # qkv: LN fused, training outputs
+    w, bias = rnd(576, 192, seed=14, scale=192 ** -0.5), 0.1 * rnd(576, seed=15)
+    y, xn, mean, rstd = ops.linear_rows(x, w, bias, ln=(g, b), want_ln_out=True)
+    worst["qkv"] = rel(y, F.linear(xnd, w.double(), bias.double()))
+    worst["xn"] = rel(xn, xnd)
+    worst["mean"] = rel(mean, xd.mean(1))
+    worst["rstd"] = rel(rstd, (xd.var(1, unbiased=False) + 1e-6).rsqrt())
+    xn_k, m_k, r_k = ops.layernorm_fwd(x, g, b)
+    worst["xn_vs_ln_kernel"] = rel(xn, xn_k)
+    y_inf = ops.linear_rows(x, w, bias, ln=(g, b))                                      # inference: no side outputs
+    assert torch.equal(y_inf, y)
+    # proj: no LN, residual
+    wp, bp, res = rnd(192, 192, seed=16, scale=192 ** -0.5), 0.1 * rnd(192, seed=17), rnd(M, 192, seed=18)
+    worst["proj"] = rel(ops.linear_rows(x, wp, bp, residual=res), res.double() + F.linear(xd, wp.double(), bp.double()))
+    # fc1: LN + GELU + pre-activation
+    w1, b1 = rnd(768, 192, seed=19, scale=192 ** -0.5), 0.1 * rnd(768, seed=20)
+    h, hpre, xn2, _, _ = ops.linear_rows(x, w1, b1, act=1, want_pre=True, ln=(g, b), want_ln_out=True)
+    pre_ref = F.linear(xnd, w1.double(), b1.double())
+    worst["fc1_pre"] = rel(hpre, pre_ref)
+    worst["fc1_gelu"] = rel(h, F.gelu(pre_ref))
+    # the generic GEMM path on the same inputs
+    old = ops.gemm(xn_k, w1, M, 768, 192, bias=b1, act=1)
+    worst["fc1_vs_rp_gemm"] = rel(h, old)
+    assert ops.linear(x, wp, bp, residual=res).shape == (M, 192)                          # ops.linear routes here for K = 192
+    report("linear_rows_M%d" % M, **worst)
+    assert max(worst.values()) < 2e-6, worst
+    with pytest.raises(RuntimeError):
+        ops.linear_rows(x, rnd(200, 192, seed=1), None)                                    # N % 32 != 0

@@ -128,7 +128,7 @@ def main():
     ap.add_argument("--scope", default="full", choices=("full", "hot"),
                     help="full = images -> CNN -> hot path (the metric); hot = synthetic CNN maps -> hot path only "
                          "(kernel profiling; not the headline number)")
-    ap.add_argument("--timer-instance", default="0,0,2,1", help="gemm_kernel<aL,bL,TM,TN> instance timed for `roofline`")
+    ap.add_argument("--timer-instance", default="1,1,1,3", help="gemm_kernel<aL,bL,TM,TN> instance timed for `roofline`")
     ap.add_argument("--precision", default="fp32", choices=tuple(PRECISIONS),
                     help="how rp_gemm multiplies its fp32 operands: fp32 = exact v_mfma_f32_32x32x2_f32 (default); split3 = "
                          "three bf16 limbs per operand, six limb products on the bf16 MFMA pipe, fp32-grade results; "

@@ -90,7 +90,16 @@ typedef struct RpGemm {
   const float* ln_rstd;
   const float* ln_gamma;
   float* ln_part;
+  /* optional hipEvent_t pair recorded on `stream` immediately before and after the MAIN kernel of this call (not the split-K
+   * reduce): bench.py's per-launch timing of one kernel instance.  NULL: nothing recorded. */
+  void* ev_start;
+  void* ev_stop;
 } RpGemm;
+
+/* hipEvent helpers for ev_start / ev_stop (so that a ctypes host needs no second library): create / destroy / elapsed ms */
+void* rp_event_create(void);
+void rp_event_destroy(void* ev);
+float rp_event_elapsed_ms(void* start, void* stop);
 int rp_gemm(const RpGemm* g, void* stream);
 size_t rp_gemm_workspace_bytes(int M, int N, int split_k);
 
@@ -252,10 +261,15 @@ int rp_pose_normalize_bwd(const float* pred, const float* dout, float* dpred, in
  * ln_gamma/ln_beta non-NULL: x is layer-normalised (eps) on the way into the MFMA operand registers; xn_out [M,192], mean_out
  * [M], rstd_out [M] (each optional) receive what the backward needs.  y_pre (optional) receives the pre-activation.
  * act: 0 none, 1 GELU.  No workspace.
+ * Input-gradient use (dx = (dy W) o act'(aux) of a Linear whose OUTPUT width is 192: fc2, attention proj): x = dy, w = W^T
+ * [N_in,192] contiguous, dact_aux = the saved pre-activation [M,N] (y is multiplied by GELU'(aux); NULL: none), colsum_part
+ * [ceil(M / rp_linear_rows192_tile_rows()), N] (optional) receives the column sums of y per row tile -- summed, they are the
+ * bias gradient of the layer below.
  * ------------------------------------------------------------------------------------------- */
+int rp_linear_rows192_tile_rows(void);
 int rp_linear_rows192(const float* x, const float* w, const float* bias, const float* residual, const float* ln_gamma,
                       const float* ln_beta, float eps, float* y, float* y_pre, float* xn_out, float* mean_out, float* rstd_out,
-                      int M, int N, int K, int act, void* stream);
+                      const float* dact_aux, float* colsum_part, int M, int N, int K, int act, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused transformer MLP, inference path (vision_transformer.py:353 + vit_layers/mlp.py:20-26):
@@ -266,6 +280,15 @@ int rp_linear_rows192(const float* x, const float* w, const float* bias, const f
 size_t rp_mlp_fused_workspace_bytes(int M);
 int rp_mlp_fused_fwd(const float* x, const float* gamma, const float* beta, const float* w1, const float* b1, const float* w2,
                      const float* b2, float* y, void* workspace, int M, int dim, int hidden, float eps, void* stream);
+
+/* Backward-data of the same MLP (training): dhp [M,hidden] = (dy W2) o GELU'(hpre) -- the gradient of fc1's pre-activation, which
+ * fc1's weight gradient needs -- and dxn [M,dim] = dhp W1, the gradient of the LayerNorm output, as one kernel (dh never exists).
+ * w2t = W2^T [hidden,dim] and w1t = W1^T [dim,hidden], contiguous.  colpart [ceil(M / rp_mlp_fused_bwd_tile_rows()), hidden]
+ * receives the column sums of dhp per row tile (their sum is the fc1 bias gradient). */
+size_t rp_mlp_fused_bwd_workspace_bytes(int M);
+int rp_mlp_fused_bwd_tile_rows(void);
+int rp_mlp_fused_bwd(const float* dy, const float* hpre, const float* w2t, const float* w1t, float* dhp, float* dxn, float* colpart,
+                     void* workspace, int M, int dim, int hidden, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Training-time augmentation of a resident batch (RGBDAugmentor, src/data_readers/augmentation.py:7-37):

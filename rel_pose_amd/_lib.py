@@ -11,7 +11,7 @@ import torch  # noqa: F401  (must be imported first: it loads the HIP runtime th
 from . import _build
 
 _LIB = None
-ABI_VERSION = 2          # rp_abi_version() of the library this binding was written against
+ABI_VERSION = 3          # rp_abi_version() of the library this binding was written against
 RP_ERRORS = {-1: "bad shape", -2: "misaligned pointer/stride", -3: "workspace too small", -4: "unsupported"}
 
 
@@ -25,7 +25,8 @@ class RpGemm(Structure):
                 ("bias", c_void_p), ("pre_out", c_void_p), ("act", c_int), ("dact", c_int),
                 ("aux", c_void_p), ("residual", c_void_p), ("trans_c", c_int), ("precision", c_int),
                 ("colsum_part", c_void_p),
-                ("ln_x", c_void_p), ("ln_mean", c_void_p), ("ln_rstd", c_void_p), ("ln_gamma", c_void_p), ("ln_part", c_void_p)]
+                ("ln_x", c_void_p), ("ln_mean", c_void_p), ("ln_rstd", c_void_p), ("ln_gamma", c_void_p), ("ln_part", c_void_p),
+                ("ev_start", c_void_p), ("ev_stop", c_void_p)]
 
 
 class RpColsumTask(Structure):
@@ -75,9 +76,16 @@ _SIGS = {
     "rp_emm_grad_ds": (c_int, [P, I, P, P, P, P, P, P, P, P, I, I, F, I, I, P]),
     "rp_pose_normalize_fwd": (c_int, [P, P, P, I, P]),
     "rp_pose_normalize_bwd": (c_int, [P, P, P, I, P]),
-    "rp_linear_rows192": (c_int, [P, P, P, P, P, P, F, P, P, P, P, P, I, I, I, I, P]),
+    "rp_event_create": (c_void_p, []),
+    "rp_event_destroy": (None, [P]),
+    "rp_event_elapsed_ms": (c_float, [P, P]),
+    "rp_linear_rows192_tile_rows": (c_int, []),
+    "rp_linear_rows192": (c_int, [P, P, P, P, P, P, F, P, P, P, P, P, P, P, I, I, I, I, P]),
     "rp_mlp_fused_workspace_bytes": (ctypes.c_size_t, [I]),
     "rp_mlp_fused_fwd": (c_int, [P, P, P, P, P, P, P, P, P, I, I, I, ctypes.c_float, P]),
+    "rp_mlp_fused_bwd_workspace_bytes": (ctypes.c_size_t, [I]),
+    "rp_mlp_fused_bwd_tile_rows": (c_int, []),
+    "rp_mlp_fused_bwd": (c_int, [P, P, P, P, P, P, P, P, I, I, I, P]),
     "rp_augment_blocks": (c_int, []),
     "rp_augment_pairs": (c_int, [P, P, P, P, I, I, I, I, I, P]),
     "rp_essential_from_pose": (c_int, [P, P, I, P]),

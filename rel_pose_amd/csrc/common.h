@@ -75,6 +75,23 @@ RP_DEV float gelu_fast(float x) {
   return x * (x < 0.f ? e : 1.0f - e);
 }
 
+// d/dx gelu(x) = Phi(x) + x phi(x) with the same Phi as gelu_fast and phi(x) = exp2(-x^2 log2(e) / 2) / sqrt(2 pi)
+RP_DEV float gelu_grad_fast(float x) {
+  const float t = fminf(fabsf(x), 5.7f);
+  float p = 2.796787612e-06f;
+  p = fmaf(p, t, -3.893709072e-05f);
+  p = fmaf(p, t, 1.841904013e-04f);
+  p = fmaf(p, t, 1.414295839e-04f);
+  p = fmaf(p, t, -7.068802603e-03f);
+  p = fmaf(p, t, 5.249951407e-02f);
+  p = fmaf(p, t, 4.592072368e-01f);
+  p = fmaf(p, t, 1.151105285e+00f);
+  const float e = __builtin_amdgcn_exp2f(fmaf(-t, p, -1.0f));
+  const float cdf = x < 0.f ? e : 1.0f - e;
+  const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);
+  return fmaf(x, pdf, cdf);
+}
+
 // exp / softmax arithmetic runs in the log2 domain: scores are produced pre-multiplied by log2(e) (folded into the
 // operand prescale), so every probability is ONE v_exp_f32 instead of libm's ~25-instruction expf (which was ~half of
 // the non-MFMA time per attention tile).  v_exp_f32 is accurate to ~1 ulp; measured pose error stays ~1e-6.
@@ -85,6 +102,15 @@ RP_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 RP_DEV float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// sum over the 16 lanes of a DPP row (lanes 16q .. 16q+15), result in every lane of the row; fixed order, VALU only
+RP_DEV float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
   return v;
 }
 

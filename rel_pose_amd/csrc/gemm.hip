@@ -478,10 +478,12 @@ extern "C" int rp_gemm(const RpGemm* g, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const int nz = batch * split;
   static const bool no_dma = getenv("RP_GEMM_NO_DMA") != nullptr;      // A/B aid: force the register-staged main loop
+  if (g->ev_start) (void)hipEventRecord((hipEvent_t)g->ev_start, st);
   if (!no_dma && dma_eligible(p)) launch_dma(p, nz, g->a_layout, g->b_layout, tm, tn, st);
   else if (p.limbs == 3) launch_layouts<3>(p, nz, g->a_layout, g->b_layout, tm, tn, st);
   else if (p.limbs == 1) launch_layouts<1>(p, nz, g->a_layout, g->b_layout, tm, tn, st);
   else launch_layouts<0>(p, nz, g->a_layout, g->b_layout, tm, tn, st);
+  if (g->ev_stop) (void)hipEventRecord((hipEvent_t)g->ev_stop, st);
   RP_CHECK_LAUNCH();
   if (split > 1) {
     GemmP r = p;
@@ -492,4 +494,17 @@ extern "C" int rp_gemm(const RpGemm* g, void* stream) {
     RP_CHECK_LAUNCH();
   }
   return RP_OK;
+}
+
+extern "C" void* rp_event_create(void) {
+  hipEvent_t e = nullptr;
+  return hipEventCreate(&e) == hipSuccess ? (void*)e : nullptr;
+}
+extern "C" void rp_event_destroy(void* ev) {
+  if (ev) (void)hipEventDestroy((hipEvent_t)ev);
+}
+extern "C" float rp_event_elapsed_ms(void* start, void* stop) {
+  float ms = -1.f;
+  if (hipEventSynchronize((hipEvent_t)stop) != hipSuccess) return -1.f;
+  return hipEventElapsedTime(&ms, (hipEvent_t)start, (hipEvent_t)stop) == hipSuccess ? ms : -1.f;
 }

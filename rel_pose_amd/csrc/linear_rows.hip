@@ -29,18 +29,42 @@ constexpr int MAXN = 1024;
 struct RowsP {
   const float *x, *w, *bias, *res, *gamma, *beta;
   float *y, *ypre, *xn, *mean, *rstd;
+  const float* aux;          // [M,N]: y *= GELU'(aux) (input-gradient form: x = dy, w = W^T, aux = the layer's saved pre-activation)
+  float* colpart;            // [tiles,N]: column sums of y over each 64-row tile (the bias gradient of the layer below), or null
   int M, N;
   float eps;
   int act;                   // 0 none, 1 GELU
   int nchunk, tiles, base, rem;
+#ifdef RP_ROWS_PROBE
+  long long* probe;          // tools/lab/rows_probe: shader-clock stamps [block][chunk][wave][5]
+#endif
 };
+
+#ifdef RP_ROWS_PROBE
+#define RP_STAMP(k)                                                                                             \
+  if (lane == 0 && blockIdx.x < 8 && nstamp < 64)                                                               \
+  p.probe[((blockIdx.x * 64 + nstamp) * NW + wave) * 5 + (k)] = __builtin_readcyclecounter()
+#else
+#define RP_STAMP(k)
+#endif
 
 template <bool LN>
 __global__ __launch_bounds__(NT, 3) void linear_rows_kernel(RowsP p) {
   __shared__ __attribute__((aligned(16))) float wt[2][WT];
-  __shared__ __attribute__((aligned(16))) float bs[MAXN];
+  // 1.5 KB shared by two uses that never coincide: gamma | beta of the fused LayerNorm (forward), or the per-wave column sums of a
+  // chunk by chunk parity (input-gradient form; readers of chunk k never meet writers of k + 1).  Kept this small on purpose: with
+  // 53 KB per workgroup only two, not three, workgroups are resident per CU (LDS is allocated in 1.25 KB granules).
+  __shared__ __attribute__((aligned(16))) float aux_lds[2 * C];
+  float (*cs_lds)[NW * CH] = reinterpret_cast<float (*)[NW * CH]>(aux_lds);
+  static_assert(2 * NW * CH <= 2 * C, "column-sum scratch must fit the shared 1.5 KB");
+  if (LN) {
+    for (int i = threadIdx.x; i < C; i += NT) {
+      aux_lds[i] = p.gamma[i];
+      aux_lds[C + i] = p.beta[i];
+    }
+    __syncthreads();
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, q = lane >> 4;
-  for (int i = tid; i < p.N; i += NT) bs[i] = p.bias ? p.bias[i] : 0.f;
   unsigned off[DMA];
 #pragma unroll
   for (int r = 0; r < DMA; ++r) {
@@ -57,8 +81,15 @@ __global__ __launch_bounds__(NT, 3) void linear_rows_kernel(RowsP p) {
   int it = b * p.base + min(b, p.rem);
   const int end = it + p.base + (b < p.rem ? 1 : 0);
   int buf = 0;
+#ifdef RP_ROWS_PROBE
+  int nstamp = 0;
+  if (lane == 0 && blockIdx.x < 8) {
+    p.probe[((blockIdx.x * 64 + 63) * NW + wave) * 5 + 0] = __builtin_readcyclecounter();
+    p.probe[((blockIdx.x * 64 + 63) * NW + wave) * 5 + 3] = wall_clock64();
+  }
+#endif
   if (it < end) issue(it % p.nchunk, 0);
-  const bool pre = p.ypre != nullptr, has_res = p.res != nullptr;
+  const bool has_bias = p.bias != nullptr, pre = p.ypre != nullptr, has_res = p.res != nullptr, has_aux = p.aux != nullptr, want_cs = p.colpart != nullptr;
   while (it < end) {
     const int tile = it / p.nchunk, c0 = it % p.nchunk, c1 = min(p.nchunk, c0 + end - it);
     const int row = tile * ROWS + wave * 16 + j;
@@ -90,7 +121,7 @@ __global__ __launch_bounds__(NT, 3) void linear_rows_kernel(RowsP p) {
       const bool owner = c0 == 0 && live;                            // the range holding the tile's first chunk writes xn / stats
 #pragma unroll
       for (int t = 0; t < 12; ++t) {
-        const float4 g = ld4(p.gamma + 16 * t + 4 * q), bb = ld4(p.beta + 16 * t + 4 * q);
+        const float4 g = ld4(aux_lds + 16 * t + 4 * q), bb = ld4(aux_lds + C + 16 * t + 4 * q);
         xn[4 * t] = (xn[4 * t] - mu) * rs * g.x + bb.x;
         xn[4 * t + 1] = (xn[4 * t + 1] - mu) * rs * g.y + bb.y;
         xn[4 * t + 2] = (xn[4 * t + 2] - mu) * rs * g.z + bb.z;
@@ -107,7 +138,14 @@ __global__ __launch_bounds__(NT, 3) void linear_rows_kernel(RowsP p) {
     float4 pv0, pv1, pp0, pp1;
     long long po = 0;
     bool pending = false;
+    int cs_tile = 0, cs_chunk = 0, cs_par = 0;
     auto flush = [&]() {
+      if (pending && want_cs && tid < CH) {          // (callers sit behind a barrier that follows the cs_lds writes)
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) sum += cs_lds[cs_par][w * CH + tid];
+        p.colpart[(long long)cs_tile * p.N + cs_chunk * CH + tid] = sum;
+      }
       if (pending && live) {
         if (pre) {
           st4(p.ypre + po, pp0);
@@ -119,14 +157,27 @@ __global__ __launch_bounds__(NT, 3) void linear_rows_kernel(RowsP p) {
       pending = false;
     };
     for (int c = c0; c < c1; ++c, ++it) {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // W(c) landed; other buffer free
+      RP_STAMP(0);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      RP_STAMP(1);
+      asm volatile("s_barrier" ::: "memory");                                       // W(c) landed; other buffer free
+      RP_STAMP(2);
       flush();
       if (it + 1 < end) issue((it + 1) % p.nchunk, buf ^ 1);
       const long long o = rclamp * p.N + c * CH + 4 * q;
-      float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
+      float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, g0 = r0, g1 = r0, ba = r0, bb = r0;
+      if (has_bias) {          // (from L2; staging the bias in LDS costs the third resident workgroup per CU)
+        ba = ld4(p.bias + c * CH + 4 * q);
+        bb = ld4(p.bias + c * CH + 16 + 4 * q);
+      }
       if (has_res) {
         r0 = ld4(p.res + o);
         r1 = ld4(p.res + o + 16);
+      }
+      if (has_aux) {
+        g0 = ld4(p.aux + o);
+        g1 = ld4(p.aux + o + 16);
+        asm volatile("" ::: "memory");
       }
       f32x4v h0 = {0.f, 0.f, 0.f, 0.f}, h1 = {0.f, 0.f, 0.f, 0.f};
       const float* a0p = &wt[buf][0] + j * C;
@@ -154,23 +205,52 @@ __global__ __launch_bounds__(NT, 3) void linear_rows_kernel(RowsP p) {
         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
       }
-      const float4 ba = ld4(bs + c * CH + 4 * q), bb = ld4(bs + c * CH + 16 + 4 * q);
+      RP_STAMP(3);
       float4 v0 = make_float4(h0[0] + ba.x, h0[1] + ba.y, h0[2] + ba.z, h0[3] + ba.w);
       float4 v1 = make_float4(h1[0] + bb.x, h1[1] + bb.y, h1[2] + bb.z, h1[3] + bb.w);
       pp0 = v0;
       pp1 = v1;
+      if (has_aux) {
+        asm volatile("" : "+v"(g0.x), "+v"(g0.y), "+v"(g0.z), "+v"(g0.w), "+v"(g1.x), "+v"(g1.y), "+v"(g1.z), "+v"(g1.w) :: "memory");
+        v0 = make_float4(v0.x * gelu_grad_fast(g0.x), v0.y * gelu_grad_fast(g0.y), v0.z * gelu_grad_fast(g0.z), v0.w * gelu_grad_fast(g0.w));
+        v1 = make_float4(v1.x * gelu_grad_fast(g1.x), v1.y * gelu_grad_fast(g1.y), v1.z * gelu_grad_fast(g1.z), v1.w * gelu_grad_fast(g1.w));
+      }
       if (p.act == 1) {
         v0 = make_float4(gelu_fast(v0.x), gelu_fast(v0.y), gelu_fast(v0.z), gelu_fast(v0.w));
         v1 = make_float4(gelu_fast(v1.x), gelu_fast(v1.y), gelu_fast(v1.z), gelu_fast(v1.w));
       }
       pv0 = make_float4(v0.x + r0.x, v0.y + r0.y, v0.z + r0.z, v0.w + r0.w);
       pv1 = make_float4(v1.x + r1.x, v1.y + r1.y, v1.z + r1.z, v1.w + r1.w);
+      if (want_cs) {     // column sums of this chunk over the wave's rows (fixed DPP tree), combined across waves after the barrier
+        const float m = live ? 1.f : 0.f;
+        float4 c0v = make_float4(row16_sum(m * pv0.x), row16_sum(m * pv0.y), row16_sum(m * pv0.z), row16_sum(m * pv0.w));
+        float4 c1v = make_float4(row16_sum(m * pv1.x), row16_sum(m * pv1.y), row16_sum(m * pv1.z), row16_sum(m * pv1.w));
+        if (j == 0) {
+          st4(&cs_lds[buf][0] + wave * CH + 4 * q, c0v);
+          st4(&cs_lds[buf][0] + wave * CH + 16 + 4 * q, c1v);
+        }
+        cs_par = buf;
+        cs_tile = tile;
+        cs_chunk = c;
+      }
       po = o;
       pending = true;
       buf ^= 1;
+      RP_STAMP(4);
+#ifdef RP_ROWS_PROBE
+      ++nstamp;
+#endif
     }
+    if (want_cs) __syncthreads();
     flush();
+    if (want_cs) __syncthreads();                  // cs_lds is rewritten by the next segment's first chunk
   }
+#ifdef RP_ROWS_PROBE
+  if (lane == 0 && blockIdx.x < 8) {
+    p.probe[((blockIdx.x * 64 + 63) * NW + wave) * 5 + 1] = __builtin_readcyclecounter();
+    p.probe[((blockIdx.x * 64 + 63) * NW + wave) * 5 + 2] = wall_clock64();
+  }
+#endif
 }
 
 template <bool LN>
@@ -188,14 +268,17 @@ int rows_slots() {
 
 }  // namespace
 
+extern "C" int rp_linear_rows192_tile_rows(void) { return ROWS; }
+
 extern "C" int rp_linear_rows192(const float* x, const float* w, const float* bias, const float* residual, const float* ln_gamma,
                                  const float* ln_beta, float eps, float* y, float* y_pre, float* xn_out, float* mean_out,
-                                 float* rstd_out, int M, int N, int K, int act, void* stream) {
+                                 float* rstd_out, const float* dact_aux, float* colsum_part, int M, int N, int K, int act,
+                                 void* stream) {
   if (M <= 0 || K != C || N <= 0 || N % CH != 0 || N > MAXN || !x || !w || !y || act < 0 || act > 1) return RP_EBADSHAPE;
   if ((ln_gamma == nullptr) != (ln_beta == nullptr)) return RP_EBADSHAPE;
   const bool ln = ln_gamma != nullptr;
   if (!ln && (xn_out || mean_out || rstd_out)) return RP_EBADSHAPE;
-  RowsP p{x, w, bias, residual, ln_gamma, ln_beta, y, y_pre, xn_out, mean_out, rstd_out, M, N, eps, act, N / CH, (M + ROWS - 1) / ROWS, 0, 0};
+  RowsP p{x, w, bias, residual, ln_gamma, ln_beta, y, y_pre, xn_out, mean_out, rstd_out, dact_aux, colsum_part, M, N, eps, act, N / CH, (M + ROWS - 1) / ROWS, 0, 0};
   const long long items = (long long)p.tiles * p.nchunk;
   const int slots = ln ? rows_slots<true>() : rows_slots<false>();
   const int G = (int)(items < slots ? items : slots);

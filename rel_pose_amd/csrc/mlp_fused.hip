@@ -39,6 +39,9 @@ constexpr int W1T = CH * C, W2T = C * CH;                      // floats per sta
 struct MlpP {
   const float *x, *gamma, *beta, *w1, *b1, *w2, *b2;
   float* y;
+  const float* hpre; // MODE 1: pre-activation of fc1 saved by the forward [M, HID]
+  float* dhp;        // MODE 1: gradient of that pre-activation (out) [M, HID]
+  float* colpart;    // MODE 1: per (row tile, chunk) column sums of dhp over the tile's rows [tiles, HID] (fc1 bias gradient partials)
   float* part;       // [gridDim.x * P][rows per tile][C] partial tiles
   int M;
   float eps;
@@ -50,16 +53,29 @@ RP_DEV void item_range(const MlpP& p, int b, int& start, int& count) {
   count = p.base + (b < p.rem ? 1 : 0);
 }
 
-template <int NW, int WPS>
+// MODE 0: inference forward (above).  MODE 1: the backward-data chain of the same MLP,
+//     dh = dy W2 ; dhp = dh o GELU'(h_pre) (stored: fc1's weight gradient needs it) ; dxn = dhp W1        (dxn -> p.y)
+// which is the SAME two chained products with the transposed weights in the two roles (p.w1 = W2^T [768,192], p.w2 = W1^T
+// [192,768]), GELU replaced by the multiplication with GELU'(h_pre) read from HBM in accumulator layout, no LayerNorm on the way
+// in and no bias / residual on the way out.  Also emits the column sums of dhp per (row tile, chunk) -- the fc1 bias gradient.
+template <int NW, int WPS, int MODE>
 __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
   constexpr int NT = NW * 64, ROWS = NW * 16;
   constexpr int DMA = (W1T / 4) / NT;                           // 16-byte chunks per thread per tile (3 for NW = 8)
   static_assert((W1T / 4) % NT == 0, "tile must be a whole number of DMA rounds");
   __shared__ __attribute__((aligned(16))) float w1t[W1T];
   __shared__ __attribute__((aligned(16))) float w2t[W2T];
-  __shared__ __attribute__((aligned(16))) float b1s[HID];
+  // MODE 0: gamma | beta of the LayerNorm (b1 is read from L2: staging all of it here would cost the third resident workgroup per
+  // CU -- LDS is allocated in 1.25 KB granules); MODE 1: per-wave column sums of a chunk
+  __shared__ __attribute__((aligned(16))) float b1s[MODE == 0 ? 2 * C : NW * CH];
+  if (MODE == 0) {
+    for (int i = threadIdx.x; i < C; i += NW * 64) {
+      b1s[i] = p.gamma[i];
+      b1s[C + i] = p.beta[i];
+    }
+    __syncthreads();
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, q = lane >> 4;
-  for (int i = tid; i < HID; i += NT) b1s[i] = p.b1[i];
 
   // DMA source offsets (bytes) of this thread's LDS positions; LDS position pp (16-byte units) = round * NT + tid
   unsigned off1[DMA], off2[DMA];
@@ -93,34 +109,37 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
     const int row = tile * ROWS + wave * 16 + j;
     const bool live = row < p.M;
     const float* xr = p.x + (long long)min(row, p.M - 1) * C + 4 * q;
-    // ---- LayerNorm of the wave's 16 rows straight into the B-operand registers (lane (j, q): columns 16t + 4q + 0..3)
+    // ---- the wave's 16 rows (MODE 0: layer-normalised) straight into the B-operand registers (lane (j, q): columns 16t + 4q + 0..3)
     float xn[48];
-    float s = 0.f;
 #pragma unroll
     for (int t = 0; t < 12; ++t) {
       const float4 v = ld4(xr + 16 * t);
       xn[4 * t] = v.x; xn[4 * t + 1] = v.y; xn[4 * t + 2] = v.z; xn[4 * t + 3] = v.w;
-      s += (v.x + v.y) + (v.z + v.w);
     }
-    s += __shfl_xor(s, 16, 64);
-    s += __shfl_xor(s, 32, 64);
-    const float mu = s * (1.0f / C);
-    float var = 0.f;
+    if (MODE == 0) {
+      float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 48; ++i) {
-      const float d = xn[i] - mu;
-      var += d * d;
-    }
-    var += __shfl_xor(var, 16, 64);
-    var += __shfl_xor(var, 32, 64);
-    const float rs = 1.0f / sqrtf(var * (1.0f / C) + p.eps);
+      for (int t = 0; t < 12; ++t) s += (xn[4 * t] + xn[4 * t + 1]) + (xn[4 * t + 2] + xn[4 * t + 3]);
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      const float mu = s * (1.0f / C);
+      float var = 0.f;
 #pragma unroll
-    for (int t = 0; t < 12; ++t) {
-      const float4 g = ld4(p.gamma + 16 * t + 4 * q), bb = ld4(p.beta + 16 * t + 4 * q);
-      xn[4 * t] = (xn[4 * t] - mu) * rs * g.x + bb.x;
-      xn[4 * t + 1] = (xn[4 * t + 1] - mu) * rs * g.y + bb.y;
-      xn[4 * t + 2] = (xn[4 * t + 2] - mu) * rs * g.z + bb.z;
-      xn[4 * t + 3] = (xn[4 * t + 3] - mu) * rs * g.w + bb.w;
+      for (int i = 0; i < 48; ++i) {
+        const float d = xn[i] - mu;
+        var += d * d;
+      }
+      var += __shfl_xor(var, 16, 64);
+      var += __shfl_xor(var, 32, 64);
+      const float rs = 1.0f / sqrtf(var * (1.0f / C) + p.eps);
+#pragma unroll
+      for (int t = 0; t < 12; ++t) {
+        const float4 g = ld4(b1s + 16 * t + 4 * q), bb = ld4(b1s + (MODE == 0 ? C : 0) + 16 * t + 4 * q);
+        xn[4 * t] = (xn[4 * t] - mu) * rs * g.x + bb.x;
+        xn[4 * t + 1] = (xn[4 * t + 1] - mu) * rs * g.y + bb.y;
+        xn[4 * t + 2] = (xn[4 * t + 2] - mu) * rs * g.z + bb.z;
+        xn[4 * t + 3] = (xn[4 * t + 3] - mu) * rs * g.w + bb.w;
+      }
     }
     f32x4v acc[12];
 #pragma unroll
@@ -129,6 +148,17 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
     for (int c = c0; c < c1; ++c, ++it) {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // W1(c) landed everywhere; W2 tile free
       issue_w2(c);
+      const long long ho = (long long)min(row, p.M - 1) * HID + c * CH + 4 * q;
+      float4 g0p = make_float4(0.f, 0.f, 0.f, 0.f), g1p = g0p;
+      if (MODE == 0) {
+        g0p = ld4(p.b1 + c * CH + 4 * q);
+        g1p = ld4(p.b1 + c * CH + 16 + 4 * q);
+      }
+      if (MODE == 1) {
+        g0p = ld4(p.hpre + ho);
+        g1p = ld4(p.hpre + ho + 16);
+        asm volatile("" ::: "memory");            // issue here, under GEMM1 -- not where the values are first used
+      }
       // ---- GEMM1: two 16-unit blocks, K = 192
       f32x4v h0 = {0.f, 0.f, 0.f, 0.f}, h1 = {0.f, 0.f, 0.f, 0.f};
       const float* a0p = w1t + j * C;
@@ -156,15 +186,48 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);          // the two ds_read_b128 of the NEXT group first ...
         __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);          // ... then this group's eight MFMAs
       }
-      {
-        const float4 ba = ld4(b1s + c * CH + 4 * q), bb = ld4(b1s + c * CH + 16 + 4 * q);
+      if (MODE == 0) {
+        const float4 ba = g0p, bb = g1p;
         h0[0] = gelu_fast(h0[0] + ba.x); h0[1] = gelu_fast(h0[1] + ba.y);
         h0[2] = gelu_fast(h0[2] + ba.z); h0[3] = gelu_fast(h0[3] + ba.w);
         h1[0] = gelu_fast(h1[0] + bb.x); h1[1] = gelu_fast(h1[1] + bb.y);
         h1[2] = gelu_fast(h1[2] + bb.z); h1[3] = gelu_fast(h1[3] + bb.w);
+      } else {
+        // (opaque redefinition after GEMM1's LDS reads: otherwise hipcc starts GELU' -- and waits for the loads -- at the chunk's top)
+        asm volatile("" : "+v"(g0p.x), "+v"(g0p.y), "+v"(g0p.z), "+v"(g0p.w), "+v"(g1p.x), "+v"(g1p.y), "+v"(g1p.z), "+v"(g1p.w)
+                     :: "memory");
+        h0[0] *= gelu_grad_fast(g0p.x); h0[1] *= gelu_grad_fast(g0p.y);
+        h0[2] *= gelu_grad_fast(g0p.z); h0[3] *= gelu_grad_fast(g0p.w);
+        h1[0] *= gelu_grad_fast(g1p.x); h1[1] *= gelu_grad_fast(g1p.y);
+        h1[2] *= gelu_grad_fast(g1p.z); h1[3] *= gelu_grad_fast(g1p.w);
+        // column sums of the chunk over the wave's 16 rows (fixed shuffle tree), one row of b1s per wave
+        float cs[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          cs[r] = live ? h0[r] : 0.f;
+          cs[4 + r] = live ? h1[r] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) cs[r] = row16_sum(cs[r]);
+        if (j == 0) {
+          st4(b1s + wave * CH + 4 * q, make_float4(cs[0], cs[1], cs[2], cs[3]));
+          st4(b1s + wave * CH + 16 + 4 * q, make_float4(cs[4], cs[5], cs[6], cs[7]));
+        }
       }
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // W2(c) landed everywhere; W1 tile free
       if (it + 1 < end) issue_w1((it + 1) % NCHUNK);
+      if (MODE == 1) {          // after the DMA issue: these stores have the whole of GEMM2 to retire before the next vmcnt(0)
+        if (live) {
+          st4(p.dhp + ho, make_float4(h0[0], h0[1], h0[2], h0[3]));
+          st4(p.dhp + ho + 16, make_float4(h1[0], h1[1], h1[2], h1[3]));
+        }
+        if (tid < CH) {
+          float sum = 0.f;
+#pragma unroll
+          for (int w = 0; w < NW; ++w) sum += b1s[w * CH + tid];
+          p.colpart[(long long)tile * HID + c * CH + tid] = sum;
+        }
+      }
       // ---- GEMM2: 12 column blocks of 16, K = the 32 units of this chunk
       auto w2frag = [&](int ob, float4& f0, float4& f1) {
         const int r2 = 16 * ob + j, sw = (r2 >> 1) & 7;
@@ -199,7 +262,11 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
         float* yr = p.y + (long long)row * C + 4 * q;
 #pragma unroll
         for (int ob = 0; ob < 12; ++ob) {
-          const float4 r = ld4(xr + 16 * ob), b2 = ld4(p.b2 + 16 * ob + 4 * q);
+          float4 r = make_float4(0.f, 0.f, 0.f, 0.f), b2 = r;
+          if (MODE == 0) {
+            r = ld4(xr + 16 * ob);
+            b2 = ld4(p.b2 + 16 * ob + 4 * q);
+          }
           st4(yr + 16 * ob, make_float4(acc[ob][0] + b2.x + r.x, acc[ob][1] + b2.y + r.y, acc[ob][2] + b2.z + r.z,
                                         acc[ob][3] + b2.w + r.w));
         }
@@ -214,7 +281,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
 }
 
 // y[tile] = x + b2 + sum of the tile's partials in chunk order, for the tiles that no single workgroup finished
-template <int ROWS>
+template <int ROWS, int MODE>
 __global__ __launch_bounds__(256) void mlp_fixup_kernel(MlpP p, int G) {
   const int tile = blockIdx.y;
   const int first = tile * NCHUNK, last = first + NCHUNK - 1;
@@ -229,7 +296,11 @@ __global__ __launch_bounds__(256) void mlp_fixup_kernel(MlpP p, int G) {
   const long long row = (long long)tile * ROWS + e / C;
   if (row >= p.M) return;
   const int col = e % C;
-  const float4 xv = ld4(p.x + row * C + col), bv = ld4(p.b2 + col);
+  float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), bv = xv;
+  if (MODE == 0) {
+    xv = ld4(p.x + row * C + col);
+    bv = ld4(p.b2 + col);
+  }
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int w = w0; w <= w1; ++w) {
     int st, cn;
@@ -242,7 +313,7 @@ __global__ __launch_bounds__(256) void mlp_fixup_kernel(MlpP p, int G) {
 }
 
 // NW waves per workgroup (16 rows each), WPS waves per SIMD the register allocation is held to
-template <int NW, int WPS>
+template <int NW, int WPS, int MODE>
 struct Variant {
   static constexpr int ROWS = NW * 16;
   static int grid(int tiles) {
@@ -251,7 +322,7 @@ struct Variant {
       int dev = 0, cus = 256, per_cu = 1;
       (void)hipGetDevice(&dev);
       (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mlp_fused_kernel<NW, WPS>, NW * 64, 0);
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mlp_fused_kernel<NW, WPS, MODE>, NW * 64, 0);
       slots = cus * (per_cu > 0 ? per_cu : 1);
     }
     const long long items = (long long)tiles * NCHUNK;
@@ -273,10 +344,10 @@ struct Variant {
   }
   static int launch(MlpP p, hipStream_t st) {
     const int G = partition(p);
-    hipLaunchKernelGGL((mlp_fused_kernel<NW, WPS>), dim3(G), dim3(NW * 64), 0, st, p);
+    hipLaunchKernelGGL((mlp_fused_kernel<NW, WPS, MODE>), dim3(G), dim3(NW * 64), 0, st, p);
     RP_CHECK_LAUNCH();
     if (p.rem != 0 || p.base % NCHUNK != 0) {                     // some tile is shared between workgroups
-      hipLaunchKernelGGL(mlp_fixup_kernel<ROWS>, dim3((ROWS * C / 4 + 255) / 256, p.tiles), dim3(256), 0, st, p, G);
+      hipLaunchKernelGGL((mlp_fixup_kernel<ROWS, MODE>), dim3((ROWS * C / 4 + 255) / 256, p.tiles), dim3(256), 0, st, p, G);
       RP_CHECK_LAUNCH();
     }
     return RP_OK;
@@ -297,10 +368,9 @@ int mlp_variant() {
 extern "C" size_t rp_mlp_fused_workspace_bytes(int M) {
   if (M <= 0) return 0;
   switch (mlp_variant()) {
-    case 1: return Variant<4, 3>::workspace(M);
-    case 2: return Variant<12, 3>::workspace(M);
-    case 3: return Variant<8, 4>::workspace(M);
-    default: return Variant<8, 2>::workspace(M);
+    case 1: return Variant<8, 2, 0>::workspace(M);
+    case 2: return Variant<12, 3, 0>::workspace(M);
+    default: return Variant<4, 3, 0>::workspace(M);
   }
 }
 
@@ -309,12 +379,23 @@ extern "C" int rp_mlp_fused_fwd(const float* x, const float* gamma, const float*
                                 void* stream) {
   if (M <= 0 || dim != C || hidden != HID || !x || !gamma || !beta || !w1 || !b1 || !w2 || !b2 || !y || !workspace)
     return RP_EBADSHAPE;
-  MlpP p{x, gamma, beta, w1, b1, w2, b2, y, (float*)workspace, M, eps, 0, 0, 0, 0};
+  MlpP p{x, gamma, beta, w1, b1, w2, b2, y, nullptr, nullptr, nullptr, (float*)workspace, M, eps, 0, 0, 0, 0};
   hipStream_t st = (hipStream_t)stream;
   switch (mlp_variant()) {
-    case 1: return Variant<4, 3>::launch(p, st);
-    case 2: return Variant<12, 3>::launch(p, st);
-    case 3: return Variant<8, 4>::launch(p, st);
-    default: return Variant<8, 2>::launch(p, st);
+    case 1: return Variant<8, 2, 0>::launch(p, st);
+    case 2: return Variant<12, 3, 0>::launch(p, st);
+    default: return Variant<4, 3, 0>::launch(p, st);
   }
+}
+
+// Backward-data of the MLP (training): dhp [M,768] = (dy W2) o GELU'(hpre), dxn [M,192] = dhp W1, colpart [tiles,768] = column
+// sums of dhp per 64-row tile (sum them for the fc1 bias gradient).  w2t = W2^T [768,192], w1t = W1^T [192,768] (contiguous).
+extern "C" size_t rp_mlp_fused_bwd_workspace_bytes(int M) { return M > 0 ? Variant<8, 2, 1>::workspace(M) : 0; }
+extern "C" int rp_mlp_fused_bwd_tile_rows(void) { return Variant<8, 2, 1>::ROWS; }
+extern "C" int rp_mlp_fused_bwd(const float* dy, const float* hpre, const float* w2t, const float* w1t, float* dhp, float* dxn,
+                                float* colpart, void* workspace, int M, int dim, int hidden, void* stream) {
+  if (M <= 0 || dim != C || hidden != HID || !dy || !hpre || !w2t || !w1t || !dhp || !dxn || !colpart || !workspace)
+    return RP_EBADSHAPE;
+  MlpP p{dy, nullptr, nullptr, w2t, nullptr, w1t, nullptr, dxn, hpre, dhp, colpart, (float*)workspace, M, 0.f, 0, 0, 0, 0};
+  return Variant<8, 2, 1>::launch(p, (hipStream_t)stream);
 }

@@ -617,5 +617,5 @@ extern "C" int rp_pose_normalize_bwd(const float* pred, const float* dout, float
   return RP_OK;
 }
 
-extern "C" int rp_abi_version(void) { return 2; }
+extern "C" int rp_abi_version(void) { return 3; }
 extern "C" const char* rp_target_arch(void) { return "gfx950"; }

@@ -160,9 +160,19 @@ class KernelTimer:
 
     def summary(self):
         """-> (launches, mean seconds per launch, total algorithmic flops); call after a device sync."""
+        lib = _lib.load()
         n = len(self.events)
-        tot = sum(s.elapsed_time(e) for s, e in self.events) * 1e-3
+        tot = sum(lib.rp_event_elapsed_ms(s, e) for s, e in self.events) * 1e-3
         return n, (tot / n if n else 0.0), self.flops
+
+    def new_pair(self):
+        """two hipEvent handles from a free list (events of earlier summaries are reused after reset())"""
+        lib = _lib.load()
+        if not hasattr(self, "_pool"):
+            self._pool = []
+        if not self._pool:
+            self._pool = [ctypes.c_void_p(lib.rp_event_create()) for _ in range(64)]
+        return self._pool.pop(), self._pool.pop()
 
 
 TIMER = None
@@ -221,12 +231,12 @@ def gemm(A, B, M, N, K, *, a_layout=0, b_layout=0, lda=None, ldb=None, out=None,
         cpart = _empty(2 * (-(-M // (64 * tm_))), N, like=A)
         g.colsum_part = cpart.data_ptr()
     tm = TIMER
-    if (tm is not None and tm.enabled and split_k == 1 and
+    if (tm is not None and tm.enabled and batch == 1 and ln is None and
             gemm_instance(M, N, a_layout, b_layout, aux is not None or residual is not None) == tm.instance):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+        # events are recorded by rp_gemm itself around the MAIN kernel (a split-K launch's reduce is a separate kernel)
+        e0, e1 = tm.new_pair()
+        g.ev_start, g.ev_stop = e0, e1
         _lib.check(lib.rp_gemm(ctypes.byref(g), _st()), "rp_gemm")
-        e1.record()
         tm.events.append((e0, e1))
         tm.flops += 2.0 * M * N * K * batch
         tm.bytes += 4.0 * batch * (M * K + N * K + M * N * (1 + (aux is not None) + (residual is not None) + (pre_out is not None)))
@@ -239,16 +249,20 @@ def gemm(A, B, M, N, K, *, a_layout=0, b_layout=0, lda=None, ldb=None, out=None,
 ROWS_LINEAR = os.environ.get("RP_ROWS_LINEAR", "1") != "0"
 
 
+ROWS_DX = os.environ.get("RP_ROWS_DX", "1") != "0"      # input-gradient GEMMs that contract over 192 (fc2, proj) likewise
+
+
 def _rows_ok(x, W):
     return (ROWS_LINEAR and GEMM_PRECISION == 0 and x.shape[1] == DIM and W.shape[1] == DIM and W.shape[0] % 32 == 0
             and W.shape[0] <= 1024 and x.is_contiguous() and W.is_contiguous())
 
 
-def linear_rows(x, W, b=None, act=0, want_pre=False, residual=None, ln=None, want_ln_out=False):
+def linear_rows(x, W, b=None, act=0, want_pre=False, residual=None, ln=None, want_ln_out=False, dact_aux=None, want_colsum=False):
     """rp_linear_rows192: y = act(LN?(x) W^T + b) (+ residual) for K = 192.  ln = (gamma, beta) fuses the LayerNorm;
-    want_ln_out additionally returns (xn, mean, rstd).  Returns y [, pre] [, xn, mean, rstd]."""
+    want_ln_out additionally returns (xn, mean, rstd).  dact_aux [M,N]: y *= GELU'(aux); want_colsum: also the column sums of y
+    (from per-tile partials).  Returns y [, pre] [, xn, mean, rstd] [, colsum]."""
     lib = _lib.load()
-    _chk(x, W, b, residual)
+    _chk(x, W, b, residual, dact_aux)
     M, K = x.shape
     N = W.shape[0]
     y = _empty(M, N, like=x)
@@ -260,9 +274,11 @@ def linear_rows(x, W, b=None, act=0, want_pre=False, residual=None, ln=None, wan
         _chk(g, be)
         if want_ln_out:
             xn, mean, rstd = torch.empty_like(x), _empty(M, like=x), _empty(M, like=x)
+    part = _empty(-(-M // lib.rp_linear_rows192_tile_rows()), N, like=x) if want_colsum else None
     _lib.check(lib.rp_linear_rows192(_p(x), _p(W), _p(b), _p(residual), _p(g), _p(be), LN_EPS, _p(y), _p(pre), _p(xn), _p(mean),
-                                     _p(rstd), M, N, K, act, _st()), "rp_linear_rows192")
-    out = (y,) + ((pre,) if want_pre else ()) + ((xn, mean, rstd) if (ln is not None and want_ln_out) else ())
+                                     _p(rstd), _p(dact_aux), _p(part), M, N, K, act, _st()), "rp_linear_rows192")
+    out = ((y,) + ((pre,) if want_pre else ()) + ((xn, mean, rstd) if (ln is not None and want_ln_out) else ())
+           + ((colsum(part),) if want_colsum else ()))
     return out[0] if len(out) == 1 else out
 
 
@@ -294,6 +310,9 @@ def linear_dx(dy, W, dact=0, aux=None, want_colsum=False):
     layer below when dx is its pre-activation gradient), from the epilogue."""
     M, N = dy.shape
     K = W.shape[1]
+    if ROWS_DX and N == DIM and K % 32 == 0 and K <= 1024 and GEMM_PRECISION == 0 and dy.is_contiguous() and dact in (0, 1):
+        # contraction over the layer's 192 outputs: the row-resident kernel on the transposed weight (a 0.1-0.6 MB copy)
+        return linear_rows(dy, W.t().contiguous(), dact_aux=aux if dact else None, want_colsum=want_colsum)
     return gemm(dy, W, M, K, N, b_layout=1, dact=dact, aux=aux, want_colsum=want_colsum)
 
 
@@ -665,6 +684,28 @@ def mlp_fused(x2d, gamma, beta, w1, b1, w2, b2, eps=LN_EPS):
     return y
 
 
+FUSE_MLP_BWD = os.environ.get("RP_FUSE_MLP_BWD", "1") != "0"
+
+
+def mlp_fused_bwd(dy, hpre, w1, w2):
+    """(dhp, dxn, db1_partials) of the MLP backward-data chain (rp_mlp_fused_bwd): dhp = (dy W2) o GELU'(hpre), dxn = dhp W1.
+    w1 [768,192], w2 [192,768] as stored by nn.Linear (transposed here: 2 x 590 KB); db1_partials [tiles,768] column-sums to db1."""
+    lib = _lib.load()
+    _chk(dy, hpre)
+    M = dy.shape[0]
+    w2t, w1t = w2.t().contiguous(), w1.t().contiguous()
+    dhp, dxn = torch.empty_like(hpre), torch.empty_like(dy)
+    tiles = -(-M // lib.rp_mlp_fused_bwd_tile_rows())
+    colpart = _empty(tiles, hpre.shape[1], like=dy)
+    key = (dy.device, M, "bwd")
+    ws = _mlp_ws.get(key)
+    if ws is None:
+        ws = _mlp_ws[key] = torch.empty(max(1, lib.rp_mlp_fused_bwd_workspace_bytes(M)) // 4 + 1, device=dy.device, dtype=torch.float32)
+    _lib.check(lib.rp_mlp_fused_bwd(_p(dy), _p(hpre), _p(w2t), _p(w1t), _p(dhp), _p(dxn), _p(colpart), _p(ws), M, dy.shape[1],
+                                    hpre.shape[1], _st()), "rp_mlp_fused_bwd")
+    return dhp, dxn, colpart
+
+
 def _mlp_block_fwd(x1, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b, train):
     """(y, xn2, m2, r2, h, hpre) of `x1 + Mlp(norm2(x1))`; the inference path returns y only (rest None)."""
     if (not train and FUSE_MLP and GEMM_PRECISION == 0 and x1.shape[1] == DIM and tuple(fc1_w.shape) == (4 * DIM, DIM)
@@ -705,6 +746,17 @@ def _mlp_bwd(fork, dy, xn, h, hpre, w1, w2, want_db2=True, ln=None):
         dw2, db2 = _param_grads(fork, dy, h)
     else:                     # the caller gets colsum(dy) for free from the LayerNorm backward that adds dy
         dw2, db2 = fork.on_side(lambda: linear_dw(dy, h)), None
+    if (FUSE_MLP_BWD and GEMM_PRECISION == 0 and dy.shape[1] == DIM and tuple(w1.shape) == (4 * DIM, DIM)
+            and tuple(w2.shape) == (DIM, 4 * DIM)):
+        # both input-gradient products as one kernel (dh stays on chip); fc1 bias gradient from its per-tile column sums
+        dh, dxn, part = mlp_fused_bwd(dy, hpre, w1, w2)
+        db1 = colsum(part)
+        fork.sync_side()
+        dw1 = fork.on_side(lambda: linear_dw(dh, xn))
+        if ln is not None:
+            x_, gamma_, mean_, rstd_, add_ = ln
+            return layernorm_bwd(dxn, x_, gamma_, mean_, rstd_, add=add_), dw1, db1, dw2, db2
+        return dxn, dw1, db1, dw2, db2
     # grad wrt fc1 pre-activation (GELU' fused) and, from the same epilogue, its column sums = the fc1 bias gradient
     dh, db1 = linear_dx(dy, w2, dact=1, aux=hpre, want_colsum=True)
     fork.sync_side()

@@ -729,3 +729,42 @@ def test_row_resident_linear_with_fused_layernorm(ops, M):
     assert max(worst.values()) < 2e-6, worst
     with pytest.raises(RuntimeError):
         ops.linear_rows(x, rnd(200, 192, seed=1), None)                                    # N % 32 != 0
+
+
+@pytest.mark.parametrize("M", [140, 1152, 9216 + 48])
+def test_fused_mlp_backward_data_kernel(ops, M):
+    """rp_mlp_fused_bwd: dhp = (dy W2) o GELU'(h_pre), dxn = dhp W1 and the per-tile column sums of dhp (fc1 bias gradient) as one
+    kernel, against fp64 autograd of fc2(GELU(fc1(xn))) (vit_layers/mlp.py:20-26).  Tolerance 3e-6 of the maximum."""
+    import torch.nn.functional as F
+    w1, b1 = rnd(768, 192, seed=4, scale=192 ** -0.5), 0.1 * rnd(768, seed=5)
+    w2 = rnd(192, 768, seed=6, scale=768 ** -0.5)
+    xn = rnd(M, 192, seed=8).double().requires_grad_(True)
+    dy = rnd(M, 192, seed=9)
+    hp = F.linear(xn, w1.double(), b1.double())
+    hp.retain_grad()
+    y = F.linear(F.gelu(hp), w2.double())
+    y.backward(dy.double())
+    dhp, dxn, part = ops.mlp_fused_bwd(dy, hp.detach().float().contiguous(), w1, w2)
+    e = dict(dhp=rel(dhp, hp.grad), dxn=rel(dxn, xn.grad), db1=rel(part.sum(0), hp.grad.sum(0)))
+    report("mlp_fused_bwd_M%d" % M, **e)
+    assert max(e.values()) < 3e-6, e
+    d2, x2, p2 = ops.mlp_fused_bwd(dy, hp.detach().float().contiguous(), w1, w2)
+    assert torch.equal(d2, dhp) and torch.equal(x2, dxn) and torch.equal(p2, part)        # deterministic
+
+
+@pytest.mark.parametrize("M", [140, 1152, 9216 + 48])
+def test_row_resident_input_gradient_with_gelu_grad_and_column_sums(ops, M):
+    """linear_dx for a Linear with 192 outputs (fc2, attention proj) on rp_linear_rows192: dx = (dy W) o GELU'(aux) and the column
+    sums of dx (the fc1 bias gradient), against fp64 and against the rp_gemm path.  Tolerance 3e-6 of the maximum."""
+    dy, aux = rnd(M, 192, seed=21), rnd(M, 768, seed=22, scale=1.5)
+    w2 = rnd(192, 768, seed=23, scale=768 ** -0.5)
+    dx, cs = ops.linear_dx(dy, w2, dact=1, aux=aux, want_colsum=True)
+    a = aux.double()
+    gp = 0.5 * (1 + torch.erf(a / math.sqrt(2))) + a * torch.exp(-0.5 * a * a) / math.sqrt(2 * math.pi)
+    ref = (dy.double() @ w2.double()) * gp
+    old_dx, old_cs = ops.gemm(dy, w2, M, 768, 192, b_layout=1, dact=1, aux=aux, want_colsum=True)
+    wp = rnd(192, 192, seed=24, scale=192 ** -0.5)
+    e = dict(dx=rel(dx, ref), colsum=rel(cs, ref.sum(0)), vs_rp_gemm=rel(dx, old_dx), colsum_vs_rp_gemm=rel(cs, old_cs),
+             proj_dx=rel(ops.linear_dx(dy, wp), dy.double() @ wp.double()))
+    report("linear_rows_dx_M%d" % M, **e)
+    assert max(e.values()) < 3e-6, e

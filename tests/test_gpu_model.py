@@ -203,8 +203,10 @@ def test_full_model_forward_vs_reference(model, golden, tag, B, H, W, key):
 
 
 def test_pairs_are_independent_at_full_batch(model):
-    """Size-independent property at BASELINE's full size (64 pairs): permuting the pairs permutes the output
-    bit-for-bit, and a batch equals its halves run separately (deterministic kernels, no cross-pair coupling)."""
+    """Size-independent property at BASELINE's full size (64 pairs): copies of a pair at different batch positions give the same
+    pose to 1e-6 (no cross-pair coupling; the stream-K MLP kernel may add a row tile's partial sums in a different association at
+    a different position, so not bit-for-bit), the batch agrees with the 4 distinct pairs run alone, and running the same batch
+    twice IS bit-identical (fixed-order reductions everywhere)."""
     B = 64
     tok = O.synthetic_tokens(8)
     fm8 = tok.permute(0, 2, 1).contiguous().view(8, 192, 24, 24).cuda()
@@ -220,13 +222,18 @@ def test_pairs_are_independent_at_full_batch(model):
     # the batched 26880->512 GEMM splits K differently for 64 rows and 4 rows: allow fp32 rounding there
     assert rel(full, small[src]) < 1e-5
     for b in range(B):
-        assert torch.equal(full[b], full[int((src == src[b]).nonzero()[0])])      # identical pairs -> identical bits
+        assert rel(full[b], full[int((src == src[b]).nonzero()[0])]) < 1e-6       # identical pairs -> identical poses
+    with torch.no_grad():
+        assert torch.equal(full, model.forward_tokens(fmap, Gs, intr))            # deterministic
 
 
 def test_full_size_backward_config3(model, states):
     """BASELINE.json configs[2] (fwd+bwd, 64 pairs per GPU) through the hot path, as a property AND an oracle check.
     The batch is 4 distinct pairs, each replicated 16 times (interleaved), with one cotangent per distinct pair:
-      * pair independence: the token gradients of the 16 copies of a pair are bit-identical;
+      * pair independence: the token gradients of the 16 copies of a pair agree to 2e-6 of the largest gradient (round 1 asserted
+        bit-identity; since the stream-K MLP kernels a row tile that is shared between two workgroups adds its partial sums in a
+        different association than one finished by a single workgroup -- still a fixed order, so run-to-run results ARE
+        bit-identical, which the kernel tests assert);
       * linearity in the batch: every parameter gradient equals 16 x the fp64 oracle's gradient on the 4 distinct pairs
         (<= 1e-3 of max|ref| per tensor -- the split-K / XCD-remap / tile choices all differ from the 4-pair launches)."""
     _, sd64 = states
@@ -248,15 +255,16 @@ def test_full_size_backward_config3(model, states):
         assert torch.isfinite(out).all()
         t_err, q_err, ang = O.pose_errors(out[:4].detach().cpu(), ref.detach())
         g = fmap.grad.view(B, 2, 192, 576)
-        for b in range(4, B):
-            assert torch.equal(g[b], g[b % 4]), "pair %d is a copy of pair %d but its token gradient differs" % (b, b % 4)
+        gmax = float(g.abs().max())
+        indep = max(float((g[b] - g[b % 4]).abs().max()) for b in range(4, B)) / gmax
+        assert indep < 2e-6, "copies of a pair differ by %.2e of the largest token gradient" % indep
         e_tok = rel(g[:4].reshape(8, 192, 576).permute(0, 2, 1), gtok)
         worst = {"tokens": e_tok}
         for name, p in model.named_parameters():
             if name.startswith("fusion_transformer") or name.startswith("pose_regressor"):
                 assert p.grad is not None, name
                 worst[name] = rel(p.grad, R * sd[name].grad)
-        report("config3_backward_64pairs", t=t_err, q=q_err, max_grad=max(worst.values()), tokens=e_tok)
+        report("config3_backward_64pairs", t=t_err, q=q_err, max_grad=max(worst.values()), tokens=e_tok, pair_copies=indep)
         bad = {k: v for k, v in worst.items() if v > 1e-3}
         assert max(t_err, q_err) < 1e-4 and not bad, bad
     finally:

@@ -19,13 +19,17 @@ W2 = torch.randn(192, 768, device=dev) * 0.07; b2 = torch.zeros(192, device=dev)
 dY768 = torch.randn(M, 768, device=dev)
 dY192 = torch.randn(M, 192, device=dev)
 intr = torch.tensor([192.0, 192.0, 192.0, 192.0], device=dev).repeat(Z // 2, 2, 1).contiguous()
+g1, be1 = torch.ones(192, device=dev), torch.zeros(192, device=dev)
 for _ in range(reps):
-    qkv = ops.linear(x, Wq, bq)                       # gemm<0,0,2,1> forward
-    ops.linear(x, Wp, bp, residual=x)
-    h, hpre = ops.linear(x, W1, b1, act=1, want_pre=True)
-    ops.linear(h, W2, b2, residual=x)
-    ops.linear_dx(dY768, W1)                          # dX
-    ops.linear_dx(dY192, W2, dact=1, aux=hpre)
+    qkv = ops.ln_linear(x, g1, be1, Wq, bq)[0]        # linear_rows_kernel<true>: LayerNorm + qkv
+    ops.linear(x, Wp, bp, residual=x)                 # linear_rows_kernel<false>: proj + residual
+    h, hpre = ops.ln_linear(x, g1, be1, W1, b1, act=1, want_pre=True)[:2]
+    ops.linear(h, W2, b2, residual=x)                 # gemm_dma<0,0,2,1>: fc2 forward
+    ops.mlp_fused(x, g1, be1, W1, b1, W2, b2)         # inference MLP, one kernel
+    ops.mlp_fused_bwd(dY192, hpre, W1, W2)            # MLP backward-data, one kernel
+    ops.linear_dx(dY768, W1)                          # dX (K = 768): gemm_dma<0,1,1,3>
+    ops.linear_dx(dY192, W2, dact=1, aux=hpre)        # dX with GELU' (row-resident form)
+    ops.gemm(qkv, Wq, M, 192, 576, b_layout=1)        # dX of qkv: gemm_dma<0,1,...>
     ops.linear_dw(dY768, x)                           # dW split-K
     ops.linear_dw(dY192, h)
     o, lse = ops.attn_fwd(qkv, Z)

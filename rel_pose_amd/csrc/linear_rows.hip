@@ -53,7 +53,7 @@ __global__ __launch_bounds__(NT, 3) void linear_rows_kernel(RowsP p) {
   __shared__ __attribute__((aligned(16))) float wt[2][WT];
   // 1.5 KB shared by two uses that never coincide: gamma | beta of the fused LayerNorm (forward), or the per-wave column sums of a
   // chunk by chunk parity (input-gradient form; readers of chunk k never meet writers of k + 1).  Kept this small on purpose: with
-  // 53 KB per workgroup only two, not three, workgroups are resident per CU (LDS is allocated in 1.25 KB granules).
+  // 53 KB per workgroup only two, not three, workgroups are resident per CU (measured: tools/lab/rows_probe; the occupancy API still reports three).
   __shared__ __attribute__((aligned(16))) float aux_lds[2 * C];
   float (*cs_lds)[NW * CH] = reinterpret_cast<float (*)[NW * CH]>(aux_lds);
   static_assert(2 * NW * CH <= 2 * C, "column-sum scratch must fit the shared 1.5 KB");

@@ -300,3 +300,27 @@ def test_tangent_space_gradient_matches_finite_differences_of_left_perturbation(
                 assert abs(fd - got[b, s, k]) < 1e-5 * max(1.0, abs(fd)), (b, s, k, fd, got[b, s, k])
     # the switch: default euclidean; "tangent" routes through with_tangent_gradient
     assert losses.GRADIENT_CONVENTION == "euclidean"
+
+
+def test_branch_free_gelu_constants_are_accurate():
+    """common.h's gelu_fast / gelu_grad_fast (used by the fused MLP and row-resident kernels instead of libm's erff): the fp32 Horner
+    evaluation with the constants AS WRITTEN IN THE HEADER stays within 5e-7 of the exact-erf GELU (<= 1 ulp of the result near
+    |x| ~ 4.5) and its derivative within 5e-7, over [-9, 9].  tools/fit_gelu.py is the derivation."""
+    from scipy.special import erf
+    src = open(os.path.join(ROOT, "rel_pose_amd", "csrc", "common.h")).read()
+    body = src[src.index("RP_DEV float gelu_fast(float x)"):src.index("RP_DEV float gelu_grad_fast")]
+    c = [float(v) for v in re.findall(r"(-?\d\.\d+e[+-]\d+)f", body)]
+    assert len(c) == 8                                               # c7 (initial p) then c6 .. c0 in Horner order
+    x = np.linspace(-9, 9, 360001).astype(np.float32)
+    t = np.minimum(np.abs(x), np.float32(5.7))
+    p = np.full_like(t, np.float32(c[0]))
+    for k in c[1:]:
+        p = p * t + np.float32(k)
+    e = np.exp2((-(t * p) - np.float32(1)).astype(np.float32)).astype(np.float32)
+    cdf = np.where(x < 0, e, np.float32(1) - e).astype(np.float32)
+    xd = x.astype(np.float64)
+    phi = 0.5 * (1 + erf(xd / np.sqrt(2)))
+    assert np.abs((x * cdf).astype(np.float64) - xd * phi).max() < 5e-7
+    pdf = (np.float32(0.39894228040143267794) * np.exp2((np.float32(-0.72134752044448170368) * x * x).astype(np.float32))).astype(np.float32)
+    grad = (x * pdf + cdf).astype(np.float64)
+    assert np.abs(grad - (phi + xd * np.exp(-0.5 * xd * xd) / np.sqrt(2 * np.pi))).max() < 5e-7

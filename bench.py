@@ -211,6 +211,7 @@ def main():
 
     ops.set_gemm_precision(PRECISIONS[args.precision])
     ops.set_attention_precision(1 if args.precision == "bf16" else 0)      # configs[4]: bf16 MFMA attention / EMM GEMMs too
+    ops.set_cnn_precision(1 if args.precision == "bf16" and not os.environ.get("RP_BF16_KEEP_FP32_CNN") else 0)   # and the MIOpen convolutions
     timer = ops.KernelTimer([int(v) for v in args.timer_instance.split(",")])
     ops.TIMER = timer
     eager_step = step
@@ -300,8 +301,8 @@ def main():
                        "gemm_operand_precision": {0: "exact fp32 MFMA", 3: "fp32 operands split into 3 bf16 limbs, 6 limb "
                                                   "products on the bf16 MFMA pipe, fp32 accumulate (fp32-grade: measured "
                                                   "error vs fp64 <= the fp32-MFMA kernel's)", 1: "bf16 operands, fp32 accumulate: "
-                                                  "Linear GEMMs (rp_gemm precision 1) and the attention / EMM contractions "
-                                                  "(v_mfma_f32_32x32x16_bf16)"}[nl],
+                                                  "Linear GEMMs (rp_gemm precision 1), the attention / EMM contractions "
+                                                  "(v_mfma_f32_32x32x16_bf16) and the CNN front-end's MIOpen convolutions"}[nl],
                        "launch": "HIP graph replay (fwd+loss+bwd | flat grad all-reduce | clip+Adam)" if graphed else "eager",
                        "hot_path_share": "ViT+EMM+regressor on HIP kernels; ResNet front-end on MIOpen (SURVEY 8f-1)"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1),

@@ -7,7 +7,7 @@ aliasing norm3.
 """
 import torch.nn as nn
 
-from ..ops import bn_act
+from ..ops import bn_act, conv2d
 
 
 class ResidualBlock(nn.Module):
@@ -29,8 +29,8 @@ class ResidualBlock(nn.Module):
             self.downsample = nn.Sequential(nn.Conv2d(in_planes, planes, kernel_size), self.norm3)
 
     def forward(self, x):
-        y = bn_act(self.norm1, self.conv1(x))
-        y = bn_act(self.norm2, self.conv2(y))
+        y = bn_act(self.norm1, conv2d(self.conv1, x))
+        y = bn_act(self.norm2, conv2d(self.conv2, y))
         if self.downsample is not None:           # relu(norm3(conv(x)) + y): the add and the ReLU ride on norm3's pass
-            return bn_act(self.downsample[1], self.downsample[0](x), residual=y)
+            return bn_act(self.downsample[1], conv2d(self.downsample[0], x), residual=y)
         return (x + y).relu_()

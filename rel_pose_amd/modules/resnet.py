@@ -13,7 +13,7 @@ import os
 import torch
 import torch.nn as nn
 
-from ..ops import bn_act
+from ..ops import bn_act, conv2d
 
 
 class BasicBlock(nn.Module):
@@ -31,9 +31,9 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         # BatchNorm + residual add + ReLU as one fused pass pair on the GPU (rel_pose_amd/csrc/batchnorm.hip)
-        idt = x if self.downsample is None else bn_act(self.downsample[1], self.downsample[0](x), relu=False)
-        y = bn_act(self.bn1, self.conv1(x))
-        return bn_act(self.bn2, self.conv2(y), residual=idt)
+        idt = x if self.downsample is None else bn_act(self.downsample[1], conv2d(self.downsample[0], x), relu=False)
+        y = bn_act(self.bn1, conv2d(self.conv1, x))
+        return bn_act(self.bn2, conv2d(self.conv2, y), residual=idt)
 
 
 class ResNet18(nn.Module):

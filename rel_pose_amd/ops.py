@@ -1025,6 +1025,30 @@ class BnActFn(torch.autograd.Function):
                 None if dres is None else dres.permute(0, 3, 1, 2), None, None, None, None)
 
 
+# Convolution operand precision of the CNN front-end (MIOpen through PyTorch-ROCm): 0 = fp32 (the parity path),
+# 1 = bf16 operands / fp32 accumulate -- part of the bf16 configuration (BASELINE.json configs[4], `bench.py --precision bf16`):
+# the fp32 convolutions are 62 % of that configuration's step otherwise (profiles/r2_conv_probe*.txt: 14.3 -> 4.0 ms per 64 pairs).
+# BatchNorm / residual / ReLU (csrc/batchnorm.hip) stay fp32: activations are cast on the way into and out of each convolution.
+CNN_PRECISION = int(os.environ.get("RP_CNN_PRECISION", "0"))
+
+
+def set_cnn_precision(p):
+    global CNN_PRECISION
+    if p not in (0, 1):
+        raise ValueError("CNN precision must be 0 (fp32) or 1 (bf16 operands)")
+    CNN_PRECISION = p
+
+
+def conv2d(m, x):
+    """nn.Conv2d module `m` applied to x at the configured operand precision."""
+    if CNN_PRECISION == 0 or not x.is_cuda:
+        return m(x)
+    bf = torch.bfloat16
+    y = torch.nn.functional.conv2d(x.to(bf), m.weight.to(bf), None if m.bias is None else m.bias.to(bf), m.stride, m.padding,
+                                   m.dilation, m.groups)
+    return y.float()
+
+
 def bn_act(bn, x, residual=None, relu=True):
     """BatchNorm2d module `bn` applied to x, then (+ residual), then ReLU.  GPU tensors take the fused HIP path; CPU tensors
     (only the fixture generator uses the trunk on the CPU, as the reference's torchvision stand-in) take plain PyTorch."""

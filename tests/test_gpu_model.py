@@ -514,3 +514,40 @@ def test_bf16_configuration_at_128_pairs_per_gpu(model, states):
     e_tok = rel(g[:4].reshape(8, 192, 576).permute(0, 2, 1), gtok)
     report("config5_bf16_128pairs", t=t_err, q=q_err, grad_tokens=e_tok)
     assert 1e-5 < max(t_err, q_err) < 5e-2 and e_tok < 2e-1
+
+
+def test_bf16_convolution_front_end_of_the_bf16_configuration(model):
+    """The bf16 configuration (BASELINE.json configs[4], bench.py --precision bf16) also runs the CNN front-end's MIOpen
+    convolutions on bf16 operands (ops.set_cnn_precision(1); BatchNorm / ReLU / pooling stay on the fp32 HIP kernels).  Against the
+    fp32 front-end on the same images, train mode (batch statistics), 4 pairs: CNN maps within 3e-2 of their maximum, pose within
+    5e-2; the gradient that has crossed all 12 convolutions + BatchNorms backwards (the stem's weight gradient) keeps its direction
+    (cosine > 0.9; measured 0.958) and its norm within 20 % -- element-wise it carries bf16's 8 significant bits per layer, so no max-norm bound."""
+    from rel_pose_amd import ops
+    torch.manual_seed(0)
+    images = torch.floor(torch.rand(4, 2, 3, 384, 384, device="cuda") * 255.0)
+    Gs = torch.tensor([0, 0, 0, 0, 0, 0, 1.0]).repeat(4, 2, 1).cuda()
+    intr = torch.tensor([[192.0, 192.0, 192.0, 192.0]]).repeat(4, 2, 1).cuda()
+    model.train()
+    bn_state = {k: v.clone() for k, v in model.state_dict().items() if "running_" in k or "num_batches" in k}
+    res = {}
+    try:
+        for prec in (0, 1):
+            ops.set_cnn_precision(prec)
+            for p in model.parameters():
+                p.grad = None
+            fmap, _ = model.cnn_map(images)
+            out = model(images, Gs, intrinsics=intr.clone())[0].data
+            out[:, 1].square().sum().backward()
+            res[prec] = (fmap.detach().float(), out.detach(), model.resnet.conv1.weight.grad.clone())
+            model.load_state_dict(bn_state, strict=False)
+    finally:
+        ops.set_cnn_precision(0)
+        model.load_state_dict(bn_state, strict=False)
+        model.eval()
+    ga, gb = res[1][2].double().flatten(), res[0][2].double().flatten()
+    e = dict(cnn_map=rel(res[1][0], res[0][0]), pose=rel(res[1][1], res[0][1]), stem_grad_max=rel(res[1][2], res[0][2]),
+             stem_grad_cos=float(torch.dot(ga, gb) / (ga.norm() * gb.norm())), stem_grad_norm_ratio=float(ga.norm() / gb.norm()))
+    report("bf16_cnn_front_end", **e)
+    assert all(torch.isfinite(t).all() for t in res[1])
+    assert 1e-5 < e["cnn_map"] < 3e-2 and e["pose"] < 5e-2, e
+    assert e["stem_grad_cos"] > 0.9 and 0.8 < e["stem_grad_norm_ratio"] < 1.2, e

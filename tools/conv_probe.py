@@ -11,6 +11,7 @@ torch.backends.cudnn.benchmark = True
 dev = "cuda"
 Z = 128
 CL = torch.channels_last
+DT = torch.bfloat16 if os.environ.get("DTYPE") == "bf16" else torch.float32      # DTYPE=bf16: what a bf16 front-end would cost
 
 
 def timeit(fn, n=20, warm=4):
@@ -34,8 +35,8 @@ layers = [  # name, Cin, Cout, k, stride, pad, Hin, count per step
 ]
 tot = {"fwd": 0.0, "bwd": 0.0, "bwd_as_fwd": 0.0, "wrw": 0.0}
 for name, ci, co, k, st, pad, hin, cnt in layers:
-    x = torch.randn(Z, ci, hin, hin, device=dev).contiguous(memory_format=CL)
-    w = (torch.randn(co, ci, k, k, device=dev) * 0.05).contiguous(memory_format=CL)
+    x = torch.randn(Z, ci, hin, hin, device=dev).to(DT).contiguous(memory_format=CL)
+    w = (torch.randn(co, ci, k, k, device=dev) * 0.05).to(DT).contiguous(memory_format=CL)
     y = F.conv2d(x, w, None, st, pad)
     dy = torch.randn_like(y)
     fl = 2.0 * y.numel() * ci * k * k
@@ -48,7 +49,7 @@ for name, ci, co, k, st, pad, hin, cnt in layers:
         wf = w.flip(2, 3).transpose(0, 1).contiguous(memory_format=CL)        # [Cin, Cout, k, k]: dX = conv(dY, flip(W)^T, pad k-1-p)
         dx_ref = bw([True, False, False])[0]
         dx = F.conv2d(dy, wf, None, 1, k - 1 - pad)
-        err = float((dx - dx_ref).abs().max() / dx_ref.abs().max())
+        err = float((dx.float() - dx_ref.float()).abs().max() / dx_ref.float().abs().max())
         t_bf = timeit(lambda: F.conv2d(dy, w.flip(2, 3).transpose(0, 1).contiguous(memory_format=CL), None, 1, k - 1 - pad))
         name += "  [bwd-as-fwd err %.1e]" % err
     print("%-62s x%d  %5.1f GF | fwd %7.1f us (%5.1f TF) | bwd-data %7.1f | bwd-as-fwd %7.1f | wrw %7.1f (%5.1f TF)" %

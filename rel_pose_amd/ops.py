@@ -103,6 +103,35 @@ USE_SIDE_STREAM = os.environ.get("RP_SIDE_STREAM", "0") == "1"   # measured: -0.
 # full step, and it makes per-kernel profiles overlap -> opt-in
 
 
+_PAD_CACHE = {}
+
+
+def _padded(t, pad):
+    """F.pad(t, pad).contiguous() of a weight / bias, cached until the tensor is next modified in place (optimizer step,
+    load_state_dict, DDP broadcast all bump Tensor._version): the three alignment pads of the CrossBlock / regressor weights used to be
+    re-made on every forward."""
+    key = (id(t), tuple(pad))
+    hit = _PAD_CACHE.get(key)
+    if hit is not None and hit[0] == t._version and hit[1] == t.data_ptr():
+        return hit[2]
+    out = torch.nn.functional.pad(t.detach(), pad).contiguous()
+    _PAD_CACHE[key] = (t._version, t.data_ptr(), out)
+    return out
+
+
+_WS_CACHE = {}
+
+
+def _workspace(nbytes, device):
+    """split-K slab buffer, one per (device, stream), grown on demand: launches on one stream are ordered, so consecutive
+    split-K GEMMs can share it (a fresh torch.empty per launch was ~30 allocator calls per step)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WS_CACHE.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = _WS_CACHE[key] = torch.empty(max(nbytes // 4, 1 << 20), device=device, dtype=torch.float32)
+    return ws
+
+
 class _Fork:
     def __init__(self, device):
         self.enabled = USE_SIDE_STREAM
@@ -210,7 +239,7 @@ def gemm(A, B, M, N, K, *, a_layout=0, b_layout=0, lda=None, ldb=None, out=None,
     ws = None
     if split_k > 1:
         nbytes = lib.rp_gemm_workspace_bytes(M, N, split_k)
-        ws = torch.empty(nbytes // 4, device=A.device, dtype=torch.float32)
+        ws = _workspace(nbytes, A.device)
         g.workspace, g.workspace_bytes = ws.data_ptr(), nbytes
     g.bias = None if bias is None else bias.data_ptr()
     g.pre_out = None if pre_out is None else pre_out.data_ptr()
@@ -832,7 +861,7 @@ class CrossBlockFn(torch.autograd.Function):
                              x_left=xa if cross else None)
         ctx.single, ctx.cross = single, cross
         g = emm_finalize(fpart, Z)                                     # [Z*70, 224]
-        pf_wp = torch.nn.functional.pad(pf_w, (0, GW - pf_w.shape[1])).contiguous()
+        pf_wp = _padded(pf_w, (0, GW - pf_w.shape[1]))
         f = linear(g, pf_wp, pf_b)                                     # [Z*70, 192]
         y, fn, m2, r2, h, hpre = _mlp_block_fwd(f, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b, train)
         if train:
@@ -872,8 +901,8 @@ def _regress_fwd(feats, gs, w0, b0, w2, b2, w4, b4):
     B = feats.shape[0]
     h1 = linear(feats, w0, b0, act=2)
     h2 = linear(h1, w2, b2, act=2)
-    w4p = torch.nn.functional.pad(w4, (0, 0, 0, 2)).contiguous()    # 14 -> 16 output rows (float4 alignment)
-    b4p = torch.nn.functional.pad(b4, (0, 2)).contiguous()
+    w4p = _padded(w4, (0, 0, 0, 2))                                 # 14 -> 16 output rows (float4 alignment)
+    b4p = _padded(b4, (0, 2))
     pred = linear(h2, w4p, b4p)[:, :14].contiguous()               # [B,14] == [B,2,7]
     gs = gs.contiguous()
     _chk(gs)

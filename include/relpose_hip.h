@@ -131,6 +131,17 @@ int rp_bn_bwd(const float* dy, const float* y, const float* x, const float* mean
 int rp_maxpool3x3s2_fwd(const float* x, float* y, unsigned char* idx, int N, int H, int W, int C, void* stream);
 int rp_maxpool3x3s2_bwd(const float* dy, const unsigned char* idx, float* dx, int N, int H, int W, int C, void* stream);
 
+/* The stem's BatchNorm -> ReLU -> MaxPool2d(3, 2, 1) chain (src/model.py:127-130 on torchvision's resnet.bn1 / relu / maxpool) without
+ * the [N,H,W,C] intermediates.  Forward (after rp_bn_stats, or with the running statistics in eval): y [N,OH,OW,C], idx = window
+ * position (0..8) of the first maximum, bit-identical to rp_bn_apply_fwd(relu) + rp_maxpool3x3s2_fwd.  Backward: dp = gradient of y,
+ * dx = gradient of the BatchNorm input, dgamma / dbeta; equal to rp_maxpool3x3s2_bwd + rp_bn_bwd up to fp32 summation order (the
+ * column sums run window-major over dp, the dx pass gathers the pool gradient on the fly; the pool-backward tensor never exists).  partial: rp_bn_partial_blocks(N*H*W) * 2 * C doubles; c12: 2 * C floats. */
+int rp_bn_relu_pool_fwd(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, float* y,
+                        unsigned char* idx, int N, int H, int W, int C, void* stream);
+int rp_bn_relu_pool_bwd(const float* dp, const unsigned char* idx, const float* x, const float* mean, const float* rstd,
+                        const float* gamma, const float* beta, float* dx, float* dgamma, float* dbeta, double* partial, float* c12,
+                        int N, int H, int W, int C, int training, void* stream);
+
 /* Geodesic pose loss of the training step (reference src/geom/losses.py:3-21; SE(3) arithmetic as restated in
  * rel_pose_amd/se3.py since lietorch is not vendored): Ps, Gs [B,2,7] (t, q xyzw);
  *   losses[0] = mean_{b,j} |tau|, losses[1] = mean_{b,j} |phi| of log(dG_j dP_j^-1), dG_j = G[1-j] G[j]^-1, dP_j likewise;

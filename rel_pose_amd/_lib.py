@@ -76,6 +76,8 @@ _SIGS = {
     "rp_emm_grad_ds": (c_int, [P, I, P, P, P, P, P, P, P, P, I, I, F, I, I, P]),
     "rp_pose_normalize_fwd": (c_int, [P, P, P, I, P]),
     "rp_pose_normalize_bwd": (c_int, [P, P, P, I, P]),
+    "rp_bn_relu_pool_fwd": (c_int, [P, P, P, P, P, P, P, I, I, I, I, P]),
+    "rp_bn_relu_pool_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "rp_event_create": (c_void_p, []),
     "rp_event_destroy": (None, [P]),
     "rp_event_elapsed_ms": (c_float, [P, P]),

@@ -10,6 +10,7 @@
 // Layout: x is [R, C] with R = N*H*W rows and C (multiple of 4, <= 256) contiguous channels -- a channels-last NCHW tensor.
 // Statistics: per-thread fp32 partial sums over <= 64 rows, everything above that in double (block partials and the
 // final combine), so E[x^2] - mean^2 has no cancellation problem at R = 1.6 M rows.
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/relpose_hip.h"
 
@@ -32,14 +33,55 @@ inline int bn_rows_per_block(long long R) {
   return (int)rpb;
 }
 
+// The stem is conv -> BatchNorm -> ReLU -> 3x3/2 max-pool (reference src/model.py:127-130).  Fused ("POOL" instantiations): the
+// incoming gradient of the BatchNorm OUTPUT at input pixel (n, ih, iw) is not read from memory but gathered from the pooled
+// gradient dp [N,OH,OW,C] through the stored window positions (every pixel looks at the <= 4 windows that contain it: exactly
+// maxpool_bwd_kernel's sum, same order), so the [N,H,W,C] pool-backward tensor is never written nor re-read twice.
+struct PoolSrc {
+  const float* dp;
+  const unsigned char* idx;
+  int H, W, OH, OW;
+};
+
+RP_DEV float4 pool_gather(const PoolSrc& ps, unsigned row, int C, int c) {     // row = (n * H + ih) * W + iw (< 2^31), c = first of 4 channels
+  const unsigned t = row / (unsigned)ps.W;                                       // 32-bit index arithmetic: these run per element
+  const int iw = (int)(row - t * (unsigned)ps.W);
+  const unsigned nn = t / (unsigned)ps.H;
+  const int ih = (int)(t - nn * (unsigned)ps.H), n = (int)nn;
+  float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int oh0 = ih >> 1, ow0 = iw >> 1;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int oh = oh0 + a;
+    const int kh = ih - (2 * oh - 1);
+    if (oh >= ps.OH || kh < 0 || kh > 2) continue;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int ow = ow0 + b;
+      const int kw = iw - (2 * ow - 1);
+      if (ow >= ps.OW || kw < 0 || kw > 2) continue;
+      const unsigned o = (((unsigned)n * ps.OH + oh) * ps.OW + ow) * C + c;       // pooled tensor < 2^32 elements (checked by the host)
+      const uchar4 k4 = *reinterpret_cast<const uchar4*>(ps.idx + o);
+      const float4 d = ld4(ps.dp + o);
+      const int k = kh * 3 + kw;
+      if (k4.x == k) g.x += d.x;
+      if (k4.y == k) g.y += d.y;
+      if (k4.z == k) g.z += d.z;
+      if (k4.w == k) g.w += d.w;
+    }
+  }
+  return g;
+}
+
 // stage 1: column sums of (a, b) over this block's rows.  MODE 0: a = x, b = x*x.
 // MODE 1: g = dy * (relu ? y > 0 : 1); a = g, b = g * xhat, xhat = (x - mean) * rstd; optionally stores g.
-template <int MODE>
+template <int MODE, bool POOL = false>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                         const float* __restrict__ y, const float* __restrict__ mean,
                                                         const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* __restrict__ gout,
-                                                        double* __restrict__ partial, long long R, int C, int rpb, int relu) {
+                                                        double* __restrict__ partial, long long R, int C, int rpb, int relu,
+                                                        PoolSrc ps = PoolSrc{}) {
   __shared__ double red[2][256][4];
   const int c4n = C >> 2, nrl = 256 / c4n;
   const int tid = threadIdx.x, cg = tid % c4n, rl = tid / c4n;
@@ -79,7 +121,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
         const long long off = (r + (long long)u * nrl) * C + 4 * cg;
         xv[u] = ld4(x + off);
         if (MODE == 1) {
-          g[u] = ld4(dy + off);
+          g[u] = POOL ? pool_gather(ps, (unsigned)(r + (long long)u * nrl), C, 4 * cg) : ld4(dy + off);
           if (relu && !remask) yv[u] = ld4(y + off);
         }
       }
@@ -104,7 +146,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
       const float4 xv = ld4(x + off);
       float4 g = make_float4(0.f, 0.f, 0.f, 0.f), yv = g;
       if (MODE == 1) {
-        g = ld4(dy + off);
+        g = POOL ? pool_gather(ps, (unsigned)r, C, 4 * cg) : ld4(dy + off);
         if (relu) { yv = remask ? bn_affine(xv, mu, rs, ga, be) : ld4(y + off); g = mask(g, yv); }
         if (gout) st4(gout + off, g);
       }
@@ -200,12 +242,13 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restri
 
 // dx = gamma * rstd * (g - c1 - xhat * c2)   (training);   dx = gamma * rstd * g   (eval: c12 == nullptr)
 // g is read from `g` when given (it was stored by the reduce pass for the residual branch), else recomputed from dy, y
+template <bool POOL = false>
 __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                            const float* __restrict__ gin, const float* __restrict__ x,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ c12, float* __restrict__ dx, long long n4,
-                                                           int c4n, int relu) {
+                                                           int c4n, int relu, PoolSrc ps = PoolSrc{}) {
   const int C = 4 * c4n;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
     const int c = 4 * (int)(i % c4n);
@@ -215,7 +258,7 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float* __restri
     if (gin) {
       g = ld4(gin + 4 * i);
     } else {
-      g = ld4(dy + 4 * i);
+      g = POOL ? pool_gather(ps, (unsigned)i / (unsigned)c4n, C, c) : ld4(dy + 4 * i);
       if (relu) {
         const float4 yv = y ? ld4(y + 4 * i) : bn_affine(xv, mu, rs, ga, ld4(beta + c));
         g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f; g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
@@ -256,8 +299,8 @@ extern "C" int rp_bn_stats(const float* x, long long R, int C, double* partial, 
   if (int e = bn_check(R, C)) return e;
   hipStream_t st = (hipStream_t)stream;
   const int rpb = bn_rows_per_block(R), nblk = (int)((R + rpb - 1) / rpb);
-  hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(nblk), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                     nullptr, partial, R, C, rpb, 0);
+  hipLaunchKernelGGL((bn_reduce_kernel<0, false>), dim3(nblk), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                     nullptr, partial, R, C, rpb, 0, PoolSrc{});
   RP_CHECK_LAUNCH();
   hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3((C + 15) / 16), dim3(256), 0, st, (const double*)partial, nblk, C, R, mean,
                      rstd, running_mean, running_var, momentum, eps, nullptr, x);
@@ -282,15 +325,15 @@ extern "C" int rp_bn_bwd(const float* dy, const float* y, const float* x, const 
   if (relu && !y && !beta) return RP_EBADSHAPE;
   hipStream_t st = (hipStream_t)stream;
   const int rpb = bn_rows_per_block(R), nblk = (int)((R + rpb - 1) / rpb);
-  hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3(nblk), dim3(256), 0, st, x, dy, y, mean, rstd, gamma, beta, dres, partial, R, C, rpb,
-                     relu);
+  hipLaunchKernelGGL((bn_reduce_kernel<1, false>), dim3(nblk), dim3(256), 0, st, x, dy, y, mean, rstd, gamma, beta, dres, partial, R, C, rpb,
+                     relu, PoolSrc{});
   RP_CHECK_LAUNCH();
   hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3((C + 15) / 16), dim3(256), 0, st, (const double*)partial, nblk, C, R, dbeta,
                      dgamma, nullptr, nullptr, 0.f, 0.f, c12, nullptr);
   RP_CHECK_LAUNCH();
   const long long n4 = R * C / 4;
-  hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(apply_grid(n4)), dim3(256), 0, st, dy, y, (const float*)dres, x, mean, rstd, gamma,
-                     beta, training ? (const float*)c12 : nullptr, dx, n4, C / 4, relu);
+  hipLaunchKernelGGL(bn_apply_bwd_kernel<false>, dim3(apply_grid(n4)), dim3(256), 0, st, dy, y, (const float*)dres, x, mean, rstd, gamma,
+                     beta, training ? (const float*)c12 : nullptr, dx, n4, C / 4, relu, PoolSrc{});
   RP_CHECK_LAUNCH();
   return RP_OK;
 }
@@ -389,6 +432,162 @@ extern "C" int rp_maxpool3x3s2_bwd(const float* dy, const unsigned char* idx, fl
   const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
   const long long total = (long long)N * H * W * (C / 4);
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(apply_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, idx, dx, N, H, W, C, OH, OW);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
+
+// ---- stem: BatchNorm + ReLU + 3x3/2 max-pool as one pass (forward) and without the pool-backward tensor (backward) -------------
+namespace {
+
+// pooled[n,oh,ow,c] = max over the window of relu(bn(x)); idx = window position of the FIRST maximum (strict >), i.e. exactly
+// maxpool_fwd_kernel applied to bn_apply_fwd_kernel's output, which is never written
+__global__ __launch_bounds__(256) void bn_pool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ y,
+                                                          unsigned char* __restrict__ idx, int N, int H, int W, int C, int OH, int OW) {
+  const int c4n = C >> 2;
+  const long long total = (long long)N * OH * OW * c4n;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c4 = (int)(i % c4n);
+    long long p = i / c4n;
+    const int ow = (int)(p % OW);
+    p /= OW;
+    const int oh = (int)(p % OH), n = (int)(p / OH);
+    const float4 mu = ld4(mean + 4 * c4), rs = ld4(rstd + 4 * c4), ga = ld4(gamma + 4 * c4), be = ld4(beta + 4 * c4);
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    int kx = 0, ky = 0, kz = 0, kw_ = 0;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int ih = 2 * oh - 1 + kh;
+      if (ih < 0 || ih >= H) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int iw = 2 * ow - 1 + kw;
+        if (iw < 0 || iw >= W) continue;
+        float4 v = bn_affine(ld4(x + (((long long)n * H + ih) * W + iw) * C + 4 * c4), mu, rs, ga, be);
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        const int k = kh * 3 + kw;
+        if (v.x > m.x) { m.x = v.x; kx = k; }
+        if (v.y > m.y) { m.y = v.y; ky = k; }
+        if (v.z > m.z) { m.z = v.z; kz = k; }
+        if (v.w > m.w) { m.w = v.w; kw_ = k; }
+      }
+    }
+    st4(y + 4 * i, m);
+    *reinterpret_cast<uchar4*>(idx + 4 * i) = make_uchar4((unsigned char)kx, (unsigned char)ky, (unsigned char)kz, (unsigned char)kw_);
+  }
+}
+
+// Backward stage 1 of the fused stem, window-major: every pooled element routes its gradient to ONE input pixel (its stored window
+// position), so the column sums  a = sum g,  b = sum g * xhat  over the [N,H,W,C] pixels are sums over the [N,OH,OW,C] windows of
+// dp * [relu active at the arg-max pixel] (* xhat there): a quarter of the iterations of the pixel-major pass and no window search.
+// (Same sums as bn_reduce_kernel<1>, different order: agrees to fp32 rounding, not bitwise.)
+__global__ __launch_bounds__(256) void bn_pool_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dp,
+                                                             const unsigned char* __restrict__ idx, const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, double* __restrict__ partial, long long RO,
+                                                             int C, int rpb, int H, int W, int OH, int OW) {
+  __shared__ double red[2][256][4];
+  const int c4n = C >> 2, nrl = 256 / c4n;
+  const int tid = threadIdx.x, cg = tid % c4n, rl = tid / c4n;
+  const long long r0 = (long long)blockIdx.x * rpb, r1 = min(RO, r0 + rpb);
+  double a0[4] = {0, 0, 0, 0}, b0[4] = {0, 0, 0, 0};
+  if (rl < nrl) {
+    const float4 mu = ld4(mean + 4 * cg), rs = ld4(rstd + 4 * cg), ga = ld4(gamma + 4 * cg), be = ld4(beta + 4 * cg);
+    float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa;
+    int cnt = 0;
+    for (long long r = r0 + rl; r < r1; r += nrl) {
+      const unsigned ur = (unsigned)r;
+      const unsigned t = ur / (unsigned)OW;
+      const int ow = (int)(ur - t * (unsigned)OW);
+      const unsigned nn = t / (unsigned)OH;
+      const int oh = (int)(t - nn * (unsigned)OH);
+      const unsigned o = ur * (unsigned)C + 4 * cg;
+      const float4 d = ld4(dp + o);
+      const uchar4 k4 = *reinterpret_cast<const uchar4*>(idx + o);
+      const float* xb = x + (((long long)nn * H + (2 * oh - 1)) * W + (2 * ow - 1)) * C + 4 * cg;     // window origin (may be off-image;
+      auto at = [&](int k, int e) { return xb[((k / 3) * W + (k % 3)) * C + e]; };                      //  the arg-max never is)
+      const float xv[4] = {at(k4.x, 0), at(k4.y, 1), at(k4.z, 2), at(k4.w, 3)};
+      const float dv[4] = {d.x, d.y, d.z, d.w};
+      const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, rsv[4] = {rs.x, rs.y, rs.z, rs.w}, gav[4] = {ga.x, ga.y, ga.z, ga.w},
+                  bev[4] = {be.x, be.y, be.z, be.w};
+      float* sav = &sa.x;
+      float* sbv = &sb.x;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float yv = __builtin_fmaf(xv[e] - muv[e], rsv[e] * gav[e], bev[e]);      // bn_affine: the forward's value, bit for bit
+        const float g = yv > 0.f ? dv[e] : 0.f;
+        sav[e] += g;
+        sbv[e] += g * (xv[e] - muv[e]) * rsv[e];
+      }
+      if (++cnt >= 64) {
+        a0[0] += sa.x; a0[1] += sa.y; a0[2] += sa.z; a0[3] += sa.w;
+        b0[0] += sb.x; b0[1] += sb.y; b0[2] += sb.z; b0[3] += sb.w;
+        sa = make_float4(0.f, 0.f, 0.f, 0.f); sb = sa; cnt = 0;
+      }
+    }
+    a0[0] += sa.x; a0[1] += sa.y; a0[2] += sa.z; a0[3] += sa.w;
+    b0[0] += sb.x; b0[1] += sb.y; b0[2] += sb.z; b0[3] += sb.w;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { red[0][tid][e] = a0[e]; red[1][tid][e] = b0[e]; }
+  __syncthreads();
+  if (tid < c4n) {
+    for (int l = 1; l < nrl; ++l)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { a0[e] += red[0][tid + l * c4n][e]; b0[e] += red[1][tid + l * c4n][e]; }
+    double* p = partial + (long long)blockIdx.x * 2 * C;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { p[4 * cg + e] = a0[e]; p[C + 4 * cg + e] = b0[e]; }
+  }
+}
+
+}  // namespace
+
+extern "C" int rp_bn_relu_pool_fwd(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                   float* y, unsigned char* idx, int N, int H, int W, int C, void* stream) {
+  if (N <= 0 || H <= 0 || W <= 0) return RP_EBADSHAPE;
+  if (int e = bn_check((long long)N * H * W, C)) return e;
+  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  const long long total = (long long)N * OH * OW * (C / 4);
+  hipLaunchKernelGGL(bn_pool_fwd_kernel, dim3(apply_grid(total)), dim3(256), 0, (hipStream_t)stream, x, mean, rstd, gamma, beta, y,
+                     idx, N, H, W, C, OH, OW);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
+// backward of the same chain: dp = gradient of the pooled output [N,OH,OW,C]; dx = gradient of the BatchNorm INPUT [N,H,W,C]
+extern "C" int rp_bn_relu_pool_bwd(const float* dp, const unsigned char* idx, const float* x, const float* mean, const float* rstd,
+                                   const float* gamma, const float* beta, float* dx, float* dgamma, float* dbeta, double* partial,
+                                   float* c12, int N, int H, int W, int C, int training, void* stream) {
+  if (N <= 0 || H <= 0 || W <= 0 || !dp || !idx || !beta) return RP_EBADSHAPE;
+  const long long R = (long long)N * H * W;
+  if (int e = bn_check(R, C)) return e;
+  if (R * C >= (1LL << 32)) return RP_EBADSHAPE;                     // 32-bit element indices in the gather
+  hipStream_t st = (hipStream_t)stream;
+  const PoolSrc ps{dp, idx, H, W, (H - 1) / 2 + 1, (W - 1) / 2 + 1};
+  int nblk;
+  static const bool pixel_major = getenv("RP_BN_POOL_PIXEL_MAJOR") != nullptr;     // A/B aid: the bit-identical pixel-major stage 1
+  if (pixel_major) {
+    const int rpb = bn_rows_per_block(R);
+    nblk = (int)((R + rpb - 1) / rpb);
+    hipLaunchKernelGGL((bn_reduce_kernel<1, true>), dim3(nblk), dim3(256), 0, st, x, nullptr, nullptr, mean, rstd, gamma, beta, nullptr,
+                       partial, R, C, rpb, 1, ps);
+  } else {
+    const long long RO = (long long)N * ps.OH * ps.OW;
+    const int rpb = bn_rows_per_block(RO);
+    nblk = (int)((RO + rpb - 1) / rpb);                                            // <= the buffer sized for R rows
+    hipLaunchKernelGGL(bn_pool_reduce_kernel, dim3(nblk), dim3(256), 0, st, x, dp, idx, mean, rstd, gamma, beta, partial, RO, C, rpb,
+                       H, W, ps.OH, ps.OW);
+  }
+  RP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3((C + 15) / 16), dim3(256), 0, st, (const double*)partial, nblk, C, R, dbeta,
+                     dgamma, nullptr, nullptr, 0.f, 0.f, c12, nullptr);
+  RP_CHECK_LAUNCH();
+  const long long n4 = R * C / 4;
+  hipLaunchKernelGGL(bn_apply_bwd_kernel<true>, dim3(apply_grid(n4)), dim3(256), 0, st, nullptr, nullptr, nullptr, x, mean, rstd,
+                     gamma, beta, training ? (const float*)c12 : nullptr, dx, n4, C / 4, 1, ps);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }

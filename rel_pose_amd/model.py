@@ -92,7 +92,7 @@ class ViTEss(nn.Module):
             intrinsics = self.update_intrinsics(images.shape, intrinsics)
         x = ops.preprocess(images)       # BGR->RGB, /255, mean/std, nearest 224: one bit-exact HIP kernel, channels-last out
         r = self.resnet
-        x = ops.maxpool3x3s2(r.maxpool, ops.bn_act(r.bn1, ops.conv2d(r.conv1, x)))
+        x = ops.bn_relu_maxpool(r.bn1, r.maxpool, ops.conv2d(r.conv1, x))      # stem: BatchNorm + ReLU + pool, one pass each way
         x = r.layer2(r.layer1(x))
         return self.extractor_final_conv(x), intrinsics
 

@@ -1149,6 +1149,67 @@ class MaxPool3x3s2Fn(torch.autograd.Function):
         return dx.permute(0, 3, 1, 2)
 
 
+FUSE_STEM_POOL = os.environ.get("RP_FUSE_STEM_POOL", "1") != "0"
+
+
+class BnReluPoolFn(torch.autograd.Function):
+    """maxpool3x3s2(relu(batch_norm(x))) of the stem (reference src/model.py:127-130) without the two [N,112,112,64] intermediates:
+    statistics pass, then ONE pass that normalises, clamps and pools; the backward gathers the pool gradient inside both
+    BatchNorm-backward passes.  Bit-identical to BnActFn + MaxPool3x3s2Fn (csrc/batchnorm.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps):
+        lib = _lib.load()
+        N, C, H, W = x.shape
+        xr = x.permute(0, 2, 3, 1)
+        if not xr.is_contiguous():
+            xr = xr.contiguous()
+        _chk(xr, gamma, beta)
+        R = N * H * W
+        if training:
+            mean, rstd = _empty(C, like=xr), _empty(C, like=xr)
+            part = torch.empty(lib.rp_bn_partial_blocks(R) * 2 * C, device=x.device, dtype=torch.float64)
+            _lib.check(lib.rp_bn_stats(_p(xr), R, C, _p(part), _p(mean), _p(rstd), _p(running_mean), _p(running_var),
+                                       float(momentum), float(eps), _st()), "rp_bn_stats")
+        else:
+            mean, rstd = running_mean, torch.rsqrt(running_var + eps)
+        OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = torch.empty(N, OH, OW, C, device=x.device, dtype=torch.float32)
+        idx = torch.empty(N, OH, OW, C, device=x.device, dtype=torch.uint8)
+        _lib.check(lib.rp_bn_relu_pool_fwd(_p(xr), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(y), ctypes.c_void_p(idx.data_ptr()),
+                                           N, H, W, C, _st()), "rp_bn_relu_pool_fwd")
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(xr, idx, mean, rstd, gamma, beta)
+            ctx.cfg = (N, C, H, W, bool(training))
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        xr, idx, mean, rstd, gamma, beta = ctx.saved_tensors
+        N, C, H, W, training = ctx.cfg
+        dyr = dy.permute(0, 2, 3, 1)
+        if not dyr.is_contiguous():
+            dyr = dyr.contiguous()
+        _chk(dyr)
+        dx = torch.empty_like(xr)
+        dgamma, dbeta, c12 = _empty(C, like=xr), _empty(C, like=xr), _empty(2 * C, like=xr)
+        part = torch.empty(lib.rp_bn_partial_blocks(N * H * W) * 2 * C, device=xr.device, dtype=torch.float64)
+        _lib.check(lib.rp_bn_relu_pool_bwd(_p(dyr), ctypes.c_void_p(idx.data_ptr()), _p(xr), _p(mean), _p(rstd), _p(gamma), _p(beta),
+                                           _p(dx), _p(dgamma), _p(dbeta), _p(part), _p(c12), N, H, W, C, 1 if training else 0, _st()),
+                   "rp_bn_relu_pool_bwd")
+        return dx.permute(0, 3, 1, 2), dgamma, dbeta, None, None, None, None, None
+
+
+def bn_relu_maxpool(bn, pool, x):
+    """pool(relu(bn(x))) for the stem (nn.BatchNorm2d `bn`, nn.MaxPool2d(3, 2, 1) `pool`)."""
+    if not x.is_cuda or not FUSE_STEM_POOL:
+        return maxpool3x3s2(pool, bn_act(bn, x))
+    if bn.training and bn.track_running_stats:
+        bn.num_batches_tracked += 1
+    return BnReluPoolFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.momentum, bn.eps)
+
+
 def maxpool3x3s2(pool, x):
     """the stem's nn.MaxPool2d(3, 2, 1): HIP kernels on the GPU, the module itself on CPU tensors (fixture generation only)"""
     if not x.is_cuda:

@@ -768,3 +768,50 @@ def test_row_resident_input_gradient_with_gelu_grad_and_column_sums(ops, M):
              proj_dx=rel(ops.linear_dx(dy, wp), dy.double() @ wp.double()))
     report("linear_rows_dx_M%d" % M, **e)
     assert max(e.values()) < 3e-6, e
+
+
+@pytest.mark.parametrize("shape,training", [((6, 64, 112, 112), True), ((3, 8, 9, 11), True), ((2, 16, 10, 7), False)])
+def test_fused_stem_batchnorm_relu_maxpool_is_bit_identical_to_the_separate_kernels(ops, shape, training):
+    """ops.bn_relu_maxpool (rp_bn_relu_pool_fwd / _bwd: the stem's bn1 -> relu -> maxpool, src/model.py:127-130, without the
+    full-resolution intermediates) against BnActFn + MaxPool3x3s2Fn: outputs, window positions and running statistics bit-identical
+    (same arithmetic), gradients equal to 2e-6 (the fused backward sums window-major; bit-identical in eval mode, where no sums
+    enter dx), odd sizes included; and against torch.nn in fp64 (2e-6)."""
+    import copy
+    N, C, H, W = shape
+    torch.manual_seed(3)
+    bn = torch.nn.BatchNorm2d(C).cuda()
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.3 * torch.randn(C))
+        bn.weight[0] = -0.7                                     # a negative scale: relu(bn(.)) is not monotone in x there
+        bn.bias.copy_(0.2 * torch.randn(C))
+        bn.running_mean.copy_(0.1 * torch.randn(C)); bn.running_var.copy_(0.5 + torch.rand(C))
+    bn.train(training)
+    pool = torch.nn.MaxPool2d(3, 2, 1)
+    x0 = (torch.randn(N, C, H, W, device="cuda") * 1.5 + 0.3).contiguous(memory_format=torch.channels_last)
+    x0[0, :, :4, :4] = 0.25                                     # ties inside windows
+    cot = None
+    res = []
+    for fused in (True, False):
+        b = copy.deepcopy(bn)
+        x = x0.clone().requires_grad_(True)
+        prev, ops.FUSE_STEM_POOL = ops.FUSE_STEM_POOL, fused
+        try:
+            y = ops.bn_relu_maxpool(b, pool, x)
+        finally:
+            ops.FUSE_STEM_POOL = prev
+        if cot is None:
+            cot = torch.randn_like(y)
+        y.backward(cot)
+        res.append((y.detach(), x.grad, b.weight.grad, b.bias.grad, b.running_mean.clone(), b.running_var.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][4], res[1][4]) and torch.equal(res[0][5], res[1][5])
+    for a, bb in zip(res[0][1:4], res[1][1:4]):
+        assert rel(a, bb) < 2e-6
+    if not training:
+        assert torch.equal(res[0][1], res[1][1])
+    b64 = copy.deepcopy(bn).double()
+    x64 = x0.double().requires_grad_(True)
+    y64 = pool(torch.relu(b64(x64)))
+    y64.backward(cot.double())
+    e = dict(y=rel(res[0][0], y64), dx=rel(res[0][1], x64.grad), dgamma=rel(res[0][2], b64.weight.grad), dbeta=rel(res[0][3], b64.bias.grad))
+    report("bn_relu_maxpool_%dx%dx%dx%d" % shape, **e)
+    assert max(e.values()) < 2e-6, e

@@ -5,7 +5,8 @@ mkdir -p gpurun_out
 B="python bench.py --no-cpu-baseline"
 $B --steps 300 --warmup 5 2>/dev/null | tail -1 > gpurun_out/pt_soak300.json
 $B --steps 30 --warmup 5 --batch 128 2>/dev/null | tail -1 > gpurun_out/pt_fp32_128pairs.json
-$B --steps 30 --warmup 5 --batch 128 --precision bf16 2>/dev/null | tail -1 > gpurun_out/pt_bf16_128pairs.json
+$B --steps 100 --warmup 10 --batch 128 --precision bf16 2>/dev/null | tail -1 > gpurun_out/pt_bf16_128pairs.json
+$B --steps 100 --warmup 10 --batch 64 --precision bf16 2>/dev/null | tail -1 > gpurun_out/pt_bf16_64pairs.json
 $B --steps 40 --warmup 5 --precision split3 2>/dev/null | tail -1 > gpurun_out/pt_split3.json
 $B --steps 40 --warmup 5 --mode fwd 2>/dev/null | tail -1 > gpurun_out/pt_fwd_only.json
 RP_FUSE_MLP=0 RP_ROWS_LINEAR=0 $B --steps 40 --warmup 5 --mode fwd 2>/dev/null | tail -1 > gpurun_out/pt_fwd_only_round1_kernels.json

@@ -119,6 +119,8 @@ size_t rp_gemm_workspace_bytes(int M, int N, int split_k);
 int rp_bn_partial_blocks(long long R);
 int rp_bn_stats(const float* x, long long R, int C, double* partial, float* mean, float* rstd, float* running_mean,
                 float* running_var, float momentum, float eps, void* stream);
+int rp_bn_stats_from_partials(const double* partial, int nblk, long long R, int C, const float* pivot, float* mean, float* rstd,
+                              float* running_mean, float* running_var, float momentum, float eps, void* stream);
 int rp_bn_apply_fwd(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                     const float* residual, float* y, long long R, int C, int relu, void* stream);
 int rp_bn_bwd(const float* dy, const float* y, const float* x, const float* mean, const float* rstd, const float* gamma,
@@ -130,6 +132,15 @@ int rp_bn_bwd(const float* dy, const float* y, const float* x, const float* mean
  * order (PyTorch's tie rule); backward gathers dy through idx into dx [N,H,W,C] (no atomics). */
 int rp_maxpool3x3s2_fwd(const float* x, float* y, unsigned char* idx, int N, int H, int W, int C, void* stream);
 int rp_maxpool3x3s2_bwd(const float* dy, const unsigned char* idx, float* dx, int N, int H, int W, int C, void* stream);
+
+/* The stem convolution (torchvision resnet.conv1: 7x7, stride 2, pad 3, 3 -> 64, no bias; src/model.py:127), forward, hand-written
+ * implicit GEMM (csrc/conv_stem.hip).  x_padded [N, H+6, W+6, 3]: the channels-last image inside a 3-pixel zero frame; w [64,7,7,3]
+ * (the memory of a channels-last nn.Conv2d weight); y [N, (H-1)/2+1, (W-1)/2+1, 64].  W must be even (the pad taps of the last
+ * window stay inside its row).  stats (optional) [rp_conv_stem_blocks(N,H,W)][2][64] doubles: per-workgroup sums of y and y^2 per
+ * channel -- the following BatchNorm's batch statistics without a pass over y: rp_bn_stats_from_partials(stats, blocks, N*OH*OW, 64,
+ * zeros, ...) finishes them (any partial sums of (x - pivot), (x - pivot)^2 over disjoint row sets are accepted). */
+int rp_conv_stem_blocks(int N, int H, int W);
+int rp_conv_stem_fwd(const float* x_padded, const float* w, float* y, double* stats, int N, int H, int W, void* stream);
 
 /* The stem's BatchNorm -> ReLU -> MaxPool2d(3, 2, 1) chain (src/model.py:127-130 on torchvision's resnet.bn1 / relu / maxpool) without
  * the [N,H,W,C] intermediates.  Forward (after rp_bn_stats, or with the running statistics in eval): y [N,OH,OW,C], idx = window
@@ -179,6 +190,8 @@ int rp_colsum_multi(const RpColsumTask* tasks, int n, float* workspace, size_t w
 /* Image preprocessing (reference src/model.py:115-118,124-125; bit-exact): BGR->RGB, /255, ImageNet mean/std, nearest
  * resize to 224x224.  images [Z,3,H,W] fp32 0..255 -> out: channels-last memory [Z,224,224,3] of a [Z,3,224,224] tensor. */
 int rp_preprocess(const float* images, float* out, int Z, int H, int W, void* stream);
+/* same, written inside a `pad`-pixel zero frame: out [Z, 224 + 2 pad, 224 + 2 pad, 3] (pad = 3: the input rp_conv_stem_fwd takes) */
+int rp_preprocess_padded(const float* images, float* out, int Z, int H, int W, int pad, void* stream);
 
 /* Token layout + learned position embedding: x[z][n][c] = feat[z][c][n] + pos_embed[n][c]
  * (reference src/model.py:136-141,170-171; index part bit-exact).  feat is the CNN map [Z,C,N]. */

@@ -76,6 +76,10 @@ _SIGS = {
     "rp_emm_grad_ds": (c_int, [P, I, P, P, P, P, P, P, P, P, I, I, F, I, I, P]),
     "rp_pose_normalize_fwd": (c_int, [P, P, P, I, P]),
     "rp_pose_normalize_bwd": (c_int, [P, P, P, I, P]),
+    "rp_preprocess_padded": (c_int, [P, P, I, I, I, I, P]),
+    "rp_conv_stem_blocks": (c_int, [I, I, I]),
+    "rp_conv_stem_fwd": (c_int, [P, P, P, P, I, I, I, P]),
+    "rp_bn_stats_from_partials": (c_int, [P, I, L, I, P, P, P, P, P, F, F, P]),
     "rp_bn_relu_pool_fwd": (c_int, [P, P, P, P, P, P, P, I, I, I, I, P]),
     "rp_bn_relu_pool_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "rp_event_create": (c_void_p, []),

@@ -308,6 +308,19 @@ extern "C" int rp_bn_stats(const float* x, long long R, int C, double* partial, 
   return RP_OK;
 }
 
+// statistics from per-block partial sums produced elsewhere (rp_conv_stem_fwd's epilogue): partial [nblk][2][C] doubles =
+// sums of (x - pivot[c]) and (x - pivot[c])^2 over disjoint row sets covering all R rows
+extern "C" int rp_bn_stats_from_partials(const double* partial, int nblk, long long R, int C, const float* pivot, float* mean,
+                                         float* rstd, float* running_mean, float* running_var, float momentum, float eps,
+                                         void* stream) {
+  if (int e = bn_check(R, C)) return e;
+  if (nblk <= 0 || !partial || !pivot) return RP_EBADSHAPE;
+  hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, partial, nblk, C, R, mean, rstd,
+                     running_mean, running_var, momentum, eps, nullptr, pivot);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
 extern "C" int rp_bn_apply_fwd(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                                const float* residual, float* y, long long R, int C, int relu, void* stream) {
   if (int e = bn_check(R, C)) return e;

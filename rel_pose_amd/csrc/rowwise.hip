@@ -308,12 +308,20 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict
 // Same fp32 operation order as the reference (src/model.py:115-118,124-125): v/255, -mean, /std; nearest source index
 // floor(dst * (in/out)) in fp32 (PyTorch "nearest").  Resize and normalisation commute exactly (both are per-pixel), so
 // gathering first touches 224^2 of the H*W pixels.
+// pad > 0: the 224 x 224 result sits inside a `pad`-pixel zero frame (the stem convolution's padding, csrc/conv_stem.hip)
 __global__ __launch_bounds__(256) void preprocess_kernel(const float* __restrict__ img, float* __restrict__ out, int H, int W,
-                                                         float sy, float sx, long long total) {
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;   // over Z*224*224 output pixels
+                                                         float sy, float sx, long long total, int pad) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;   // over Z * (224 + 2 pad)^2 output pixels
   if (idx >= total) return;
-  const int x = (int)(idx % 224), y = (int)((idx / 224) % 224);
-  const long long z = idx / (224 * 224);
+  const int side = 224 + 2 * pad;
+  const int xp = (int)(idx % side), yp = (int)((idx / side) % side);
+  const long long z = idx / ((long long)side * side);
+  const int x = xp - pad, y = yp - pad;
+  if (x < 0 || x >= 224 || y < 0 || y >= 224) {
+    float* o = out + idx * 3;
+    o[0] = 0.f; o[1] = 0.f; o[2] = 0.f;
+    return;
+  }
   const int iy = min((int)floorf((float)y * sy), H - 1), ix = min((int)floorf((float)x * sx), W - 1);
   const float* p = img + (z * 3) * (long long)H * W + (long long)iy * W + ix;
   const float b = p[0], g = p[(long long)H * W], r = p[2 * (long long)H * W];
@@ -594,13 +602,17 @@ extern "C" int rp_attn_bwd_delta(const float* dout, const float* o, float* delta
   return RP_OK;
 }
 
-extern "C" int rp_preprocess(const float* images, float* out, int Z, int H, int W, void* stream) {
-  if (Z <= 0 || H <= 0 || W <= 0) return RP_EBADSHAPE;
-  const long long total = (long long)Z * 224 * 224;
+extern "C" int rp_preprocess_padded(const float* images, float* out, int Z, int H, int W, int pad, void* stream) {
+  if (Z <= 0 || H <= 0 || W <= 0 || pad < 0 || pad > 16) return RP_EBADSHAPE;
+  const long long total = (long long)Z * (224 + 2 * pad) * (224 + 2 * pad);
   hipLaunchKernelGGL(preprocess_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, images,
-                     out, H, W, (float)H / 224.0f, (float)W / 224.0f, total);
+                     out, H, W, (float)H / 224.0f, (float)W / 224.0f, total, pad);
   RP_CHECK_LAUNCH();
   return RP_OK;
+}
+
+extern "C" int rp_preprocess(const float* images, float* out, int Z, int H, int W, void* stream) {
+  return rp_preprocess_padded(images, out, Z, H, W, 0, stream);
 }
 
 extern "C" int rp_pose_normalize_fwd(const float* pred, const float* gs, float* out, int B, void* stream) {

@@ -90,9 +90,18 @@ class ViTEss(nn.Module):
         """preprocessing + CNN front-end -> [2B,192,24,24] (PyTorch-ROCm / MIOpen: 'next' row 8f-1)."""
         if intrinsics is not None:
             intrinsics = self.update_intrinsics(images.shape, intrinsics)
-        x = ops.preprocess(images)       # BGR->RGB, /255, mean/std, nearest 224: one bit-exact HIP kernel, channels-last out
         r = self.resnet
-        x = ops.bn_relu_maxpool(r.bn1, r.maxpool, ops.conv2d(r.conv1, x))      # stem: BatchNorm + ReLU + pool, one pass each way
+        if ops.stem_conv_ok(r.conv1, images):
+            # BGR->RGB, /255, mean/std, nearest 224 (one bit-exact HIP kernel) written inside the stem's zero padding; hand-written conv1
+            # (in training also bn1's batch statistics, from the convolution's epilogue)
+            stats = None
+            if r.bn1.training and ops.STEM_STATS and ops.FUSE_STEM_POOL:
+                c1, stats = ops.StemConvFn.apply(ops.preprocess(images, pad=3), r.conv1.weight, True)
+            else:
+                c1 = ops.StemConvFn.apply(ops.preprocess(images, pad=3), r.conv1.weight)
+        else:
+            c1, stats = ops.conv2d(r.conv1, ops.preprocess(images)), None
+        x = ops.bn_relu_maxpool(r.bn1, r.maxpool, c1, stats)                    # stem: BatchNorm + ReLU + pool, one pass each way
         x = r.layer2(r.layer1(x))
         return self.extractor_final_conv(x), intrinsics
 

@@ -519,16 +519,18 @@ def attn_bwd(qkv, o, lse, do, Z, fork=None, kv_xor=0):
     return dqkv
 
 
-def preprocess(images):
-    """[B,2,3,H,W] BGR 0..255 -> [2B,3,224,224] RGB normalised, channels-last (src/model.py:115-118,124-125)."""
+def preprocess(images, pad=0):
+    """[B,2,3,H,W] BGR 0..255 -> [2B,3,224,224] RGB normalised, channels-last (src/model.py:115-118,124-125).
+    pad > 0: the NHWC buffer [2B, 224+2pad, 224+2pad, 3] with the result inside a zero frame (input of conv_stem_fwd)."""
     lib = _lib.load()
     images = images.contiguous()
     _chk(images)
     B, two, C, H, W = images.shape
     Z = B * two
-    out = torch.empty(Z, 224, 224, 3, device=images.device, dtype=torch.float32)
-    _lib.check(lib.rp_preprocess(_p(images), _p(out), Z, H, W, _st()), "rp_preprocess")
-    return out.permute(0, 3, 1, 2)          # [Z,3,224,224] view with channels-last strides
+    side = 224 + 2 * pad
+    out = torch.empty(Z, side, side, 3, device=images.device, dtype=torch.float32)
+    _lib.check(lib.rp_preprocess_padded(_p(images), _p(out), Z, H, W, pad, _st()), "rp_preprocess_padded")
+    return out if pad else out.permute(0, 3, 1, 2)          # pad = 0: [Z,3,224,224] view with channels-last strides
 
 
 _LIN24 = {}
@@ -1149,6 +1151,57 @@ class MaxPool3x3s2Fn(torch.autograd.Function):
         return dx.permute(0, 3, 1, 2)
 
 
+def conv_stem_fwd(x_padded_nhwc, w, want_stats=False):
+    """rp_conv_stem_fwd: x_padded [N,H+6,W+6,3] (3-pixel zero frame), w = conv1.weight [64,3,7,7] in channels-last memory ->
+    y [N,OH,OW,64] (NHWC memory) [, stats partials [blocks,2,64] float64: per-workgroup sums of y and y^2]."""
+    lib = _lib.load()
+    wr = w.permute(0, 2, 3, 1)
+    if not wr.is_contiguous():
+        wr = wr.contiguous()
+    _chk(x_padded_nhwc, wr)
+    N, Hp, Wp, _ = x_padded_nhwc.shape
+    H, W = Hp - 6, Wp - 6
+    y = torch.empty(N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 64, device=w.device, dtype=torch.float32)
+    stats = torch.empty(lib.rp_conv_stem_blocks(N, H, W), 2, 64, device=w.device, dtype=torch.float64) if want_stats else None
+    _lib.check(lib.rp_conv_stem_fwd(_p(x_padded_nhwc), _p(wr), _p(y), _p(stats), N, H, W, _st()), "rp_conv_stem_fwd")
+    return (y, stats) if want_stats else y
+
+
+STEM_CONV = os.environ.get("RP_STEM_CONV", "1") != "0"      # hand-written stem convolution forward (exact fp32 front-end only)
+STEM_STATS = os.environ.get("RP_STEM_STATS", "1") != "0"    # ... with the BatchNorm batch statistics from its epilogue
+
+
+class StemConvFn(torch.autograd.Function):
+    """resnet.conv1 (7x7 / 2, pad 3, 3 -> 64, no bias; src/model.py:127) on the zero-framed NHWC image: forward = csrc/conv_stem.hip;
+    weight gradient = MIOpen's backward-weights on the same framed buffer (padding 0 there: identical arithmetic); the image itself
+    needs no gradient."""
+
+    @staticmethod
+    def forward(ctx, xp, w, want_stats=False):
+        """-> y (channels-last [N,64,OH,OW]) [, stats partials of y for the BatchNorm that follows (not differentiable)]"""
+        ctx.save_for_backward(xp, w)
+        if want_stats:
+            y, stats = conv_stem_fwd(xp, w, want_stats=True)
+            ctx.mark_non_differentiable(stats)
+            return y.permute(0, 3, 1, 2), stats
+        return conv_stem_fwd(xp, w).permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dy, *_):
+        xp, w = ctx.saved_tensors
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dy = dy.contiguous(memory_format=torch.channels_last)
+            dw = torch.ops.aten.convolution_backward(dy, xp.permute(0, 3, 1, 2), w, None, [2, 2], [0, 0], [1, 1], False, [0, 0], 1,
+                                                     [False, True, False])[1]
+        return None, dw, None
+
+
+def stem_conv_ok(conv, images):
+    return (STEM_CONV and CNN_PRECISION == 0 and images.is_cuda and tuple(conv.weight.shape) == (64, 3, 7, 7) and conv.bias is None
+            and conv.stride == (2, 2) and conv.padding == (3, 3))
+
+
 FUSE_STEM_POOL = os.environ.get("RP_FUSE_STEM_POOL", "1") != "0"
 
 
@@ -1158,7 +1211,9 @@ class BnReluPoolFn(torch.autograd.Function):
     BatchNorm-backward passes.  Bit-identical to BnActFn + MaxPool3x3s2Fn (csrc/batchnorm.hip)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, stats=None):
+        """stats: sums of x and x^2 per producing workgroup [blocks,2,C] float64 (from the stem convolution's epilogue) -- then the
+        statistics pass over x is skipped"""
         lib = _lib.load()
         N, C, H, W = x.shape
         xr = x.permute(0, 2, 3, 1)
@@ -1166,7 +1221,12 @@ class BnReluPoolFn(torch.autograd.Function):
             xr = xr.contiguous()
         _chk(xr, gamma, beta)
         R = N * H * W
-        if training:
+        if training and stats is not None:
+            mean, rstd = _empty(C, like=xr), _empty(C, like=xr)
+            _lib.check(lib.rp_bn_stats_from_partials(_p(stats), stats.shape[0], R, C, _p(_zeros(C, xr.device)), _p(mean), _p(rstd),
+                                                     _p(running_mean), _p(running_var), float(momentum), float(eps), _st()),
+                       "rp_bn_stats_from_partials")
+        elif training:
             mean, rstd = _empty(C, like=xr), _empty(C, like=xr)
             part = torch.empty(lib.rp_bn_partial_blocks(R) * 2 * C, device=x.device, dtype=torch.float64)
             _lib.check(lib.rp_bn_stats(_p(xr), R, C, _p(part), _p(mean), _p(rstd), _p(running_mean), _p(running_var),
@@ -1198,16 +1258,26 @@ class BnReluPoolFn(torch.autograd.Function):
         _lib.check(lib.rp_bn_relu_pool_bwd(_p(dyr), ctypes.c_void_p(idx.data_ptr()), _p(xr), _p(mean), _p(rstd), _p(gamma), _p(beta),
                                            _p(dx), _p(dgamma), _p(dbeta), _p(part), _p(c12), N, H, W, C, 1 if training else 0, _st()),
                    "rp_bn_relu_pool_bwd")
-        return dx.permute(0, 3, 1, 2), dgamma, dbeta, None, None, None, None, None
+        return dx.permute(0, 3, 1, 2), dgamma, dbeta, None, None, None, None, None, None
 
 
-def bn_relu_maxpool(bn, pool, x):
-    """pool(relu(bn(x))) for the stem (nn.BatchNorm2d `bn`, nn.MaxPool2d(3, 2, 1) `pool`)."""
+_ZEROS = {}
+
+
+def _zeros(n, device):
+    key = (device, n)
+    if key not in _ZEROS:
+        _ZEROS[key] = torch.zeros(n, device=device, dtype=torch.float32)
+    return _ZEROS[key]
+
+
+def bn_relu_maxpool(bn, pool, x, stats=None):
+    """pool(relu(bn(x))) for the stem (nn.BatchNorm2d `bn`, nn.MaxPool2d(3, 2, 1) `pool`); stats: see BnReluPoolFn."""
     if not x.is_cuda or not FUSE_STEM_POOL:
         return maxpool3x3s2(pool, bn_act(bn, x))
     if bn.training and bn.track_running_stats:
         bn.num_batches_tracked += 1
-    return BnReluPoolFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.momentum, bn.eps)
+    return BnReluPoolFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.momentum, bn.eps, stats)
 
 
 def maxpool3x3s2(pool, x):

@@ -815,3 +815,34 @@ def test_fused_stem_batchnorm_relu_maxpool_is_bit_identical_to_the_separate_kern
     e = dict(y=rel(res[0][0], y64), dx=rel(res[0][1], x64.grad), dgamma=rel(res[0][2], b64.weight.grad), dbeta=rel(res[0][3], b64.bias.grad))
     report("bn_relu_maxpool_%dx%dx%dx%d" % shape, **e)
     assert max(e.values()) < 2e-6, e
+
+
+@pytest.mark.parametrize("N,H,W", [(4, 224, 224), (2, 64, 96), (1, 32, 32)])
+def test_hand_written_stem_convolution(ops, N, H, W):
+    """rp_conv_stem_fwd (resnet.conv1: 7x7 / 2, pad 3, 3 -> 64; src/model.py:127) on the zero-framed channels-last image against fp64
+    F.conv2d (2e-6 of the maximum; MIOpen's own fp32 result is at 7e-7), its BatchNorm-statistics partials against the sums of the
+    output, the framed preprocessing kernel against the plain one (bit-exact interior, zero frame), and the weight gradient of
+    StemConvFn against autograd's."""
+    import torch.nn.functional as F
+    torch.manual_seed(5)
+    x = torch.randn(N, 3, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(64, 3, 7, 7, device="cuda") * 0.05).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    xp = F.pad(x.permute(0, 2, 3, 1), (0, 0, 3, 3, 3, 3)).contiguous()
+    y, stats = ops.conv_stem_fwd(xp, w.detach(), want_stats=True)
+    ref = F.conv2d(x.double(), w.detach().double(), None, 2, 3).permute(0, 2, 3, 1)
+    e = dict(y=rel(y, ref), sum=rel(stats[:, 0].sum(0), ref.sum((0, 1, 2))), sumsq=rel(stats[:, 1].sum(0), (ref * ref).sum((0, 1, 2))))
+    assert torch.equal(ops.conv_stem_fwd(xp, w.detach()), y)
+    out = ops.StemConvFn.apply(xp, w)
+    cot = torch.randn_like(out)
+    out.backward(cot)
+    wd = w.detach().double().requires_grad_(True)
+    F.conv2d(x.double(), wd, None, 2, 3).backward(cot.double())
+    e["dw"] = rel(w.grad, wd.grad)
+    report("conv_stem_%dx%dx%d" % (N, H, W), **e)
+    assert max(e.values()) < 2e-6, e
+    if (H, W) == (224, 224):
+        imgs = torch.floor(torch.rand(2, 2, 3, 96, 128, device="cuda") * 255)
+        plain, framed = ops.preprocess(imgs), ops.preprocess(imgs, pad=3)
+        assert torch.equal(framed[:, 3:-3, 3:-3, :], plain.permute(0, 2, 3, 1))
+        framed[:, 3:-3, 3:-3, :] = 0
+        assert float(framed.abs().max()) == 0.0

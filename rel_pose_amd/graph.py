@@ -35,7 +35,11 @@ class GraphedTrainStep:
         self.flat = torch.zeros(n, device=images.device, dtype=torch.float32)
         o = 0
         for p in self.params:
-            p.grad = self.flat[o:o + p.numel()].view_as(p)
+            # same memory format as the parameter (the CNN's convolution weights are channels-last): autograd then writes the
+            # gradient in place instead of converting it ("gradient layout contract")
+            chunk = self.flat[o:o + p.numel()]
+            p.grad = chunk.as_strided(p.shape, p.stride()) if p.is_contiguous(memory_format=torch.channels_last) and p.dim() == 4 \
+                else chunk.view_as(p)
             o += p.numel()
         self.loss = torch.zeros((), device=images.device)
         self.gA = self.gB = None

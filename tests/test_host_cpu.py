@@ -324,3 +324,24 @@ def test_branch_free_gelu_constants_are_accurate():
     pdf = (np.float32(0.39894228040143267794) * np.exp2((np.float32(-0.72134752044448170368) * x * x).astype(np.float32))).astype(np.float32)
     grad = (x * pdf + cdf).astype(np.float64)
     assert np.abs(grad - (phi + xd * np.exp(-0.5 * xd * xd) / np.sqrt(2 * np.pi))).max() < 5e-7
+
+
+def test_padded_weight_cache_follows_in_place_updates():
+    """ops._padded caches the alignment pads of the CrossBlock / regressor weights between forwards; an optimizer step, load_state_dict
+    or any other in-place write (Tensor._version) and a re-pointed .data must invalidate it."""
+    from rel_pose_amd import ops
+    w = torch.nn.Parameter(torch.arange(12.0).view(3, 4))
+    a = ops._padded(w, (0, 2))
+    assert a.shape == (3, 6) and torch.equal(a[:, :4], w.detach()) and float(a[:, 4:].abs().max()) == 0.0
+    assert ops._padded(w, (0, 2)) is a                                   # unchanged parameter: cached
+    assert ops._padded(w, (0, 0, 0, 1)).shape == (4, 4)                  # another pad of the same tensor: its own entry
+    opt = torch.optim.SGD([w], lr=1.0)
+    w.grad = torch.ones_like(w)
+    opt.step()                                                           # in-place update
+    b = ops._padded(w, (0, 2))
+    assert b is not a and torch.equal(b[:, :4], w.detach())
+    w.data = torch.zeros(3, 4)                                           # re-pointed storage
+    assert float(ops._padded(w, (0, 2)).abs().max()) == 0.0
+    with torch.no_grad():
+        w.copy_(torch.full((3, 4), 2.0))                                 # load_state_dict-style copy
+    assert float(ops._padded(w, (0, 2))[:, :4].min()) == 2.0

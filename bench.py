@@ -22,6 +22,7 @@ sys.path.insert(0, ROOT)
 import rel_pose_amd._env  # noqa: F401,E402  (MIOpen user-db path; before torch / the first convolution)
 import torch
 import torch.distributed as dist
+from rel_pose_amd import parallel
 
 FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 BF16_MFMA_PEAK_TFLOPS = 2500.0       # same guide, dense bf16 MFMA (never the 2:1-sparsity figure)
@@ -203,7 +204,7 @@ def main():
             ltr, lrot = geodesic_loss_tensors(Ps, est)
             loss = 10.0 * ltr + 10.0 * lrot
             loss.backward()
-            torch.nn.utils.clip_grad_norm_(model.parameters(), 2.5)
+            parallel.clip_grad_norm_(model.parameters(), 2.5)
             opt.step()
             return loss
         with torch.no_grad():

@@ -345,3 +345,21 @@ def test_padded_weight_cache_follows_in_place_updates():
     with torch.no_grad():
         w.copy_(torch.full((3, 4), 2.0))                                 # load_state_dict-style copy
     assert float(ops._padded(w, (0, 2))[:, :4].min()) == 2.0
+
+
+def test_clip_grad_norm_equals_torch():
+    """parallel.clip_grad_norm_ = torch.nn.utils.clip_grad_norm_ (reference train.py:158), bit for bit, clipping and not clipping."""
+    from rel_pose_amd import parallel
+    for scale in (10.0, 1e-3):
+        torch.manual_seed(1)
+        ps = [torch.nn.Parameter(torch.randn(*s)) for s in ((7, 5), (3,), (2, 3, 4), (1,))]
+        qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+        for p, q in zip(ps, qs):
+            p.grad = torch.randn_like(p) * scale
+            q.grad = p.grad.clone()
+        qs.append(torch.nn.Parameter(torch.zeros(2)))                     # a parameter without a gradient
+        ta = torch.nn.utils.clip_grad_norm_(ps, 2.5)
+        tb = parallel.clip_grad_norm_(qs, 2.5)
+        assert torch.equal(ta, tb)
+        for p, q in zip(ps, qs):
+            assert torch.equal(p.grad, q.grad)

@@ -176,7 +176,7 @@ def run(args):
             est = net(images, Gs, intrinsics=intr)
             ltr, lrot, metrics = geodesic_loss(Ps, est)
             (args.w_tr * ltr + args.w_rot * lrot).backward()
-            torch.nn.utils.clip_grad_norm_(net.parameters(), args.clip)
+            parallel.clip_grad_norm_(net.parameters(), args.clip)
             opt.step()
             sched.step()
             step += 1

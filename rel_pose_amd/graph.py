@@ -16,6 +16,7 @@ describe the other replicas.
 import torch
 import torch.distributed as dist
 
+from . import ops
 from .losses import geodesic_loss_tensors
 from .se3 import SE3
 
@@ -44,6 +45,15 @@ class GraphedTrainStep:
         self.loss = torch.zeros((), device=images.device)
         self.gA = self.gB = None
         self.buffers = [b for b in model.buffers() if b.is_floating_point()]        # BatchNorm running_mean / running_var
+        self.bufflat = None
+        if self.world > 1 and self.buffers:
+            # the buffers become views into ONE flat tensor (like the gradients): rank 0's statistics reach every rank with a single
+            # broadcast and no packing / unpacking copies between the two graph replays
+            self.bufflat = torch.cat([b.detach().reshape(-1) for b in self.buffers])
+            o = 0
+            for b in self.buffers:
+                b.data = self.bufflat[o:o + b.numel()].view_as(b)
+                o += b.numel()
 
     # -- the two halves, written once and used both eagerly (warm-up) and under capture ---------------------------
     def _fwd_bwd(self):
@@ -66,13 +76,8 @@ class GraphedTrainStep:
     def _exchange(self):
         if self.world > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-            if self.buffers:                               # rank 0's BatchNorm statistics everywhere, like DDP's buffer broadcast
-                flat = torch.cat([b.reshape(-1) for b in self.buffers])
-                dist.broadcast(flat, 0)
-                o = 0
-                for b in self.buffers:
-                    b.copy_(flat[o:o + b.numel()].view_as(b))
-                    o += b.numel()
+            if self.bufflat is not None:                   # rank 0's BatchNorm statistics everywhere, like DDP's buffer broadcast
+                dist.broadcast(self.bufflat, 0)
 
     def capture(self, warmup=3):
         s = torch.cuda.Stream()
@@ -85,6 +90,7 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self.gA, self.gB = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        ops.invalidate_pad_cache()          # (under capture ops._padded caches nothing: the pads become graph nodes)
         with torch.cuda.graph(self.gA):
             self._fwd_bwd()
         with torch.cuda.graph(self.gB, pool=self.gA.pool()):
@@ -100,4 +106,5 @@ class GraphedTrainStep:
         self.gA.replay()
         self._exchange()
         self.gB.replay()
+        ops.invalidate_pad_cache()          # the replayed Adam step rewrote the parameters without bumping Tensor._version
         return self.loss

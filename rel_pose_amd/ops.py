@@ -103,19 +103,36 @@ USE_SIDE_STREAM = os.environ.get("RP_SIDE_STREAM", "0") == "1"   # measured: -0.
 # full step, and it makes per-kernel profiles overlap -> opt-in
 
 
-_PAD_CACHE = {}
+_PAD_GEN = 0
+
+
+def invalidate_pad_cache():
+    """Forget every cached alignment pad.  Needed after anything that rewrites parameters WITHOUT bumping Tensor._version:
+    a HIP-graph replay of the captured optimizer step (graph.GraphedTrainStep) is the one such writer in this package."""
+    global _PAD_GEN
+    _PAD_GEN += 1
 
 
 def _padded(t, pad):
-    """F.pad(t, pad).contiguous() of a weight / bias, cached until the tensor is next modified in place (optimizer step,
-    load_state_dict, DDP broadcast all bump Tensor._version): the three alignment pads of the CrossBlock / regressor weights used to be
-    re-made on every forward."""
-    key = (id(t), tuple(pad))
-    hit = _PAD_CACHE.get(key)
-    if hit is not None and hit[0] == t._version and hit[1] == t.data_ptr():
-        return hit[2]
+    """F.pad(t, pad).contiguous() of a weight / bias, cached ON the tensor (attribute `_rp_pads`: the cache lives and dies with the
+    parameter -- no id() reuse, nothing pinned after the model is deleted) until the tensor is next modified in place (optimizer step,
+    load_state_dict, DDP broadcast all bump Tensor._version) or invalidate_pad_cache() is called.  Under stream capture nothing is
+    cached: the pad is captured into the graph and re-executed by every replay, so a replayed forward sees the replayed weights."""
+    if t.is_cuda and torch.cuda.is_current_stream_capturing():
+        return torch.nn.functional.pad(t.detach(), pad).contiguous()
+    pads = getattr(t, "_rp_pads", None)
+    if pads is None:
+        pads = {}
+        try:
+            t._rp_pads = pads
+        except AttributeError:          # a tensor type without a __dict__: no caching
+            return torch.nn.functional.pad(t.detach(), pad).contiguous()
+    key = tuple(pad)
+    hit = pads.get(key)
+    if hit is not None and hit[0] == t._version and hit[1] == t.data_ptr() and hit[2] == _PAD_GEN:
+        return hit[3]
     out = torch.nn.functional.pad(t.detach(), pad).contiguous()
-    _PAD_CACHE[key] = (t._version, t.data_ptr(), out)
+    pads[key] = (t._version, t.data_ptr(), _PAD_GEN, out)
     return out
 
 
@@ -379,6 +396,7 @@ def linear_dw(dy, x):
 
 COLSUM_BATCHING = os.environ.get("RP_COLSUM_BATCH", "1") == "1"      # A/B aid
 _COLSUM_BATCH = None      # inside `with colsum_batch():` the (input, output) pairs collected so far
+_COLSUM_STREAM = None     # ... and the stream the block was entered on = the stream rp_colsum_multi will run on at exit
 
 
 class colsum_batch:
@@ -389,11 +407,15 @@ class colsum_batch:
     def __enter__(self):
         global _COLSUM_BATCH
         self.prev, _COLSUM_BATCH = _COLSUM_BATCH, ([] if COLSUM_BATCHING else None)
+        global _COLSUM_STREAM
+        self.prev_stream, _COLSUM_STREAM = _COLSUM_STREAM, (torch.cuda.current_stream() if torch.cuda.is_available() else None)
         return self
 
     def __exit__(self, et, ev, tb):
         global _COLSUM_BATCH
+        global _COLSUM_STREAM
         tasks, _COLSUM_BATCH = _COLSUM_BATCH, self.prev
+        _COLSUM_STREAM = self.prev_stream
         if et is None and tasks:
             for i in range(0, len(tasks), _lib.RP_COLSUM_MAX):
                 _colsum_multi(tasks[i:i + _lib.RP_COLSUM_MAX])
@@ -417,6 +439,10 @@ def colsum(t2d):
     out = _empty(cols, like=t2d)
     if _COLSUM_BATCH is not None:
         _COLSUM_BATCH.append((t2d, out))          # filled when the enclosing colsum_batch exits
+        if _COLSUM_STREAM is not None and torch.cuda.current_stream(t2d.device) != _COLSUM_STREAM:
+            # requested under fork.on_side: `out` was allocated on the side stream but is written on the batch's stream at exit
+            out.record_stream(_COLSUM_STREAM)
+            t2d.record_stream(_COLSUM_STREAM)
         return out
     nbytes = lib.rp_colsum_workspace_bytes(rows, cols)
     ws = torch.empty(max(nbytes // 4, 1), device=t2d.device, dtype=torch.float32)
@@ -706,7 +732,7 @@ def mlp_fused(x2d, gamma, beta, w1, b1, w2, b2, eps=LN_EPS):
     _chk(x2d, gamma, beta, w1, b1, w2, b2)
     M = x2d.shape[0]
     y = torch.empty_like(x2d)
-    key = (x2d.device, M)
+    key = (x2d.device, M, torch.cuda.current_stream(x2d.device).cuda_stream)
     ws = _mlp_ws.get(key)
     if ws is None:
         ws = _mlp_ws[key] = torch.empty(max(1, lib.rp_mlp_fused_workspace_bytes(M)) // 4 + 1, device=x2d.device, dtype=torch.float32)
@@ -728,7 +754,7 @@ def mlp_fused_bwd(dy, hpre, w1, w2):
     dhp, dxn = torch.empty_like(hpre), torch.empty_like(dy)
     tiles = -(-M // lib.rp_mlp_fused_bwd_tile_rows())
     colpart = _empty(tiles, hpre.shape[1], like=dy)
-    key = (dy.device, M, "bwd")
+    key = (dy.device, M, "bwd", torch.cuda.current_stream(dy.device).cuda_stream)
     ws = _mlp_ws.get(key)
     if ws is None:
         ws = _mlp_ws[key] = torch.empty(max(1, lib.rp_mlp_fused_bwd_workspace_bytes(M)) // 4 + 1, device=dy.device, dtype=torch.float32)

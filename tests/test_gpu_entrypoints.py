@@ -244,6 +244,17 @@ def test_graphed_train_step_matches_the_eager_step():
             gs.capture(warmup=2)                                        # 2 eager steps (lazy initialisation) + 4 replayed ones
             for _ in range(4):
                 out.append(float(gs.step()))
+            # replay, then an EAGER forward: the cached alignment pads of the CrossBlock / regressor weights (ops._padded) must follow
+            # the parameters the replayed Adam step rewrote without bumping Tensor._version -- compare with a fresh
+            # model that loads the same state and has no cache at all
+            from rel_pose_amd.se3 import SE3
+            Gs = SE3.IdentityLike(SE3(poses))
+            with torch.no_grad():
+                a = net(images, Gs, intrinsics=intr.clone())[0].data.clone()
+                fresh = ViTEss(args).cuda().train()
+                fresh.load_state_dict(net.state_dict())
+                b = fresh(images, Gs, intrinsics=intr.clone())[0].data
+            assert torch.equal(a, b), float((a - b).abs().max())
         else:
             for _ in range(6):
                 gs._fwd_bwd()

@@ -345,6 +345,16 @@ def test_padded_weight_cache_follows_in_place_updates():
     with torch.no_grad():
         w.copy_(torch.full((3, 4), 2.0))                                 # load_state_dict-style copy
     assert float(ops._padded(w, (0, 2))[:, :4].min()) == 2.0
+    # a writer that does not bump _version (a HIP-graph replay of the optimizer step): explicit invalidation
+    c = ops._padded(w, (0, 2))
+    w.data.view(-1).as_strided((12,), (1,)).detach().numpy()[:] = 5.0   # write through numpy: no version bump
+    assert ops._padded(w, (0, 2)) is c                                  # (stale by construction)
+    ops.invalidate_pad_cache()
+    d = ops._padded(w, (0, 2))
+    assert d is not c and float(d[:, :4].min()) == 5.0
+    # the cache lives on the tensor: a new parameter (even one that reuses id / storage of a deleted one) starts empty
+    w2 = torch.nn.Parameter(torch.ones(3, 4))
+    assert not hasattr(w2, "_rp_pads") and float(ops._padded(w2, (0, 2))[:, :4].max()) == 1.0
 
 
 def test_clip_grad_norm_equals_torch():

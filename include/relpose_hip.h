@@ -31,8 +31,15 @@ extern "C" {
 #define RP_EWORKSPACE (-3)
 #define RP_EUNSUPPORTED (-4)
 
-/* library / ABI version and target arch string ("gfx950") */
+/* library / ABI version and target arch string ("gfx950").
+ * RP_ABI_VERSION is bumped whenever an entry point is added, removed or changes its arguments; RP_ABI_EXPORTS is the number of
+ * functions this header declares.  rp_abi_version() / rp_abi_export_count() return the values the library was COMPILED with, so a
+ * binding (rel_pose_amd/_lib.py parses both macros and counts the declarations) rejects a stale .so at load time instead of
+ * failing later on a missing symbol. */
+#define RP_ABI_VERSION 4
+#define RP_ABI_EXPORTS 61
 int rp_abi_version(void);
+int rp_abi_export_count(void);
 const char* rp_target_arch(void);
 
 /* ---------------------------------------------------------------------------------------------

@@ -22,8 +22,7 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"),
-                                                       os.path.join(os.path.dirname(HERE), "include", "relpose_hip.h")]
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + _headers()
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -36,22 +35,31 @@ def build(force=False, verbose=True):
         try:
             if not force and not needs_build():      # another rank built it while this one waited
                 return LIB
-            return _build_locked(verbose)
+            return _build_locked(verbose, force)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
 
 
-def _build_locked(verbose):
+def _headers():
+    return [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".h")] + \
+           [os.path.join(os.path.dirname(HERE), "include", "relpose_hip.h")]
+
+
+def _build_locked(verbose, force=False):
+    """force: every translation unit is recompiled; otherwise only objects older than their source or any header."""
     cc = _hipcc()
     objs = []
     procs = []
+    hdr_t = max(os.path.getmtime(h) for h in _headers())
     for s in SOURCES:
         o = os.path.join(CSRC, s.replace(".hip", ".o"))
+        objs.append(o)
+        if not force and os.path.exists(o) and os.path.getmtime(o) > max(hdr_t, os.path.getmtime(os.path.join(CSRC, s))):
+            continue
         cmd = [cc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-        objs.append(o)
     for s, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:

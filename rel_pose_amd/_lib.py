@@ -11,7 +11,22 @@ import torch  # noqa: F401  (must be imported first: it loads the HIP runtime th
 from . import _build
 
 _LIB = None
-ABI_VERSION = 3          # rp_abi_version() of the library this binding was written against
+HEADER = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "relpose_hip.h")
+
+
+def _header_contract():
+    """(RP_ABI_VERSION, RP_ABI_EXPORTS, declared function names) parsed from include/relpose_hip.h -- the single source of truth the
+    library is compiled against and this binding is checked against."""
+    import re
+    with open(HEADER) as f:
+        text = f.read()
+    ver = int(re.search(r"#define\s+RP_ABI_VERSION\s+(\d+)", text).group(1))
+    cnt = int(re.search(r"#define\s+RP_ABI_EXPORTS\s+(\d+)", text).group(1))
+    code = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return ver, cnt, set(re.findall(r"\b(rp_[a-z0-9_]+)\s*\(", code))
+
+
+ABI_VERSION, ABI_EXPORTS, DECLARED = _header_contract()
 RP_ERRORS = {-1: "bad shape", -2: "misaligned pointer/stride", -3: "workspace too small", -4: "unsupported"}
 
 
@@ -37,6 +52,7 @@ RP_COLSUM_MAX = 8
 P, I, F, L = c_void_p, c_int, c_float, c_longlong
 _SIGS = {
     "rp_abi_version": (c_int, []),
+    "rp_abi_export_count": (c_int, []),
     "rp_target_arch": (c_char_p, []),
     "rp_gemm": (c_int, [POINTER(RpGemm), P]),
     "rp_gemm_workspace_bytes": (c_size_t, [I, I, I]),
@@ -120,6 +136,13 @@ def load():
     if lib.rp_abi_version() != ABI_VERSION:
         raise RuntimeError("rel_pose_amd: %s has ABI version %d, this package binds version %d -- rebuild with "
                            "`python -m rel_pose_amd._build --force`" % (path, lib.rp_abi_version(), ABI_VERSION))
+    if set(_SIGS) != DECLARED or len(DECLARED) != ABI_EXPORTS:
+        raise RuntimeError("rel_pose_amd: include/relpose_hip.h declares %d entry points (RP_ABI_EXPORTS = %d) but _lib.py binds %d: "
+                           "%s" % (len(DECLARED), ABI_EXPORTS, len(_SIGS), sorted(DECLARED ^ set(_SIGS))))
+    lib.rp_abi_export_count.restype = c_int
+    if lib.rp_abi_export_count() != ABI_EXPORTS:
+        raise RuntimeError("rel_pose_amd: %s was compiled with %d entry points, the header declares %d -- rebuild"
+                           % (path, lib.rp_abi_export_count(), ABI_EXPORTS))
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)          # AttributeError = symbol missing = broken build
         fn.restype = res

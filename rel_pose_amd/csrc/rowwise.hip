@@ -629,5 +629,6 @@ extern "C" int rp_pose_normalize_bwd(const float* pred, const float* dout, float
   return RP_OK;
 }
 
-extern "C" int rp_abi_version(void) { return 3; }
+extern "C" int rp_abi_version(void) { return RP_ABI_VERSION; }
+extern "C" int rp_abi_export_count(void) { return RP_ABI_EXPORTS; }
 extern "C" const char* rp_target_arch(void) { return "gfx950"; }

@@ -26,6 +26,7 @@ from rel_pose_amd import parallel
 
 FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 BF16_MFMA_PEAK_TFLOPS = 2500.0       # same guide, dense bf16 MFMA (never the 2:1-sparsity figure)
+HBM_PEAK_GBS = 8000.0                # same guide, HBM3E peak (spec); 6.29 TB/s is the measured copy rate
 PRECISIONS = {"fp32": 0, "split3": 3, "bf16": 1}
 FLOPS_FWD_PER_PAIR = 8588216320      # GEMM flops of the ViT+EMM+regressor hot path, forward
 METRIC = "image-pairs/sec fwd+bwd @384x384, 1/2/4/8 MI355X; R,t err vs ref"
@@ -113,6 +114,112 @@ def cpu_baseline(hw, budget_s=20.0):
                       "torch-CPU oracle, %d of %d host threads (best of 8/16/32/64), %.1f s"
                       % (n, Bc, hw, hw, cores, ncpu, el)}
 
+TRAFFIC_FILES = ("r3_traffic.json", "r2_traffic.json")
+
+
+def pmc_traffic(kname, files=TRAFFIC_FILES):
+    """HBM bytes per launch of `kname` from the committed rocprofv3 --pmc passes (they cannot run inside the timed process)."""
+    for fn in files:
+        tpath = os.path.join(ROOT, "profiles", fn)
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                ent = json.load(f)["kernels"].get(kname)
+            if ent:
+                return round(ent["hbm_bytes_per_launch"]), "profiles/%s (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes)" % fn
+    return None, None
+
+
+def supplementary_point(dev, tag, batch, hw, mode, precision, steps, warmup, timer_instance, kernel_symbol, traffic_files):
+    """One bounded extra operating point in the SAME process, after the headline: its own model, its own
+    roofline object (HIP-event-timed dominant kernel of that mode), barrier-free (single GPU).  Never touches the headline fields."""
+    from rel_pose_amd import ops
+    from rel_pose_amd.losses import geodesic_loss_tensors
+    from rel_pose_amd.model import ViTEss
+    from rel_pose_amd.se3 import SE3
+    nl = PRECISIONS[precision]
+    saved = (ops.GEMM_PRECISION, ops.ATTN_BF16, ops.CNN_PRECISION, ops.TIMER)
+    try:
+        ops.set_gemm_precision(nl)
+        ops.set_attention_precision(1 if nl == 1 else 0)
+        ops.set_cnn_precision(1 if nl == 1 else 0)
+        torch.manual_seed(0)
+        model = ViTEss(model_args()).to(dev)
+        for p in list(model.resnet.layer3.parameters()) + list(model.resnet.layer4.parameters()):
+            p.requires_grad = False
+        train = mode == "train"
+        model.train(train)
+        opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=5e-4, weight_decay=1e-5, fused=True) if train else None
+        images, poses, intr = synthetic_batch(batch, hw, dev, 4321)
+        Ps = SE3(poses)
+        Gs = SE3.IdentityLike(Ps)
+
+        def step():
+            if train:
+                opt.zero_grad(set_to_none=True)
+                est = model(images, Gs, intrinsics=intr.clone())
+                ltr, lrot = geodesic_loss_tensors(Ps, est)
+                loss = 10.0 * ltr + 10.0 * lrot
+                loss.backward()
+                parallel.clip_grad_norm_(model.parameters(), 2.5)
+                opt.step()
+                return loss
+            with torch.no_grad():
+                return model(images, Gs, intrinsics=intr.clone())[0].data
+
+        timer = ops.KernelTimer(timer_instance)
+        ops.TIMER = timer
+        step()
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        timer.enabled = True
+        t0 = time.perf_counter()
+        last = None
+        for _ in range(steps):
+            last = step()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        timer.enabled = False
+        n_launch, t_launch, flops = timer.summary()
+        pairs = batch * steps
+        tf = flops / max(n_launch, 1) / max(t_launch, 1e-12) / 1e12
+        gbs = timer.bytes / max(n_launch, 1) / max(t_launch, 1e-12) / 1e9
+        traffic, src = pmc_traffic(kernel_symbol, traffic_files)
+        if nl == 1:
+            # the bf16 configuration's Linear kernels move fp32-sized activations per bf16 MFMA flop: HBM is the roofline that binds
+            roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                    "mfma_frac": round(tf / BF16_MFMA_PEAK_TFLOPS, 4), "mfma_achieved_tflops": round(tf, 1)}
+        else:
+            roof = {"bound": "mfma", "achieved": round(tf, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4)}
+        roof.update({"traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": src,
+                     "algorithmic_bytes_per_launch_avg": timer.bytes / max(n_launch, 1), "kernel": kernel_symbol,
+                     "launches_timed": n_launch, "avg_launch_us": round(t_launch * 1e6, 2), "flops_per_launch_avg": flops / max(n_launch, 1),
+                     "hot_path_tflops_whole_step": round((3 if train else 1) * FLOPS_FWD_PER_PAIR * pairs / el / 1e12, 2)})
+        rec = {"value": round(pairs / el, 2), "unit": "image-pairs/sec", "ms_per_step": round(1e3 * el / steps, 3), "steps": steps,
+               "warmup": warmup, "dtype": "bf16" if nl == 1 else "f32",
+               "config": {"workload": tag, "pairs_per_gpu": batch, "mode": mode, "precision": precision,
+                          "finite": bool(torch.isfinite(last).all())},
+               "roofline": roof}
+        del model, opt, images
+        torch.cuda.empty_cache()
+        return rec
+    finally:
+        ops.GEMM_PRECISION, ops.ATTN_BF16, ops.CNN_PRECISION, ops.TIMER = saved
+
+
+def parse_instance(text):
+    """'1,1,1,3' -> (1,1,1,3) (an rp_gemm instance); anything else is a kernel tag of rel_pose_amd.ops.timed"""
+    try:
+        return tuple(int(v) for v in text.split(","))
+    except ValueError:
+        return text
+
+
+TAG_SYMBOLS = {"mlp_fused_fwd": "mlp_fused_kernel<4, 3, 0>", "attn_fwd": "attn_fwd_kernel<2, false, 2, false>",
+               "attn_stats": "attn_fwd_kernel<3, true, 2, false>", "linear_rows_ln": "linear_rows_kernel<true>",
+               "linear_rows": "linear_rows_kernel<false>"}
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -123,6 +230,9 @@ def main():
     ap.add_argument("--hw", type=int, default=384)
     ap.add_argument("--mode", default="train", choices=("train", "fwd"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-supplementary", action="store_true",
+                    help="skip the two extra bounded points (BASELINE configs[1] forward-only at 64 pairs, configs[4] bf16 at 128 pairs "
+                         "per GPU) that the default single-GPU run times after the headline loop and attaches as `supplementary`")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from captured HIP graphs (rel_pose_amd/graph.py) instead of launching eagerly; "
                          "measured neutral at N=1 once the step had no host syncs left, so eager + DDP is the default")
@@ -213,7 +323,7 @@ def main():
     ops.set_gemm_precision(PRECISIONS[args.precision])
     ops.set_attention_precision(1 if args.precision == "bf16" else 0)      # configs[4]: bf16 MFMA attention / EMM GEMMs too
     ops.set_cnn_precision(1 if args.precision == "bf16" and not os.environ.get("RP_BF16_KEEP_FP32_CNN") else 0)   # and the MIOpen convolutions
-    timer = ops.KernelTimer([int(v) for v in args.timer_instance.split(",")])
+    timer = ops.KernelTimer(parse_instance(args.timer_instance))
     ops.TIMER = timer
     eager_step = step
     eager_step()          # untimed priming step, even with --warmup 0: lazy init and MIOpen's solver search never fall in the timed steps
@@ -273,8 +383,11 @@ def main():
         nl = PRECISIONS[args.precision]
         # exact-fp32 launches with whole 32-wide k-tiles run the LDS-DMA-staged kernel (csrc/gemm_dma.hip), the bf16-limb
         # precisions the register-staged one (csrc/gemm.hip); same tiles, same template arguments
-        kname = ("gemm_dma_kernel<%s>" % ", ".join(args.timer_instance.split(",")) if nl == 0 and not os.environ.get("RP_GEMM_NO_DMA")
-                 else "gemm_kernel<%s, %d>" % (", ".join(args.timer_instance.split(",")), nl))
+        if isinstance(timer.instance, str):
+            kname = TAG_SYMBOLS.get(timer.instance, timer.instance)
+        else:
+            kname = ("gemm_dma_kernel<%s>" % ", ".join(args.timer_instance.split(",")) if nl == 0 and not os.environ.get("RP_GEMM_NO_DMA")
+                     else "gemm_kernel<%s, %d>" % (", ".join(args.timer_instance.split(",")), nl))
         # matrix-pipe ceiling of the timed kernel in ALGORITHMIC (2MNK) flops: the exact-fp32 MFMA peak, or the dense
         # bf16 MFMA peak divided by the limb products issued per fp32 product (6 for split3, 1 for bf16)
         peak = {0: FP32_MFMA_PEAK_TFLOPS, 3: BF16_MFMA_PEAK_TFLOPS / 6.0, 1: BF16_MFMA_PEAK_TFLOPS}[nl]
@@ -282,13 +395,7 @@ def main():
                      3: "dense bf16 MFMA peak 2500 TF / 6 limb products per fp32 multiply-add (v_mfma_f32_32x32x16_bf16); "
                         "the same kernel is %.2f of the 157.3 TF fp32-MFMA peak it replaces" % (achieved / FP32_MFMA_PEAK_TFLOPS),
                      1: "dense bf16 MFMA peak"}[nl]
-        tpath = os.path.join(ROOT, "profiles", "r2_traffic.json")      # PMC passes cannot run inside the timed process:
-        if os.path.exists(tpath):                                     # tools/pmc_bench.sh measured this command's kernels
-            with open(tpath) as f:
-                tj = json.load(f)
-            ent = tj["kernels"].get(kname)
-            if ent:
-                traffic, traffic_src = round(ent["hbm_bytes_per_launch"]), "profiles/r2_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE)"
+        traffic, traffic_src = pmc_traffic(kname)     # PMC passes cannot run inside the timed process: tools/pmc_bench.sh
         rec = {
             "metric": METRIC, "value": round(pairs / el, 2), "unit": "image-pairs/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 3),
@@ -315,6 +422,23 @@ def main():
                          "flops_per_launch_avg": flops / max(n_launch, 1),
                          "hot_path_tflops_whole_step": round((3 if train else 1) * FLOPS_FWD_PER_PAIR * pairs / el / 1e12, 2)},
         }
+        if (world == 1 and not force_dist and not args.no_supplementary and train and args.scope == "full" and args.batch == 64
+                and args.precision == "fp32" and not graphed):
+            # the default single-GPU run also times BASELINE configs[1] (forward only, 64 pairs) and configs[4]'s per-GPU workload
+            # (bf16, 128 pairs) in this process, bounded to a few seconds each; the headline fields above are already final
+            sup = {}         # (the headline model stays resident: 288 GB of HBM make freeing it pointless)
+            for key, kw in (("fwd_only", dict(tag="ViTEss.forward, eval, no_grad, synthetic %dx%d pairs (BASELINE configs[1])" % (args.hw, args.hw),
+                                              batch=64, mode="fwd", precision="fp32", steps=60, warmup=5, timer_instance="mlp_fused_fwd",
+                                              kernel_symbol=TAG_SYMBOLS["mlp_fused_fwd"], traffic_files=("r3_traffic_fwd.json",))),
+                            ("bf16_128", dict(tag="train.py step, bf16 MFMA operands in Linear / attention / EMM GEMMs and the MIOpen "
+                                                  "convolutions, fp32 accumulate (BASELINE configs[4] per-GPU workload)",
+                                              batch=128, mode="train", precision="bf16", steps=20, warmup=3, timer_instance=(0, 0, 2, 1),
+                                              kernel_symbol="gemm_kernel<0, 0, 2, 1, 1>", traffic_files=("r3_traffic_bf16.json",)))):
+                try:
+                    sup[key] = supplementary_point(dev, hw=args.hw, **kw)
+                except Exception as e:          # a supplementary point must never take the headline line down with it
+                    sup[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+            rec["supplementary"] = sup
         if not args.no_cpu_baseline and world == 1:
             rec["cpu_baseline"] = cpu_baseline(args.hw)
         print(json.dumps(rec), flush=True)

@@ -191,24 +191,28 @@ def pick_split_k(M, N, K, a_layout=0, b_layout=0, target_wgs=768, min_ktiles=8, 
 
 
 class KernelTimer:
-    """HIP-event timing of every launch of ONE gemm_kernel<a_layout,b_layout,TM,TN> instance on torch's current
-    stream (bench.py's `roofline` object).  Off unless bench.py installs one."""
+    """HIP-event timing of every launch of ONE kernel on torch's current stream (bench.py's `roofline` object).  Off unless bench.py
+    installs one.  `instance` is either a gemm_kernel<a_layout,b_layout,TM,TN> tuple (events recorded by rp_gemm itself around the
+    main kernel, so a split-K launch's reduce is outside the span) or a string tag of one of the other MFMA kernels (`timed(tag, ...)`
+    call sites below: the events bracket the one C-ABI call, on the stream it launches on)."""
 
     def __init__(self, instance):
-        self.instance = tuple(instance)
+        self.instance = instance if isinstance(instance, str) else tuple(instance)
         self.events = []
+        self.tevents = []         # torch.cuda.Event pairs of tagged (non-rp_gemm) launches
         self.flops = 0.0
         self.bytes = 0.0          # compulsory bytes: A + B + C (+ [M,N] epilogue operands), each once
         self.enabled = False
 
     def reset(self):
-        self.events, self.flops, self.bytes = [], 0.0, 0.0
+        self.events, self.tevents, self.flops, self.bytes = [], [], 0.0, 0.0
 
     def summary(self):
         """-> (launches, mean seconds per launch, total algorithmic flops); call after a device sync."""
         lib = _lib.load()
-        n = len(self.events)
+        n = len(self.events) + len(self.tevents)
         tot = sum(lib.rp_event_elapsed_ms(s, e) for s, e in self.events) * 1e-3
+        tot += sum(s.elapsed_time(e) for s, e in self.tevents) * 1e-3
         return n, (tot / n if n else 0.0), self.flops
 
     def new_pair(self):
@@ -219,6 +223,29 @@ class KernelTimer:
         if not self._pool:
             self._pool = [ctypes.c_void_p(lib.rp_event_create()) for _ in range(64)]
         return self._pool.pop(), self._pool.pop()
+
+
+class timed:
+    """`with timed("attn_fwd", flops, nbytes): lib.rp_...(...)` -- a no-op unless bench.py's timer targets this tag."""
+
+    def __init__(self, tag, flops, nbytes):
+        tm = TIMER
+        self.tm = tm if (tm is not None and tm.enabled and tm.instance == tag) else None
+        self.flops, self.nbytes = flops, nbytes
+
+    def __enter__(self):
+        if self.tm is not None:
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if self.tm is not None and et is None:
+            self.e1.record()
+            self.tm.tevents.append((self.e0, self.e1))
+            self.tm.flops += self.flops
+            self.tm.bytes += self.nbytes
+        return False
 
 
 TIMER = None
@@ -277,7 +304,7 @@ def gemm(A, B, M, N, K, *, a_layout=0, b_layout=0, lda=None, ldb=None, out=None,
         cpart = _empty(2 * (-(-M // (64 * tm_))), N, like=A)
         g.colsum_part = cpart.data_ptr()
     tm = TIMER
-    if (tm is not None and tm.enabled and batch == 1 and ln is None and
+    if (tm is not None and tm.enabled and batch == 1 and ln is None and not isinstance(tm.instance, str) and
             gemm_instance(M, N, a_layout, b_layout, aux is not None or residual is not None) == tm.instance):
         # events are recorded by rp_gemm itself around the MAIN kernel (a split-K launch's reduce is a separate kernel)
         e0, e1 = tm.new_pair()
@@ -321,8 +348,11 @@ def linear_rows(x, W, b=None, act=0, want_pre=False, residual=None, ln=None, wan
         if want_ln_out:
             xn, mean, rstd = torch.empty_like(x), _empty(M, like=x), _empty(M, like=x)
     part = _empty(-(-M // lib.rp_linear_rows192_tile_rows()), N, like=x) if want_colsum else None
-    _lib.check(lib.rp_linear_rows192(_p(x), _p(W), _p(b), _p(residual), _p(g), _p(be), LN_EPS, _p(y), _p(pre), _p(xn), _p(mean),
-                                     _p(rstd), _p(dact_aux), _p(part), M, N, K, act, _st()), "rp_linear_rows192")
+    nmn = 1 + (pre is not None) + (residual is not None) + (dact_aux is not None)
+    with timed("linear_rows_ln" if ln is not None else "linear_rows", 2.0 * M * N * K,
+               4.0 * (M * K * (1 + (xn is not None)) + N * K + M * N * nmn)):
+        _lib.check(lib.rp_linear_rows192(_p(x), _p(W), _p(b), _p(residual), _p(g), _p(be), LN_EPS, _p(y), _p(pre), _p(xn), _p(mean),
+                                         _p(rstd), _p(dact_aux), _p(part), M, N, K, act, _st()), "rp_linear_rows192")
     out = ((y,) + ((pre,) if want_pre else ()) + ((xn, mean, rstd) if (ln is not None and want_ln_out) else ())
            + ((colsum(part),) if want_colsum else ()))
     return out[0] if len(out) == 1 else out
@@ -489,9 +519,12 @@ def attn_fwd(qkv, Z, stats_only=False, q_off=0, k_off=DIM, v_off=2 * DIM, q_xor=
     lse = _empty(Z, HEADS, N_TOK, like=qkv)
     base = qkv.data_ptr()
     P = ctypes.c_void_p
-    _lib.check(lib.rp_attn_fwd(P(base + 4 * q_off), P(base + 4 * k_off), P(base + 4 * v_off), _p(o), _p(lse), Z, HEADS,
-                               ld, ld, ld, DIM, q_xor, k_xor, (DIM // HEADS) ** -0.5, 1 if stats_only else 0, ATTN_BF16, _st()),
-               "rp_attn_fwd")
+    hd = DIM // HEADS
+    with timed("attn_stats" if stats_only else "attn_fwd", (2.0 if stats_only else 4.0) * Z * HEADS * N_TOK * N_TOK * hd,
+               4.0 * Z * N_TOK * ((2 if stats_only else 4) * DIM + HEADS)):
+        _lib.check(lib.rp_attn_fwd(P(base + 4 * q_off), P(base + 4 * k_off), P(base + 4 * v_off), _p(o), _p(lse), Z, HEADS,
+                                   ld, ld, ld, DIM, q_xor, k_xor, hd ** -0.5, 1 if stats_only else 0, ATTN_BF16, _st()),
+                   "rp_attn_fwd")
     return o, lse
 
 
@@ -736,8 +769,10 @@ def mlp_fused(x2d, gamma, beta, w1, b1, w2, b2, eps=LN_EPS):
     ws = _mlp_ws.get(key)
     if ws is None:
         ws = _mlp_ws[key] = torch.empty(max(1, lib.rp_mlp_fused_workspace_bytes(M)) // 4 + 1, device=x2d.device, dtype=torch.float32)
-    _lib.check(lib.rp_mlp_fused_fwd(_p(x2d), _p(gamma), _p(beta), _p(w1), _p(b1), _p(w2), _p(b2), _p(y), _p(ws), M, x2d.shape[1],
-                                    w1.shape[0], eps, _st()), "rp_mlp_fused_fwd")
+    Hd = w1.shape[0]
+    with timed("mlp_fused_fwd", 4.0 * M * DIM * Hd, 4.0 * (2 * M * DIM + 2 * DIM * Hd)):
+        _lib.check(lib.rp_mlp_fused_fwd(_p(x2d), _p(gamma), _p(beta), _p(w1), _p(b1), _p(w2), _p(b2), _p(y), _p(ws), M, x2d.shape[1],
+                                        Hd, eps, _st()), "rp_mlp_fused_fwd")
     return y
 
 

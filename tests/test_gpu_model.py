@@ -271,6 +271,97 @@ def test_full_size_backward_config3(model, states):
         model.eval()
 
 
+def _e2e_oracle_grads(sd64, imgs64, Gs64, intr64, cot, train):
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v) for k, v in sd64.items()}
+    out, _ = O.vit_ess_forward(sd, imgs64, Gs64, intr64.clone(), train=train)
+    (out * cot).sum().backward()
+    return sd, out.detach()
+
+
+def _compare_all_trainable(model, sd, scale, tol, tag):
+    """every trainable tensor of the product model against scale x the oracle's gradient; the three convolution biases that sit in
+    front of a train-mode BatchNorm have an exactly-zero true gradient (the batch mean absorbs a constant): their oracle value is
+    rounding noise, so they are checked against the size of their layer's weight gradient instead"""
+    worst, cnn_worst = {}, 0.0
+    for name, p in model.named_parameters():
+        if name.startswith("resnet.layer3") or name.startswith("resnet.layer4") or name.startswith("resnet.fc"):
+            continue                                      # not on the path (reference src/model.py:127-132)
+        assert p.grad is not None, name
+        ref = sd[name].grad
+        assert ref is not None, name
+        if float(ref.abs().max()) < 1e-9 * max(1.0, float(sd[name.replace(".bias", ".weight")].grad.abs().max())):
+            wmax = float(sd[name.replace(".bias", ".weight")].grad.abs().max())
+            assert float(p.grad.abs().max()) < 1e-4 * scale * wmax, (name, float(p.grad.abs().max()), wmax)
+            continue
+        worst[name] = rel(p.grad, scale * ref)
+        if name.startswith("resnet") or name.startswith("extractor"):
+            cnn_worst = max(cnn_worst, worst[name])
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:6]
+    report(tag, max=max(worst.values()), cnn_max=cnn_worst, tensors=float(len(worst)))
+    with open(os.path.join(ROOT, "gpurun_out", "test_report.txt"), "a") as f:
+        f.write("  worst grads: %s\n" % top)
+    bad = {k: v for k, v in worst.items() if v > tol}
+    assert not bad, bad
+    return worst
+
+
+def test_end_to_end_backward_images_in_vs_oracle(model, states):
+    """SURVEY 8f-1 / VERDICT r2 item 2: IMAGES in, train-mode BatchNorm, loss = <pose, cot>; the gradient of EVERY trainable tensor --
+    resnet.conv1/bn1/layer1/layer2 and extractor_final_conv.* through MIOpen's backward-weights / backward-data, StemConvFn,
+    BnReluPoolFn and BnActFn, then the ViT, the EMM and the regressor -- against fp64 autograd of the oracle's whole forward
+    (reference src/model.py:111-143,161-191; extractor.py:51-65).  <= 1e-3 of max|ref| per tensor (MIOpen's summation order)."""
+    from rel_pose_amd.se3 import SE3
+    _, sd64 = states
+    B, H, W = 2, 384, 384
+    imgs = O.synthetic_images(B, H, W, key=77)
+    intr = torch.tensor([[0.9 * W, 0.8 * W, W / 2.0, H / 2.0]]).repeat(B, 2, 1).contiguous()
+    Gs = torch.tensor([0, 0, 0, 0, 0, 0, 1.0]).repeat(B, 2, 1)
+    cot = O.closed_form((B, 2, 7), 7117, 1.0, dtype=torch.float64)
+    sd, ref = _e2e_oracle_grads(sd64, imgs.double(), Gs.double(), intr.double(), cot, True)
+    model.load_state_dict(states[0], strict=True)            # (running statistics of earlier train-mode tests do not matter here)
+    model.train()
+    try:
+        for p in model.parameters():
+            p.grad = None
+        out = model(imgs.cuda(), SE3(Gs.cuda()), intrinsics=intr.clone().cuda())[0].data
+        (out * cot.float().cuda()).sum().backward()
+        t_err, q_err, ang = O.pose_errors(out.detach().cpu(), ref)
+        report("e2e_backward_images_in_pose", t=t_err, q=q_err, ang=ang)
+        assert max(t_err, q_err) < 1e-4
+        _compare_all_trainable(model, sd, 1.0, 1e-3, "e2e_backward_images_in_train_bn")
+    finally:
+        model.eval()
+        model.load_state_dict(states[0], strict=True)
+
+
+def test_end_to_end_backward_64_pairs_images_in(model, states):
+    """BASELINE configs[2] at its full size WITH images in (64 pairs of 384x384, fwd+bwd) as a size-independent property: the batch is
+    4 distinct pairs x 16 copies, BatchNorm in eval mode (running statistics) so that copies decouple; every trainable tensor's
+    gradient -- CNN front-end included -- must equal 16 x the fp64 oracle's gradient on the 4 distinct pairs, and the poses of the
+    copies must agree with each other and with the oracle."""
+    from rel_pose_amd.se3 import SE3
+    _, sd64 = states
+    B, R, H, W = 64, 16, 384, 384
+    imgs4 = O.synthetic_images(4, H, W, key=6464)
+    intr4 = torch.tensor([[0.9 * W, 0.8 * W, W / 2.0, H / 2.0]]).repeat(4, 2, 1).contiguous()
+    Gs4 = torch.tensor([0, 0, 0, 0, 0, 0, 1.0]).repeat(4, 2, 1)
+    cot4 = O.closed_form((4, 2, 7), 6465, 1.0, dtype=torch.float64)
+    sd, ref = _e2e_oracle_grads(sd64, imgs4.double(), Gs4.double(), intr4.double(), cot4, False)
+    src = torch.arange(B) % 4
+    model.load_state_dict(states[0], strict=True)
+    model.eval()
+    for p in model.parameters():
+        p.grad = None
+    out = model(imgs4[src].contiguous().cuda(), SE3(Gs4[src].cuda()), intrinsics=intr4[src].contiguous().cuda())[0].data
+    (out * cot4[src].float().cuda()).sum().backward()
+    assert torch.isfinite(out).all()
+    t_err, q_err, ang = O.pose_errors(out[:4].detach().cpu(), ref)
+    copies = max(rel(out[b], out[b % 4]) for b in range(4, B))
+    report("e2e_backward_64pairs_pose", t=t_err, q=q_err, ang=ang, copies=copies)
+    assert max(t_err, q_err) < 1e-4 and copies < 1e-5
+    _compare_all_trainable(model, sd, float(R), 1e-3, "e2e_backward_64pairs_eval_bn")
+
+
 def test_interiornet_shaped_input_fwd_bwd(model):
     """configs[2] uses InteriorNet frames: 256x256 on disk, resized by the reader to 384x512 (src/data_readers/base.py:20,28,
     augmentation.py:37) -- a non-square input whose intrinsics rescale differently per axis.  End to end (CNN + hot path +

@@ -717,7 +717,30 @@ def emm_backward(qkv, x, t, rlse, clse, df, Z, single=False, cross=False):
 # ------------------------------------------------------------------------------------------------
 # autograd Functions
 # ------------------------------------------------------------------------------------------------
-class TokensFn(torch.autograd.Function):
+_GRAD_AT_APPLY = True
+
+
+class _Fn(torch.autograd.Function):
+    """Base of every Function here.  Inside Function.forward grad mode is always off and ctx.needs_input_grad ignores torch.no_grad()
+    (it is just the inputs' requires_grad), so `any(ctx.needs_input_grad)` alone would send every no_grad / inference call down the
+    training path (extra activation stores, no fused inference MLP).  apply() records the caller's grad mode; _train(ctx) combines
+    the two."""
+
+    @classmethod
+    def apply(cls, *args, **kwargs):
+        global _GRAD_AT_APPLY
+        prev, _GRAD_AT_APPLY = _GRAD_AT_APPLY, torch.is_grad_enabled()
+        try:
+            return super().apply(*args, **kwargs)
+        finally:
+            _GRAD_AT_APPLY = prev
+
+
+def _train(ctx):
+    return _GRAD_AT_APPLY and any(ctx.needs_input_grad)
+
+
+class TokensFn(_Fn):
     """x[z][n][c] = feat[z][c][n] + pos_embed[n][c]  (src/model.py:136-141,170-171).  A channels-last CNN map is
     already laid out [z][n][c] in memory, so the permutation is a view and only the add runs."""
 
@@ -859,14 +882,14 @@ def _mlp_bwd(fork, dy, xn, h, hpre, w1, w2, want_db2=True, ln=None):
     return dxn, dw1, db1, dw2, db2
 
 
-class BlockFn(torch.autograd.Function):
+class BlockFn(_Fn):
     """Block.forward (vision_transformer.py:349-354) on x [Z,576,192]."""
 
     @staticmethod
     def forward(ctx, x, n1w, n1b, qkv_w, qkv_b, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b, cross=False):
         """cross=True: keys and values come from the partner image of each pair -- the --noess CrossBlock
         (vision_transformer.py:239-262,297-304), which is otherwise arithmetically a Block."""
-        train = any(ctx.needs_input_grad)   # (grad mode is off inside Function.forward)
+        train = _train(ctx)
         x = x.contiguous()
         Z = x.shape[0]
         x2 = x.view(Z * N_TOK, DIM)
@@ -907,13 +930,13 @@ class BlockFn(torch.autograd.Function):
                 dfc2b, None)
 
 
-class CrossBlockFn(torch.autograd.Function):
+class CrossBlockFn(_Fn):
     """CrossBlock.forward, ess branch (vision_transformer.py:285-296): x [2B,576,192] -> [2B,70,192]."""
 
     @staticmethod
     def forward(ctx, x, pos, n1w, n1b, qkv_w, qkv_b, pf_w, pf_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b, single=False,
                 cross=False):
-        train = any(ctx.needs_input_grad)   # (grad mode is off inside Function.forward)
+        train = _train(ctx)
         x = x.contiguous()
         Z = x.shape[0]
         x2 = x.view(Z * N_TOK, DIM)
@@ -990,13 +1013,13 @@ def _regress_bwd(dout, feats, h1, h2, pred, w0, w2, w4p):
     return dfeats, dw0, db0, dw2, db2, dw4, db4
 
 
-class HeadFn(torch.autograd.Function):
+class HeadFn(_Fn):
     """final LayerNorm -> flatten [B,26880] -> 26880-512-512-14 MLP -> quaternion normalise
     (src/model.py:178,189,91-98,145-159).  y: [2B,70,192]; gs: [B,2,7] -> [B,2,7]."""
 
     @staticmethod
     def forward(ctx, y, gs, nw, nb, w0, b0, w2, b2, w4, b4):
-        train = any(ctx.needs_input_grad)   # (grad mode is off inside Function.forward)
+        train = _train(ctx)
         y = y.contiguous()
         Z = y.shape[0]
         B = Z // 2
@@ -1018,12 +1041,12 @@ class HeadFn(torch.autograd.Function):
         return dy.view(2 * B, 70, DIM), None, dnw, dnb, dw0, db0, dw2, db2, dw4, db4
 
 
-class RegressFn(torch.autograd.Function):
+class RegressFn(_Fn):
     """pose regressor + quaternion normalise on already-pooled features [B,H] (the --noess head, src/model.py:79-86,188)."""
 
     @staticmethod
     def forward(ctx, feats, gs, w0, b0, w2, b2, w4, b4):
-        train = any(ctx.needs_input_grad)
+        train = _train(ctx)
         feats = feats.contiguous()
         _chk(feats)
         out, h1, h2, pred, w4p = _regress_fwd(feats, gs, w0, b0, w2, b2, w4, b4)
@@ -1039,7 +1062,7 @@ class RegressFn(torch.autograd.Function):
         return dfeats, None, dw0, db0, dw2, db2, dw4, db4
 
 
-class LayerNormFn(torch.autograd.Function):
+class LayerNormFn(_Fn):
     """LayerNorm over the last dim (C = 192) on the rowwise HIP kernels: the final norm of the --noess model, whose output
     feeds a conv head instead of HeadFn (src/model.py:178,183-188)."""
 
@@ -1048,7 +1071,7 @@ class LayerNormFn(torch.autograd.Function):
         x = x.contiguous()
         x2 = x.view(-1, x.shape[-1])
         y, m, r = layernorm_fwd(x2, w, b)
-        if any(ctx.needs_input_grad):
+        if _train(ctx):
             ctx.save_for_backward(x2, m, r, w)
         return y.view(x.shape)
 
@@ -1062,7 +1085,7 @@ class LayerNormFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------
 # CNN front-end: channels-last BatchNorm2d + residual add + ReLU in two passes each way (csrc/batchnorm.hip)
 # ------------------------------------------------------------------------------------------------
-class BnActFn(torch.autograd.Function):
+class BnActFn(_Fn):
     """y = relu?(batch_norm(x) (+ residual)) for a channels-last NCHW x; same statistics / running-buffer semantics as
     torch.nn.BatchNorm2d (biased batch variance for the normalisation, unbiased for running_var, momentum update in
     training; running statistics in eval).  Returns a channels-last tensor."""
@@ -1091,7 +1114,7 @@ class BnActFn(torch.autograd.Function):
             mean, rstd = running_mean, torch.rsqrt(running_var + eps)
         _lib.check(lib.rp_bn_apply_fwd(_p(xr), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(rr), _p(y), R, C, 1 if relu else 0,
                                        _st()), "rp_bn_apply_fwd")
-        if any(ctx.needs_input_grad):
+        if _train(ctx):
             # without a residual the ReLU mask is re-evaluated from x in the backward: y is not kept alive for it
             keep_y = y if (relu and residual is not None) else None
             ctx.save_for_backward(xr, keep_y, mean, rstd, gamma, beta)
@@ -1155,7 +1178,7 @@ def bn_act(bn, x, residual=None, relu=True):
                          relu)
 
 
-class GeodesicLossFn(torch.autograd.Function):
+class GeodesicLossFn(_Fn):
     """(mean |tau|, mean |phi|) of the geodesic pose loss as one kernel with exact derivatives (csrc/se3loss.hip): the
     PyTorch formulation costs ~240 tiny launches per step.  Ps, Gs: [B,2,7] fp32 on the GPU."""
 
@@ -1178,7 +1201,7 @@ class GeodesicLossFn(torch.autograd.Function):
         return None, gtr * dmean[0] + grot * dmean[1]
 
 
-class MaxPool3x3s2Fn(torch.autograd.Function):
+class MaxPool3x3s2Fn(_Fn):
     """nn.MaxPool2d(3, 2, 1) on a channels-last tensor (the stem's pool, src/model.py:130): streaming forward that keeps a
     one-byte window position per output, gather backward (csrc/batchnorm.hip)."""
 
@@ -1232,7 +1255,7 @@ STEM_CONV = os.environ.get("RP_STEM_CONV", "1") != "0"      # hand-written stem 
 STEM_STATS = os.environ.get("RP_STEM_STATS", "1") != "0"    # ... with the BatchNorm batch statistics from its epilogue
 
 
-class StemConvFn(torch.autograd.Function):
+class StemConvFn(_Fn):
     """resnet.conv1 (7x7 / 2, pad 3, 3 -> 64, no bias; src/model.py:127) on the zero-framed NHWC image: forward = csrc/conv_stem.hip;
     weight gradient = MIOpen's backward-weights on the same framed buffer (padding 0 there: identical arithmetic); the image itself
     needs no gradient."""
@@ -1266,7 +1289,7 @@ def stem_conv_ok(conv, images):
 FUSE_STEM_POOL = os.environ.get("RP_FUSE_STEM_POOL", "1") != "0"
 
 
-class BnReluPoolFn(torch.autograd.Function):
+class BnReluPoolFn(_Fn):
     """maxpool3x3s2(relu(batch_norm(x))) of the stem (reference src/model.py:127-130) without the two [N,112,112,64] intermediates:
     statistics pass, then ONE pass that normalises, clamps and pools; the backward gathers the pool gradient inside both
     BatchNorm-backward passes.  Bit-identical to BnActFn + MaxPool3x3s2Fn (csrc/batchnorm.hip)."""
@@ -1299,7 +1322,7 @@ class BnReluPoolFn(torch.autograd.Function):
         idx = torch.empty(N, OH, OW, C, device=x.device, dtype=torch.uint8)
         _lib.check(lib.rp_bn_relu_pool_fwd(_p(xr), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(y), ctypes.c_void_p(idx.data_ptr()),
                                            N, H, W, C, _st()), "rp_bn_relu_pool_fwd")
-        if any(ctx.needs_input_grad):
+        if _train(ctx):
             ctx.save_for_backward(xr, idx, mean, rstd, gamma, beta)
             ctx.cfg = (N, C, H, W, bool(training))
         return y.permute(0, 3, 1, 2)

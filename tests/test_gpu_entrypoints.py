@@ -254,7 +254,9 @@ def test_graphed_train_step_matches_the_eager_step():
                 fresh = ViTEss(args).cuda().train()
                 fresh.load_state_dict(net.state_dict())
                 b = fresh(images, Gs, intrinsics=intr.clone())[0].data
-            assert torch.equal(a, b), float((a - b).abs().max())
+            # (a stale pad would show up at the size of the weight updates, >= 1e-4; rounding-level differences between two model
+            # instances come from MIOpen's workspace-dependent solver paths)
+            assert float((a - b).abs().max()) < 5e-6, float((a - b).abs().max())
         else:
             for _ in range(6):
                 gs._fwd_bwd()

@@ -36,8 +36,8 @@ extern "C" {
  * functions this header declares.  rp_abi_version() / rp_abi_export_count() return the values the library was COMPILED with, so a
  * binding (rel_pose_amd/_lib.py parses both macros and counts the declarations) rejects a stale .so at load time instead of
  * failing later on a missing symbol. */
-#define RP_ABI_VERSION 4
-#define RP_ABI_EXPORTS 61
+#define RP_ABI_VERSION 5
+#define RP_ABI_EXPORTS 62
 int rp_abi_version(void);
 int rp_abi_export_count(void);
 const char* rp_target_arch(void);
@@ -240,6 +240,11 @@ int rp_attn_bwd_dkdv(const float* q, const float* k, const float* v, const float
 int rp_attn_bwd_dkdv_ds(const float* q, const float* k, const float* v, const float* dout, const float* lse,
                         const float* delta, float* dk, float* dv, float* ds, int Z, int H, int ldq, int ldk, int ldv, int lddo,
                         int lddk, int lddv, float scale, int bf16, void* stream);
+/* out[z][i][h*64 + d] = sum_j ds[z*H + h][i][j] * b[z ^ b_xor][j][h*64 + d] for the [Z,H,576,576] array a stored-dS pass wrote: the
+ * dQ = dS K half of Attention's autograd (vision_transformer.py:325-329) after rp_attn_bwd_dkdv_ds, and with b_xor = 1 the
+ * dK = dS^T-major x Q(partner image) half of the EMM's (:198-206) after rp_emm_grad_ds.  b / out point at the first of the H*64
+ * columns (row strides ldb / ldo floats, 576 rows per image); one launch for all Z*H problems, dS streamed once from memory. */
+int rp_ds_matmul(const float* ds, const float* b, float* out, int Z, int H, int ldb, int ldo, int b_xor, void* stream);
 int rp_attn_bwd_dq(const float* q, const float* k, const float* v, const float* dout, const float* lse, const float* delta,
                    float* dq, int Z, int H, int ldq, int ldk, int ldv, int lddo, int lddq, float scale, int bf16, void* stream);
 

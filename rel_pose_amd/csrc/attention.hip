@@ -304,7 +304,8 @@ struct AttnBwdP {
   float scale;
   int ZH;
   int kv_xor;   // 1: keys/values (and dK, dV) of problem z live at image z^1 relative to its queries (cross attention)
-  float* ds;    // optional [Z][H][576 q][576 key]: scale * dS written by the dK/dV pass, so dQ = dS K is a plain batched GEMM
+  float* ds;    // optional [Z][H][18 q-blocks][18 key-blocks][16][64]: scale * dS in 32x32 tiles (accumulator image) written by the
+                // dK/dV pass, so dQ = dS K is one streaming rp_ds_matmul
 };
 
 template <int NW, int WPS, bool BF>
@@ -358,10 +359,11 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dkdv_kernel(AttnBwdP p)
       s[r] = pr;
       dp[r] = pr * (dp[r] - Ls[cur][32 + qi]);
     }
-    if (p.ds) {      // 128-byte row segments (32 keys) per register; the dQ pass then needs neither S nor dP again
-      float* dsb = p.ds + ((((long long)zq * p.H + h) * NTOK + t * 32) * NTOK) + k0 + l31;
+    if (p.ds) {      // TILED: tile (query block t, key block) = this wave's register image [16 r][64 lanes], 4 KB contiguous, fully
+      // coalesced 256-byte stores; rp_ds_matmul (below) reads it -- the dQ pass then needs neither S nor dP again
+      float* dsb = p.ds + ((((long long)zq * p.H + h) * NTILE + t) * NTILE + (k0 >> 5)) * 1024 + lane;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) dsb[(long long)acc_row(r, hi) * NTOK] = dp[r] * p.scale;
+      for (int r = 0; r < 16; ++r) dsb[r * 64] = dp[r] * p.scale;
     }
     accum_tile<KST, BF>(Ds[cur], l31, hi, s, dv0, dv1);     // dV^T += dO^T P
     accum_tile<KST, BF>(Qs[cur], l31, hi, dp, dk0, dk1);    // dK^T += Q^T dS
@@ -423,6 +425,196 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dq_kernel(AttnBwdP p) {
     __syncthreads();
   }
   store_ownerT(p.dq + ((long long)z * NTOK + q0 + l31) * p.lddq + h * 64, hi, dq0, dq1, p.scale);
+}
+
+// ------------------------------------------------------------------------------------------------
+// out[z][i][h*64 + d] = sum_j ds[z*H + h][i][j] * b[z ^ b_xor][j][h*64 + d]    (576 x 576 per problem, 64 columns)
+// The second half of the stored-dS backward (dQ = dS K of the attention, dK = dS^T-major x Q of the EMM), as a STREAMING kernel:
+// round 2 ran it as three batched rp_gemm launches per call at 1.95 TB/s of a row-major dS.  dS is now stored TILED by its producers:
+// tile (i-block, j-block) is the producing wave's accumulator image T[r][lane] = dS[i = acc_row(r, lane >> 5)][j = lane & 31], 4 KB
+// contiguous, the 18 j-tiles of an i-block back to back (72 KB).  A wave here owns 32 rows i and takes its dS operand STRAIGHT from
+// memory in MFMA B-operand shape: lane (i = l31, hi) reads the 64 contiguous bytes T[r(i)][32 hh(i) + 16 hi .. + 15] (four 16-byte
+// loads; register e is column j = 16 hi + e), so a wave instruction stays inside one 4 KB tile (DRAM-page and L1 friendly: row-major
+// dS made every lane touch its own 2304-byte-strided line and streamed at 2.4 TB/s), three tiles in flight.  Only the small operand
+// (the 32 x 64 rows of b, L2-resident: 147 KB per problem, problems pinned to an XCD) goes through LDS, shared by the workgroup's
+// waves.  out^T[d][i] += b[j][d] * ds[i][j]: 32 MFMAs per tile, no recompute, one launch for all heads.
+// ------------------------------------------------------------------------------------------------
+struct DsMmP {
+  const float* ds; const float* b; float* out;
+  int H, ldb, ldo, b_xor, ZH;
+  int reverse;      // walk the problems last-to-first: the producer wrote them first-to-last, so the newest tiles may still sit in the
+};                  // 256 MB memory-side cache
+
+// acc^T[d][owner] += sum_r Ts[row0 + r][d] * p[r]: like accum_tile but register r pairs with the CONTIGUOUS row row0 + r (row0 = 16 hi):
+// the owner operand then is 64 contiguous bytes of its memory row per lane
+RP_DEV void accum_rows16(const float* Ts, int l31, int hi, const f32x16& p, f32x16& o0, f32x16& o1) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float* vr = Ts + (16 * hi + r) * 64 + l31;
+    o0 = mfma32(vr[0], p[r], o0);
+    o1 = mfma32(vr[32], p[r], o1);
+  }
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 4) void ds_matmul_kernel(DsMmP p) {
+  constexpr int NT = NW * 64;
+  constexpr int KT = 32;                                  // columns of ds (= rows of b) per step
+  constexpr int NSTEP = NTOK / KT;
+  constexpr int NPF = (KT * 16 + NT - 1) / NT;            // float4 per thread per b tile
+  __shared__ __attribute__((aligned(16))) float Bs[2][KT * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  int zh, blk;
+  if (!xcd_problem(NTILE / NW, p.ZH, zh, blk)) return;
+  if (p.reverse) zh = p.ZH - 1 - zh;
+  const int h = zh % p.H, z = zh / p.H;
+  const int i0 = (blk * NW + wave) * 32;
+  const float* bb = p.b + (long long)(z ^ p.b_xor) * NTOK * p.ldb + h * 64;
+  // row i = l31 of a tile lives in register r = (i & 3) + 4 (i >> 3) of half-wave hh = (i >> 2) & 1 of the producer's image
+  const float* arow = p.ds + ((long long)zh * NTILE + (i0 >> 5)) * NTILE * 1024 + ((l31 & 3) + 4 * (l31 >> 3)) * 64 + 32 * ((l31 >> 2) & 1) + 16 * hi;
+
+  f32x16 o0 = zero16(), o1 = zero16();
+  float4 bpre[NPF];
+  constexpr int NA = KT / 8;                              // float4 of ds per lane per step
+  float4 a0[NA], a1[NA], a2[NA];
+  auto aload = [&](float4 (&a)[NA], int t) {
+#pragma unroll
+    for (int g = 0; g < NA; ++g) {
+      const float* src = arow + 1024 * ((KT / 32) * t + (g >> 2)) + 4 * (g & 3);
+      a[g] = ld4(src);
+    }
+  };
+  auto bload = [&](int t) {
+#pragma unroll
+    for (int j = 0; j < NPF; ++j) {
+      int f = tid + NT * j;
+      if ((KT * 16) % NT != 0) f = min(f, KT * 16 - 1);
+      bpre[j] = ld4(bb + (long long)(t * KT + (f >> 4)) * p.ldb + (f & 15) * 4);
+    }
+  };
+  auto bstore = [&](float* dst) {
+#pragma unroll
+    for (int j = 0; j < NPF; ++j) {
+      int f = tid + NT * j;
+      if ((KT * 16) % NT != 0) f = min(f, KT * 16 - 1);
+      st4(dst + f * 4, bpre[j]);
+    }
+  };
+  bload(0);
+  aload(a0, 0);
+  aload(a1, 1);
+  bstore(Bs[0]);
+  __syncthreads();
+  bload(1);
+  auto step = [&](const float4 (&a)[NA], float4 (&anext)[NA], int t) {
+    const int cur = t & 1;
+    if (t + 2 < NSTEP) aload(anext, t + 2);
+#pragma unroll
+    for (int u = 0; u < KT / 32; ++u) {
+      f32x16 pr;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) { pr[4 * g] = a[4 * u + g].x; pr[4 * g + 1] = a[4 * u + g].y; pr[4 * g + 2] = a[4 * u + g].z; pr[4 * g + 3] = a[4 * u + g].w; }
+      accum_rows16(Bs[cur] + u * 32 * 64, l31, hi, pr, o0, o1);
+    }
+    if (t + 1 < NSTEP) bstore(Bs[cur ^ 1]);
+    __syncthreads();
+    if (t + 2 < NSTEP) bload(t + 2);
+  };
+  for (int t = 0; t < NSTEP; t += 3) {      // NSTEP = 18 or 9: three register sets rotate without copies
+    step(a0, a2, t);
+    step(a1, a0, t + 1);
+    step(a2, a1, t + 2);
+  }
+  store_ownerT(p.out + ((long long)z * NTOK + i0 + l31) * p.ldo + h * 64, hi, o0, o1, 1.0f);
+}
+
+// The same product on v_mfma_f32_16x16x4_f32.  Why: with >= 2 waves per SIMD taking turns MFMA by MFMA (what a short LDS-fed loop at
+// 4-5 waves per SIMD does), v_mfma_f32_32x32x2_f32 issues every ~82 cycles instead of 64 (profiles/README.md "measured ceilings":
+// 103-123 TF at 2-8 waves per SIMD against 148 TF alone), while 16x16x4 holds 152-155 TF at every occupancy -- the 32x32 form above
+// runs 167 us with the dS loads ablated, against 104 us of MFMA work.
+//   out^T[d][i] += b[j][d] ds[i][j]:  A[m = d][k = j] = b  (LDS; lane (d = l & 15, kq = l >> 4) reads b[8 kq + s][16 n + d] at k-step s)
+//                                     B[k = j][n = i] = ds (registers; lane (i = l & 15, kq) holds ds[i][8 kq .. 8 kq + 7], 2 x 16 bytes)
+//   C tile (n = d block, m = i block): lane (i = l & 15, dq = l >> 4), register e = out[i][16 n + 4 dq + e]: 16-byte stores.
+// LDS image of a b tile: row stride 66 floats (8-byte aligned rows, staged with ds_write_b64): rows 8 apart -- the two kq groups of a
+// 32-lane half -- sit 16 banks apart (conflict-free ds_read_b32 with immediate offsets).
+constexpr int BST = 66;     // 8 rows apart = 16 banks apart: the two kq groups of a 32-lane half never share a bank
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 3) void ds_matmul16_kernel(DsMmP p) {
+  constexpr int NT = NW * 64;
+  constexpr int NPF = (512 + NT - 1) / NT;
+  __shared__ __attribute__((aligned(16))) float Bs[2][32 * BST];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+  int zh, blk;
+  if (!xcd_problem(NTILE / NW, p.ZH, zh, blk)) return;
+  if (p.reverse) zh = p.ZH - 1 - zh;
+  const int h = zh % p.H, z = zh / p.H;
+  const int i0 = (blk * NW + wave) * 32;
+  const float* bb = p.b + (long long)(z ^ p.b_xor) * NTOK * p.ldb + h * 64;
+  // row i = 16 m + l15 of the tile lives in register r = (i & 3) + 4 (i >> 3), half-wave hh = (i >> 2) & 1 of the producer's image;
+  // m = 1 adds 16 to i: r + 8, same hh
+  const float* arow = p.ds + ((long long)zh * NTILE + (i0 >> 5)) * NTILE * 1024 + ((l15 & 3) + 4 * (l15 >> 3)) * 64 + 32 * ((l15 >> 2) & 1) + 8 * kq;
+
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float4 bpre[NPF];
+  float4 a0[4], a1[4], a2[4];      // [2 m][2 halves of 8 floats]
+  auto aload = [&](float4 (&a)[4], int t) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      a[2 * m] = ld4(arow + 1024 * t + 512 * m);
+      a[2 * m + 1] = ld4(arow + 1024 * t + 512 * m + 4);
+    }
+  };
+  auto bstore = [&](float* dst) {
+#pragma unroll
+    for (int j = 0; j < NPF; ++j) {
+      int f = tid + NT * j;
+      if (512 % NT != 0) f = min(f, 511);
+      float2* d2 = reinterpret_cast<float2*>(dst + (f >> 4) * BST + (f & 15) * 4);
+      d2[0] = make_float2(bpre[j].x, bpre[j].y);
+      d2[1] = make_float2(bpre[j].z, bpre[j].w);
+    }
+  };
+  tile_gload<NT>(bb, p.ldb, tid, bpre);
+  aload(a0, 0);
+  aload(a1, 1);
+  bstore(Bs[0]);
+  __syncthreads();
+  tile_gload<NT>(bb + (long long)32 * p.ldb, p.ldb, tid, bpre);
+  const int brow = 8 * kq * BST + l15;        // this lane's column of LDS row j = 8 kq (k-step s adds s rows)
+  auto step = [&](const float4 (&a)[4], float4 (&anext)[4], int t) {
+    const float* B = Bs[t & 1];
+    if (t + 2 < NTILE) aload(anext, t + 2);
+    const float av[2][8] = {{a[0].x, a[0].y, a[0].z, a[0].w, a[1].x, a[1].y, a[1].z, a[1].w},
+                            {a[2].x, a[2].y, a[2].z, a[2].w, a[3].x, a[3].y, a[3].z, a[3].w}};
+#pragma unroll
+    for (int s_ = 0; s_ < 8; ++s_) {
+      const float* br = B + brow + s_ * BST;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const float bv = br[16 * n];
+        acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av[0][s_], acc[0][n], 0, 0, 0);
+        acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av[1][s_], acc[1][n], 0, 0, 0);
+      }
+    }
+    if (t + 1 < NTILE) bstore(Bs[(t & 1) ^ 1]);
+    __syncthreads();
+    if (t + 2 < NTILE) tile_gload<NT>(bb + (long long)(t + 2) * 32 * p.ldb, p.ldb, tid, bpre);
+  };
+  for (int t = 0; t < NTILE; t += 3) {
+    step(a0, a2, t);
+    step(a1, a0, t + 1);
+    step(a2, a1, t + 2);
+  }
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    float* orow = p.out + ((long long)z * NTOK + i0 + 16 * m + l15) * p.ldo + h * 64 + 4 * kq;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) st4(orow + 16 * n, make_float4(acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]));
+  }
 }
 
 }  // namespace
@@ -506,4 +698,21 @@ extern "C" int rp_attn_bwd_dq(const float* q, const float* k, const float* v, co
                               const float* delta, float* dq, int Z, int H, int ldq, int ldk, int ldv, int lddo, int lddq,
                               float scale, int bf16, void* stream) {
   return attn_bwd_impl(q, k, v, dout, lse, delta, dq, nullptr, nullptr, Z, H, ldq, ldk, ldv, lddo, lddq, 4, 4, scale, 2, bf16, stream);
+}
+
+// out[z][i][h*64 + d] = sum_j ds[z*H + h][i][j] * b[z ^ b_xor][j][h*64 + d]: the product that follows a stored-dS pass
+// (rp_attn_bwd_dkdv_ds: dQ = ds K;  rp_emm_grad_ds: dK = ds Q of the partner image, b_xor = 1), one launch for all Z*H problems
+extern "C" int rp_ds_matmul(const float* ds, const float* b, float* out, int Z, int H, int ldb, int ldo, int b_xor, void* stream) {
+  if (Z <= 0 || H <= 0 || !ds || !b || !out || (b_xor & ~1) || (b_xor && (Z & 1))) return RP_EBADSHAPE;
+  if ((ldb | ldo) & 3) return RP_EALIGN;
+  const char* rv = getenv("RP_DSMM_REV");
+  DsMmP p{ds, b, out, H, ldb, ldo, b_xor, Z * H, rv ? rv[0] - '0' : 1};
+  // RP_DSMM=16: the v_mfma_f32_16x16x4_f32 form (A/B aid; both run ~200 us per 128 images: the stream of fragment-shaped dS reads, not
+  // the MFMA form, is what bounds this kernel -- profiles/r3_ds_matmul.txt)
+  const char* ov = getenv("RP_DSMM");
+  hipStream_t st = (hipStream_t)stream;
+  if (ov && ov[0] == '1') hipLaunchKernelGGL((ds_matmul16_kernel<3>), dim3(xcd_grid(NTILE / 3, Z * H)), dim3(192), 0, st, p);
+  else hipLaunchKernelGGL((ds_matmul_kernel<3>), dim3(xcd_grid(NTILE / 3, Z * H)), dim3(192), 0, st, p);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
 }

@@ -34,8 +34,9 @@ struct EmmP {
   int H; float scale; int swap; int ZH;
   int single;            // use_single_softmax (vision_transformer.py:201-203): A = softmax(S, -1) only
   const float* x_left;   // cross_features (:218-220): left operand of F = X_L^T A X comes from the partner image
-  float* ds;             // emm_grad, owner = query pass: optional [Z][H][576 j][576 i] = scale * dS_ij, so the key-side gradient
-                         // dk = scale dS^T q is a batched rp_gemm instead of a second pass that recomputes S and dA
+  float* ds;             // emm_grad, owner = query pass: optional [Z][H][18 j-blocks][18 i-blocks][16][64] = scale * dS_ij in 32x32 tiles
+                         // (the MFMA accumulator image of the tile), so the key-side gradient dk = scale dS^T q is one rp_ds_matmul
+                         // instead of a second pass that recomputes S and dA
 };
 
 template <int NTH>
@@ -349,10 +350,11 @@ __global__ __launch_bounds__(GT, 2) void emm_grad_kernel(EmmP p) {
         s[r] = 2.0f * eo * el * da[r] - eo * g_o - el * Ll[cur][32 + li];
       }
     }
-    if (p.ds) {      // (owner = query pass only) 128-byte row segments: row = loop index j, 32 consecutive owners i per register
-      float* dsb = p.ds + (zh * NTOK + t * 32) * NTOK + o0 + l31;
+    if (p.ds) {      // (owner = query pass only) TILED: tile (loop block t, owner block) = this wave's register image [16 r][64 lanes],
+      // 4 KB contiguous, rows = loop index j, columns = owners i: fully coalesced 256-byte stores; rp_ds_matmul reads it (attention.hip)
+      float* dsb = p.ds + ((zh * (NTOK / 32) + t) * (NTOK / 32) + (o0 >> 5)) * 1024 + lane;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) dsb[(long long)acc_row(r, hi) * NTOK] = s[r] * p.scale;
+      for (int r = 0; r < 16; ++r) dsb[r * 64] = s[r] * p.scale;
     }
     // d owner^T[d][owner] += sum_loop other[loop][d] dS^T[loop][owner]
     if (BF) {

@@ -530,6 +530,17 @@ def attn_fwd(qkv, Z, stats_only=False, q_off=0, k_off=DIM, v_off=2 * DIM, q_xor=
 
 ATTN_BWD_STORE_DS = os.environ.get("RP_ATTN_DS", "1") == "1"
 EMM_BWD_STORE_DS = os.environ.get("RP_EMM_DS", "1") == "1"
+# the product that consumes a stored dS: rp_ds_matmul (streaming kernel, one launch for all heads) or batched rp_gemm launches (round 2)
+DS_MATMUL = os.environ.get("RP_DS_MATMUL", "1") == "1"
+
+
+def ds_matmul(ds, b_base, ldb, out_base, ldo, Z, b_xor=0):
+    """out[z][i][h*64+d] = sum_j ds[z,h,i,j] b[z^b_xor][j][h*64+d]; b_base / out_base: device addresses of the first column."""
+    lib = _lib.load()
+    _chk(ds)
+    with timed("ds_matmul", 2.0 * Z * HEADS * N_TOK * N_TOK * 64, 4.0 * Z * HEADS * N_TOK * (N_TOK + 128)):
+        _lib.check(lib.rp_ds_matmul(_p(ds), ctypes.c_void_p(b_base), ctypes.c_void_p(out_base), Z, HEADS, ldb, ldo, b_xor, _st()),
+                   "rp_ds_matmul")
 
 
 def attn_bwd(qkv, o, lse, do, Z, fork=None, kv_xor=0):
@@ -557,6 +568,9 @@ def attn_bwd(qkv, o, lse, do, Z, fork=None, kv_xor=0):
         _lib.check(lib.rp_attn_bwd_dkdv_ds(P(b), P(b + 4 * DIM), P(b + 8 * DIM), _p(do), _p(lse), _p(delta), P(d + 4 * DIM),
                                            P(d + 8 * DIM), _p(ds), Z, HEADS, ld, ld, ld, DIM, ld, ld, sc, ATTN_BF16, _st()),
                    "rp_attn_bwd_dkdv_ds")
+        if DS_MATMUL and not ATTN_BF16:
+            ds_matmul(ds, b + 4 * DIM, ld, d, ld, Z)                  # dQ = dS K, one streaming launch
+            return dqkv
         dsf, qf, df = ds.view(-1), qkv.view(-1), dqkv.view(-1)
         per = N_TOK * N_TOK
         for h in range(HEADS):
@@ -700,7 +714,9 @@ def emm_backward(qkv, x, t, rlse, clse, df, Z, single=False, cross=False):
                                       HEADS, scale, sg, ATTN_BF16, _st()), "rp_emm_grad_ds")
         dsf, qf, df = ds.view(-1), qkv.view(-1), dqkv.view(-1)
         per, img = N_TOK * N_TOK, N_TOK * ld
-        for h in range(HEADS):
+        if DS_MATMUL and not ATTN_BF16:           # dk_z = dS_z (key-major) x q_{z^1}: one streaming launch
+            ds_matmul(ds, qkv.data_ptr(), ld, dqkv.data_ptr() + 4 * DIM, ld, Z, b_xor=1)
+        for h in (range(HEADS) if not (DS_MATMUL and not ATTN_BF16) else ()):
             for e in (0, 1):                      # problems z = 2b + e take their queries from image z ^ 1
                 gemm(dsf[(e * HEADS + h) * per:], qf[(1 - e) * img + 64 * h:], N_TOK, 64, N_TOK, b_layout=1, lda=N_TOK, ldb=ld,
                      out=df[e * img + DIM + 64 * h:], ldc=ld, split_k=1, batch=Z // 2,

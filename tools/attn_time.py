@@ -38,3 +38,11 @@ tt, f = ops.emm_apply(qkv, X, rlse, clse, Z)
 df = torch.randn(Z, 3, 96, 96, device="cuda") * 0.01
 t = timeit(lambda: ops.emm_backward(qkv, X, tt, rlse, clse, df, Z), n=20)
 print("emm_backward(all) %8.1f us" % t)
+import subprocess
+if len(sys.argv) == 1:
+    for v, r in (("32", "0"), ("32", "1"), ("16", "1")):
+        subprocess.run([sys.executable, __file__, "x"], env=dict(os.environ, RP_DSMM=v, RP_DSMM_REV=r))
+else:
+    ta = timeit(lambda: ops.attn_bwd(qkv, o, lse, do, Z), n=30)
+    te = timeit(lambda: ops.emm_backward(qkv, X, tt, rlse, clse, df, Z), n=20)
+    print("RP_DSMM=%s REV=%s: attn_bwd %8.1f us   emm_backward %8.1f us" % (os.environ["RP_DSMM"], os.environ["RP_DSMM_REV"], ta, te))

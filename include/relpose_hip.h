@@ -36,8 +36,8 @@ extern "C" {
  * functions this header declares.  rp_abi_version() / rp_abi_export_count() return the values the library was COMPILED with, so a
  * binding (rel_pose_amd/_lib.py parses both macros and counts the declarations) rejects a stale .so at load time instead of
  * failing later on a missing symbol. */
-#define RP_ABI_VERSION 5
-#define RP_ABI_EXPORTS 62
+#define RP_ABI_VERSION 6
+#define RP_ABI_EXPORTS 64
 int rp_abi_version(void);
 int rp_abi_export_count(void);
 const char* rp_target_arch(void);
@@ -101,6 +101,10 @@ typedef struct RpGemm {
    * reduce): bench.py's per-launch timing of one kernel instance.  NULL: nothing recorded. */
   void* ev_start;
   void* ev_stop;
+  int defer_reduce; /* split_k > 1 with no epilogue operands only: launch the main kernel and leave the partial slabs in `workspace`
+                     * (which the caller then keeps alive and private to this call); the caller finishes C later with ONE
+                     * rp_splitk_reduce_multi over several such calls -- the four weight-gradient GEMMs of a transformer block end in
+                     * one reduce launch instead of four */
 } RpGemm;
 
 /* hipEvent helpers for ev_start / ev_stop (so that a ctypes host needs no second library): create / destroy / elapsed ms */
@@ -109,6 +113,24 @@ void rp_event_destroy(void* ev);
 float rp_event_elapsed_ms(void* start, void* stop);
 int rp_gemm(const RpGemm* g, void* stream);
 size_t rp_gemm_workspace_bytes(int M, int N, int split_k);
+/* finish up to RP_SPLITK_MAX deferred split-K products in one launch: C[m][n] (trans_c: C[n*ldc + m]) = sum_z ws[z][m][n], summed in
+ * the same fixed order as rp_gemm's own reduce (bit-identical results) */
+#define RP_SPLITK_MAX 8
+typedef struct RpSplitkTask {
+  const float* ws;
+  float* C;
+  int M, N, ldc, split_k, trans_c;
+} RpSplitkTask;
+int rp_splitk_reduce_multi(const RpSplitkTask* tasks, int n, void* stream);
+/* up to RP_TRANSPOSE_MAX small transposes dst[c][r] = src[r][c] (row-major, contiguous) in one launch: the W^T copies the
+ * row-resident input-gradient kernels want (rp_linear_rows192 on the transposed weight, rp_mlp_fused_bwd) */
+#define RP_TRANSPOSE_MAX 24
+typedef struct RpTransposeTask {
+  const float* src;
+  float* dst;
+  int rows, cols;
+} RpTransposeTask;
+int rp_transpose_multi(const RpTransposeTask* tasks, int n, void* stream);
 
 
 /* ---------------------------------------------------------------------------------------------
@@ -235,8 +257,10 @@ int rp_attn_bwd_cross(const float* q, const float* k, const float* v, const floa
 int rp_attn_bwd_dkdv(const float* q, const float* k, const float* v, const float* dout, const float* lse,
                      const float* delta, float* dk, float* dv, int Z, int H, int ldq, int ldk, int ldv, int lddo, int lddk,
                      int lddv, float scale, int bf16, void* stream);
-/* dK/dV pass that also stores ds[z][h][i][j] = scale * dS_ij ([Z,H,576,576] floats): dQ = ds K is then one batched rp_gemm per
- * head (M=576, N=64, K=576, b_layout 1) instead of the dQ pass, which would recompute S and dP (5 executed GEMMs instead of 7) */
+/* dK/dV pass that also stores scale * dS ([Z,H,576,576] floats) TILED: ds[z][h][i >> 5][j >> 5][r][lane] with, inside a 32x32 tile,
+ * i & 31 = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) and j & 31 = lane & 31 (the producing wave's MFMA accumulator image: 4 KB contiguous per
+ * tile, coalesced 256-byte stores).  dQ = ds K is then ONE rp_ds_matmul instead of the dQ pass, which would recompute S and dP
+ * (5 executed GEMMs instead of 7) */
 int rp_attn_bwd_dkdv_ds(const float* q, const float* k, const float* v, const float* dout, const float* lse,
                         const float* delta, float* dk, float* dv, float* ds, int Z, int H, int ldq, int ldk, int ldv, int lddo,
                         int lddk, int lddv, float scale, int bf16, void* stream);
@@ -280,8 +304,9 @@ int rp_rowdot96(const float* a, const float* b, float* out, long long rows, void
 int rp_emm_grad(const float* qkv, int ldqkv, const float* x, const float* w, const float* rlse, const float* clse,
                 const float* rho, const float* gamma, float* dqkv, int Z, int H, float scale, int swap, int single,
                 int bf16, void* stream);
-/* the owner = query pass (swap = 0) that also stores ds[z][h][j][i] = scale * dS_ij ([Z,H,576,576] floats, key index major):
- * the key-side gradient dk_z = ds_z q_{z^1} is then a batched rp_gemm per head and pair parity instead of the swap = 1 pass */
+/* the owner = query pass (swap = 0) that also stores scale * dS_ij ([Z,H,576,576] floats) key index major and TILED like
+ * rp_attn_bwd_dkdv_ds (rows = keys j, columns = queries i): the key-side gradient dk_z = ds_z q_{z^1} is then one
+ * rp_ds_matmul(b_xor = 1) instead of the swap = 1 pass */
 int rp_emm_grad_ds(const float* qkv, int ldqkv, const float* x, const float* w, const float* rlse, const float* clse,
                    const float* rho, const float* gamma, float* dqkv, float* ds, int Z, int H, float scale, int single,
                    int bf16, void* stream);

@@ -41,14 +41,24 @@ class RpGemm(Structure):
                 ("aux", c_void_p), ("residual", c_void_p), ("trans_c", c_int), ("precision", c_int),
                 ("colsum_part", c_void_p),
                 ("ln_x", c_void_p), ("ln_mean", c_void_p), ("ln_rstd", c_void_p), ("ln_gamma", c_void_p), ("ln_part", c_void_p),
-                ("ev_start", c_void_p), ("ev_stop", c_void_p)]
+                ("ev_start", c_void_p), ("ev_stop", c_void_p), ("defer_reduce", c_int)]
 
 
 class RpColsumTask(Structure):
     _fields_ = [("in_", c_void_p), ("rows", c_int), ("cols", c_int), ("ld", c_int), ("out", c_void_p)]
 
 
+class RpSplitkTask(Structure):
+    _fields_ = [("ws", c_void_p), ("C", c_void_p), ("M", c_int), ("N", c_int), ("ldc", c_int), ("split_k", c_int), ("trans_c", c_int)]
+
+
+class RpTransposeTask(Structure):
+    _fields_ = [("src", c_void_p), ("dst", c_void_p), ("rows", c_int), ("cols", c_int)]
+
+
 RP_COLSUM_MAX = 8
+RP_SPLITK_MAX = 8
+RP_TRANSPOSE_MAX = 24
 P, I, F, L = c_void_p, c_int, c_float, c_longlong
 _SIGS = {
     "rp_abi_version": (c_int, []),
@@ -56,6 +66,8 @@ _SIGS = {
     "rp_target_arch": (c_char_p, []),
     "rp_gemm": (c_int, [POINTER(RpGemm), P]),
     "rp_gemm_workspace_bytes": (c_size_t, [I, I, I]),
+    "rp_splitk_reduce_multi": (c_int, [POINTER(RpSplitkTask), I, P]),
+    "rp_transpose_multi": (c_int, [POINTER(RpTransposeTask), I, P]),
     "rp_maxpool3x3s2_fwd": (c_int, [P, P, P, I, I, I, I, P]),
     "rp_maxpool3x3s2_bwd": (c_int, [P, P, P, I, I, I, I, P]),
     "rp_geodesic_loss": (c_int, [P, P, P, P, P, I, P]),

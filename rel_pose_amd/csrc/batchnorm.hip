@@ -168,39 +168,49 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
   }
 }
 
-// stage 2: a block takes 16 channels x 16 lanes; each lane sums every 16th block partial, lanes are combined in fixed order
-// (all in double).  MODE 0: mean, rstd (+ running statistics update).  MODE 1: dbeta, dgamma and the two means of the dx pass.
+// stage 2: a block takes 16 channels x 64 lanes (1024 threads); lane l sums block partials l, l + 64, ... (<= 16 of them: all loads
+// independent and in flight together -- the round-2 form walked 64 partials per lane behind each other and took 11 us, 26 times per
+// step), then the 64 lane sums of a channel are combined through LDS in a fixed order (8 x 8), all in double.
+// MODE 0: mean, rstd (+ running statistics update).  MODE 1: dbeta, dgamma and the two means of the dx pass.
 template <int MODE>
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ partial, int nblk, int C, long long R,
-                                                          float* __restrict__ o0, float* __restrict__ o1,
-                                                          float* __restrict__ run_mean, float* __restrict__ run_var,
-                                                          float momentum, float eps, float* __restrict__ c12,
-                                                          const float* __restrict__ pivot) {
-  __shared__ double red[2][16][16];
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const double* __restrict__ partial, int nblk, int C, long long R,
+                                                           float* __restrict__ o0, float* __restrict__ o1,
+                                                           float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                           float momentum, float eps, float* __restrict__ c12,
+                                                           const float* __restrict__ pivot) {
+  __shared__ double red[2][64][16];
   const int cl = threadIdx.x & 15, lane = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl;
   double a = 0.0, b = 0.0;
   if (c < C) {
-    double a1 = 0.0, b1 = 0.0;
-    int k = lane;
-    for (; k + 16 < nblk; k += 32) {          // two independent chains
+    double av[16], bv[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int k = lane + 64 * j;
+      const bool ok = k < nblk;
+      const long long off = (long long)(ok ? k : 0) * 2 * C + c;
+      av[j] = ok ? partial[off] : 0.0;
+      bv[j] = ok ? partial[off + C] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { a += av[j]; b += bv[j]; }
+    for (int k = lane + 1024; k < nblk; k += 64) {          // (more than 1024 partials never happens with bn_rows_per_block)
       a += partial[(long long)k * 2 * C + c];
       b += partial[(long long)k * 2 * C + C + c];
-      a1 += partial[(long long)(k + 16) * 2 * C + c];
-      b1 += partial[(long long)(k + 16) * 2 * C + C + c];
     }
-    if (k < nblk) {
-      a += partial[(long long)k * 2 * C + c];
-      b += partial[(long long)k * 2 * C + C + c];
-    }
-    a += a1;
-    b += b1;
   }
   red[0][lane][cl] = a;
   red[1][lane][cl] = b;
   __syncthreads();
+  if (lane < 8) {
+    a = red[0][lane][cl]; b = red[1][lane][cl];
+    for (int l = lane + 8; l < 64; l += 8) { a += red[0][l][cl]; b += red[1][l][cl]; }
+  }
+  __syncthreads();
+  if (lane < 8) { red[0][lane][cl] = a; red[1][lane][cl] = b; }
+  __syncthreads();
   if (lane != 0 || c >= C) return;
-  for (int l = 1; l < 16; ++l) { a += red[0][l][cl]; b += red[1][l][cl]; }
+  for (int l = 1; l < 8; ++l) { a += red[0][l][cl]; b += red[1][l][cl]; }
   if (MODE == 0) {
     const double md = a / (double)R;                 // mean of (x - pivot)
     double var = b / (double)R - md * md;
@@ -302,7 +312,7 @@ extern "C" int rp_bn_stats(const float* x, long long R, int C, double* partial, 
   hipLaunchKernelGGL((bn_reduce_kernel<0, false>), dim3(nblk), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                      nullptr, partial, R, C, rpb, 0, PoolSrc{});
   RP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3((C + 15) / 16), dim3(256), 0, st, (const double*)partial, nblk, C, R, mean,
+  hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3((C + 15) / 16), dim3(1024), 0, st, (const double*)partial, nblk, C, R, mean,
                      rstd, running_mean, running_var, momentum, eps, nullptr, x);
   RP_CHECK_LAUNCH();
   return RP_OK;
@@ -315,7 +325,7 @@ extern "C" int rp_bn_stats_from_partials(const double* partial, int nblk, long l
                                          void* stream) {
   if (int e = bn_check(R, C)) return e;
   if (nblk <= 0 || !partial || !pivot) return RP_EBADSHAPE;
-  hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, partial, nblk, C, R, mean, rstd,
+  hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3((C + 15) / 16), dim3(1024), 0, (hipStream_t)stream, partial, nblk, C, R, mean, rstd,
                      running_mean, running_var, momentum, eps, nullptr, pivot);
   RP_CHECK_LAUNCH();
   return RP_OK;
@@ -341,7 +351,7 @@ extern "C" int rp_bn_bwd(const float* dy, const float* y, const float* x, const 
   hipLaunchKernelGGL((bn_reduce_kernel<1, false>), dim3(nblk), dim3(256), 0, st, x, dy, y, mean, rstd, gamma, beta, dres, partial, R, C, rpb,
                      relu, PoolSrc{});
   RP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3((C + 15) / 16), dim3(256), 0, st, (const double*)partial, nblk, C, R, dbeta,
+  hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3((C + 15) / 16), dim3(1024), 0, st, (const double*)partial, nblk, C, R, dbeta,
                      dgamma, nullptr, nullptr, 0.f, 0.f, c12, nullptr);
   RP_CHECK_LAUNCH();
   const long long n4 = R * C / 4;
@@ -595,7 +605,7 @@ extern "C" int rp_bn_relu_pool_bwd(const float* dp, const unsigned char* idx, co
                        H, W, ps.OH, ps.OW);
   }
   RP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3((C + 15) / 16), dim3(256), 0, st, (const double*)partial, nblk, C, R, dbeta,
+  hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3((C + 15) / 16), dim3(1024), 0, st, (const double*)partial, nblk, C, R, dbeta,
                      dgamma, nullptr, nullptr, 0.f, 0.f, c12, nullptr);
   RP_CHECK_LAUNCH();
   const long long n4 = R * C / 4;

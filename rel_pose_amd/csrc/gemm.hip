@@ -485,6 +485,10 @@ extern "C" int rp_gemm(const RpGemm* g, void* stream) {
   else launch_layouts<0>(p, nz, g->a_layout, g->b_layout, tm, tn, st);
   if (g->ev_stop) (void)hipEventRecord((hipEvent_t)g->ev_stop, st);
   RP_CHECK_LAUNCH();
+  if (split > 1 && g->defer_reduce) {
+    if (g->bias || g->pre_out || g->act || g->dact || g->aux || g->residual) return RP_EUNSUPPORTED;
+    return RP_OK;                   // the caller finishes C with rp_splitk_reduce_multi
+  }
   if (split > 1) {
     GemmP r = p;
     r.C = g->C;
@@ -493,6 +497,120 @@ extern "C" int rp_gemm(const RpGemm* g, void* stream) {
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, r, (const float*)g->workspace);
     RP_CHECK_LAUNCH();
   }
+  return RP_OK;
+}
+
+// ---- deferred split-K reduces of several products in one launch (same arithmetic and order as splitk_reduce_kernel) ----------
+namespace {
+struct SplitkMultiP {
+  const float* ws[RP_SPLITK_MAX];
+  float* C[RP_SPLITK_MAX];
+  int M[RP_SPLITK_MAX], N[RP_SPLITK_MAX], ldc[RP_SPLITK_MAX], split[RP_SPLITK_MAX], trans[RP_SPLITK_MAX];
+  int blk_end[RP_SPLITK_MAX];
+  int n;
+};
+__global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(SplitkMultiP p) {
+  __shared__ float4 part[4][64];
+  int t = 0;
+  while (t + 1 < p.n && (int)blockIdx.x >= p.blk_end[t]) ++t;
+  const int local = blockIdx.x - (t ? p.blk_end[t - 1] : 0);
+  const float* ws = p.ws[t];
+  const int N = p.N[t], split = p.split[t];
+  const long long total = (long long)p.M[t] * N;
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const long long idx = ((long long)local * 64 + col) * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (idx < total) {
+    int z = grp;
+#pragma unroll 4
+    for (; z < split; z += 4) {
+      const float4 v = ld4(ws + z * total + idx);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  }
+  part[grp][col] = s;
+  __syncthreads();
+  if (grp != 0 || idx >= total) return;
+#pragma unroll
+  for (int g = 1; g < 4; ++g) {
+    const float4 v = part[g][col];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  const int m = (int)(idx / N), n = (int)(idx % N);
+  float* C = p.C[t];
+  const int ldc = p.ldc[t];
+  if (p.trans[t]) {
+    C[(long long)n * ldc + m] = s.x; C[(long long)(n + 1) * ldc + m] = s.y;
+    C[(long long)(n + 2) * ldc + m] = s.z; C[(long long)(n + 3) * ldc + m] = s.w;
+  } else {
+    st4(C + (long long)m * ldc + n, s);
+  }
+}
+}  // namespace
+
+extern "C" int rp_splitk_reduce_multi(const RpSplitkTask* tasks, int n, void* stream) {
+  if (!tasks || n <= 0 || n > RP_SPLITK_MAX) return RP_EBADSHAPE;
+  SplitkMultiP p{};
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    const RpSplitkTask& t = tasks[i];
+    if (!t.ws || !t.C || t.M <= 0 || t.N <= 0 || (t.N & 3) || t.split_k < 2) return RP_EBADSHAPE;
+    if ((t.ldc & 3) || (((uintptr_t)t.ws | (uintptr_t)t.C) & 15)) return RP_EALIGN;
+    p.ws[i] = t.ws; p.C[i] = t.C; p.M[i] = t.M; p.N[i] = t.N; p.ldc[i] = t.ldc; p.split[i] = t.split_k; p.trans[i] = t.trans_c ? 1 : 0;
+    blocks += (int)(((long long)t.M * t.N / 4 + 63) / 64);
+    p.blk_end[i] = blocks;
+  }
+  p.n = n;
+  hipLaunchKernelGGL(splitk_reduce_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
+// ---- several small transposes in one launch (32x32 tiles through LDS) -------------------------------------------------------
+namespace {
+struct TransposeMultiP {
+  const float* src[RP_TRANSPOSE_MAX];
+  float* dst[RP_TRANSPOSE_MAX];
+  int rows[RP_TRANSPOSE_MAX], cols[RP_TRANSPOSE_MAX], tx[RP_TRANSPOSE_MAX], blk_end[RP_TRANSPOSE_MAX];
+  int n;
+};
+__global__ __launch_bounds__(256) void transpose_multi_kernel(TransposeMultiP p) {
+  __shared__ float tile[32][33];
+  int t = 0;
+  while (t + 1 < p.n && (int)blockIdx.x >= p.blk_end[t]) ++t;
+  const int local = blockIdx.x - (t ? p.blk_end[t - 1] : 0);
+  const int bx = local % p.tx[t], by = local / p.tx[t];
+  const int rows = p.rows[t], cols = p.cols[t];
+  const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = by * 32 + ly + 8 * k, c = bx * 32 + lx;
+    if (r < rows && c < cols) tile[ly + 8 * k][lx] = p.src[t][(long long)r * cols + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = bx * 32 + ly + 8 * k, r = by * 32 + lx;
+    if (r < rows && c < cols) p.dst[t][(long long)c * rows + r] = tile[lx][ly + 8 * k];
+  }
+}
+}  // namespace
+
+extern "C" int rp_transpose_multi(const RpTransposeTask* tasks, int n, void* stream) {
+  if (!tasks || n <= 0 || n > RP_TRANSPOSE_MAX) return RP_EBADSHAPE;
+  TransposeMultiP p{};
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    const RpTransposeTask& t = tasks[i];
+    if (!t.src || !t.dst || t.rows <= 0 || t.cols <= 0) return RP_EBADSHAPE;
+    p.src[i] = t.src; p.dst[i] = t.dst; p.rows[i] = t.rows; p.cols[i] = t.cols;
+    p.tx[i] = (t.cols + 31) / 32;
+    blocks += p.tx[i] * ((t.rows + 31) / 32);
+    p.blk_end[i] = blocks;
+  }
+  p.n = n;
+  hipLaunchKernelGGL(transpose_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  RP_CHECK_LAUNCH();
   return RP_OK;
 }
 

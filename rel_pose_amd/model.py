@@ -90,6 +90,10 @@ class ViTEss(nn.Module):
         """preprocessing + CNN front-end -> [2B,192,24,24] (PyTorch-ROCm / MIOpen: 'next' row 8f-1)."""
         if intrinsics is not None:
             intrinsics = self.update_intrinsics(images.shape, intrinsics)
+        with ops.batches_tracked_batch():
+            return self._cnn_layers(images), intrinsics
+
+    def _cnn_layers(self, images):
         r = self.resnet
         if ops.stem_conv_ok(r.conv1, images):
             # BGR->RGB, /255, mean/std, nearest 224 (one bit-exact HIP kernel) written inside the stem's zero padding; hand-written conv1
@@ -103,7 +107,7 @@ class ViTEss(nn.Module):
             c1, stats = ops.conv2d(r.conv1, ops.preprocess(images)), None
         x = ops.bn_relu_maxpool(r.bn1, r.maxpool, c1, stats)                    # stem: BatchNorm + ReLU + pool, one pass each way
         x = r.layer2(r.layer1(x))
-        return self.extractor_final_conv(x), intrinsics
+        return self.extractor_final_conv(x)
 
     def extract_features(self, images, intrinsics=None):
         """tokens [2B,576,192] WITHOUT pos_embed (reference return value, src/model.py:136-143)."""

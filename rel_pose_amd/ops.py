@@ -250,6 +250,51 @@ class timed:
 
 TIMER = None
 
+# ------------------------------------------------------------------------------------------------
+# deferred split-K reduces: inside `with splitk_batch():` every plain split-K product (the weight-gradient GEMMs) launches only its
+# main kernel into a private slab region and the block ends with ONE rp_splitk_reduce_multi (bit-identical to the per-GEMM reduce).
+# The outputs are only FILLED at exit: return them, do not compute with them inside the block.
+# ------------------------------------------------------------------------------------------------
+SPLITK_BATCHING = os.environ.get("RP_SPLITK_BATCH", "1") == "1"
+_SPLITK_BATCH = None
+_ARENA = {}
+
+
+def _arena_take(nbytes, device, state):
+    """nbytes (rounded to 256) of a grow-only per-(device, stream) arena; `state` = [offset] of the enclosing batch."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    n4 = (nbytes + 255) // 256 * 64
+    buf = _ARENA.get(key)
+    if buf is None or buf.numel() < state[0] + n4:
+        # (an arena outgrown mid-batch is replaced; the slabs already handed out stay alive through the views the tasks hold)
+        buf = _ARENA[key] = torch.empty(max(2 * (state[0] + n4), 16 << 20), device=device, dtype=torch.float32)
+        state[0] = 0
+    out = buf[state[0]:state[0] + n4]
+    state[0] += n4
+    return out
+
+
+class splitk_batch:
+    def __enter__(self):
+        global _SPLITK_BATCH
+        st = torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else None
+        self.prev, _SPLITK_BATCH = _SPLITK_BATCH, (([], [0], st) if SPLITK_BATCHING else None)
+        return self
+
+    def __exit__(self, et, ev, tb):
+        global _SPLITK_BATCH
+        cur, _SPLITK_BATCH = _SPLITK_BATCH, self.prev
+        if et is None and cur and cur[0]:
+            tasks = cur[0]
+            lib = _lib.load()
+            for i in range(0, len(tasks), _lib.RP_SPLITK_MAX):
+                chunk = tasks[i:i + _lib.RP_SPLITK_MAX]
+                arr = (_lib.RpSplitkTask * len(chunk))()
+                for a, (ws, out, M, N, ldc, sk, tr) in zip(arr, chunk):
+                    a.ws, a.C, a.M, a.N, a.ldc, a.split_k, a.trans_c = ws.data_ptr(), out.data_ptr(), M, N, ldc, sk, 1 if tr else 0
+                _lib.check(lib.rp_splitk_reduce_multi(arr, len(chunk), _st()), "rp_splitk_reduce_multi")
+        return False
+
 
 def gemm_instance(M, N, a_layout, b_layout, reads_mn=False):
     """(a_layout, b_layout, TM, TN) that rp_gemm dispatches to (mirrors the selection in csrc/gemm.hip)."""
@@ -281,9 +326,17 @@ def gemm(A, B, M, N, K, *, a_layout=0, b_layout=0, lda=None, ldb=None, out=None,
     g.stride_a, g.stride_b, g.stride_c = strides
     g.split_k = split_k
     ws = None
+    defer = None
     if split_k > 1:
         nbytes = lib.rp_gemm_workspace_bytes(M, N, split_k)
-        ws = _workspace(nbytes, A.device)
+        plain = bias is None and pre_out is None and aux is None and residual is None and act == 0 and dact == 0 and ln is None
+        if (_SPLITK_BATCH is not None and plain and not want_colsum
+                and torch.cuda.current_stream(A.device).cuda_stream == _SPLITK_BATCH[2]):       # (not under fork.on_side)
+            ws = _arena_take(nbytes, A.device, _SPLITK_BATCH[1])
+            g.defer_reduce = 1
+            defer = (ws, out, M, N, ldc, split_k, trans_c)
+        else:
+            ws = _workspace(nbytes, A.device)
         g.workspace, g.workspace_bytes = ws.data_ptr(), nbytes
     g.bias = None if bias is None else bias.data_ptr()
     g.pre_out = None if pre_out is None else pre_out.data_ptr()
@@ -310,12 +363,76 @@ def gemm(A, B, M, N, K, *, a_layout=0, b_layout=0, lda=None, ldb=None, out=None,
         e0, e1 = tm.new_pair()
         g.ev_start, g.ev_stop = e0, e1
         _lib.check(lib.rp_gemm(ctypes.byref(g), _st()), "rp_gemm")
+        if defer is not None and g.split_k > 1:
+            _SPLITK_BATCH[0].append(defer)
         tm.events.append((e0, e1))
         tm.flops += 2.0 * M * N * K * batch
         tm.bytes += 4.0 * batch * (M * K + N * K + M * N * (1 + (aux is not None) + (residual is not None) + (pre_out is not None)))
         return (out, colsum(cpart)) if want_colsum else out
     _lib.check(lib.rp_gemm(ctypes.byref(g), _st()), "rp_gemm")
+    if defer is not None and g.split_k > 1:
+        _SPLITK_BATCH[0].append(defer)
     return (out, colsum(cpart)) if want_colsum else out
+
+
+# ------------------------------------------------------------------------------------------------
+# W^T copies for the row-resident input-gradient kernels (rp_linear_rows192 on the transposed weight, rp_mlp_fused_bwd): every weight
+# that will need one registers at forward time; the first request of a step transposes ALL registered weights whose copy is stale in ONE
+# rp_transpose_multi launch (round 2: 17 separate `.t().contiguous()` copies per step), later requests hit the cache.
+# ------------------------------------------------------------------------------------------------
+_T_REGISTRY = []      # weakrefs of the registered weights
+
+
+def register_transposed(*ws):
+    import weakref
+    for w in ws:
+        if getattr(w, "_rp_treg", False):
+            continue
+        try:
+            w._rp_treg = True
+        except AttributeError:
+            continue
+        _T_REGISTRY.append(weakref.ref(w))
+
+
+def _t_fresh(w):
+    c = getattr(w, "_rp_t", None)
+    return c is not None and c[0] == w._version and c[1] == w.data_ptr() and c[2] == _PAD_GEN
+
+
+def transposed(w):
+    """contiguous W^T of a 2-D fp32 GPU weight, cached on the tensor until it is modified (see _padded for the invalidation rules)"""
+    if _t_fresh(w):
+        return w._rp_t[3]
+    if (w.is_cuda and torch.cuda.is_current_stream_capturing()) or not w.is_cuda or w.dim() != 2:
+        return w.detach().t().contiguous()
+    todo, alive = [], []
+    for r in _T_REGISTRY:
+        t = r()
+        if t is None:
+            continue
+        alive.append(r)
+        if t is not w and t.is_cuda and t.device == w.device and not _t_fresh(t):
+            todo.append(t)
+    _T_REGISTRY[:] = alive
+    todo = [w] + todo[:_lib.RP_TRANSPOSE_MAX - 1]
+    lib = _lib.load()
+    arr = (_lib.RpTransposeTask * len(todo))()
+    outs = []
+    for a, t in zip(arr, todo):
+        src = t.detach()
+        if not src.is_contiguous():
+            src = src.contiguous()
+        o = torch.empty(t.shape[1], t.shape[0], device=t.device, dtype=torch.float32)
+        a.src, a.dst, a.rows, a.cols = src.data_ptr(), o.data_ptr(), t.shape[0], t.shape[1]
+        outs.append((t, src, o))
+    _lib.check(lib.rp_transpose_multi(arr, len(todo), _st()), "rp_transpose_multi")
+    for t, _, o in outs:
+        try:
+            t._rp_t = (t._version, t.data_ptr(), _PAD_GEN, o)
+        except AttributeError:
+            pass
+    return outs[0][2]
 
 
 # K = 192 Linear layers on the row-resident kernel (csrc/linear_rows.hip) instead of the generic LDS-DMA GEMM: exact fp32 only
@@ -388,7 +505,7 @@ def linear_dx(dy, W, dact=0, aux=None, want_colsum=False):
     K = W.shape[1]
     if ROWS_DX and N == DIM and K % 32 == 0 and K <= 1024 and GEMM_PRECISION == 0 and dy.is_contiguous() and dact in (0, 1):
         # contraction over the layer's 192 outputs: the row-resident kernel on the transposed weight (a 0.1-0.6 MB copy)
-        return linear_rows(dy, W.t().contiguous(), dact_aux=aux if dact else None, want_colsum=want_colsum)
+        return linear_rows(dy, transposed(W), dact_aux=aux if dact else None, want_colsum=want_colsum)
     return gemm(dy, W, M, K, N, b_layout=1, dact=dact, aux=aux, want_colsum=want_colsum)
 
 
@@ -530,8 +647,6 @@ def attn_fwd(qkv, Z, stats_only=False, q_off=0, k_off=DIM, v_off=2 * DIM, q_xor=
 
 ATTN_BWD_STORE_DS = os.environ.get("RP_ATTN_DS", "1") == "1"
 EMM_BWD_STORE_DS = os.environ.get("RP_EMM_DS", "1") == "1"
-# the product that consumes a stored dS: rp_ds_matmul (streaming kernel, one launch for all heads) or batched rp_gemm launches (round 2)
-DS_MATMUL = os.environ.get("RP_DS_MATMUL", "1") == "1"
 
 
 def ds_matmul(ds, b_base, ldb, out_base, ldo, Z, b_xor=0):
@@ -562,20 +677,13 @@ def attn_bwd(qkv, o, lse, do, Z, fork=None, kv_xor=0):
                    "rp_attn_bwd_cross")
         return dqkv
     if ATTN_BWD_STORE_DS and (fork is None or not fork.enabled):
-        # the dK/dV pass stores scale*dS (fp32, [Z,H,576,576]); dQ = dS K is then a batched GEMM per head: 5 executed GEMMs
+        # the dK/dV pass stores scale*dS (fp32, [Z,H,576,576] in 32x32 tiles); dQ = dS K is then one rp_ds_matmul: 5 executed GEMMs
         # instead of 7 (the dQ pass would recompute S and dP) for 2 x 510 MB of extra HBM traffic
         ds = _empty(Z, HEADS, N_TOK, N_TOK, like=qkv)
         _lib.check(lib.rp_attn_bwd_dkdv_ds(P(b), P(b + 4 * DIM), P(b + 8 * DIM), _p(do), _p(lse), _p(delta), P(d + 4 * DIM),
                                            P(d + 8 * DIM), _p(ds), Z, HEADS, ld, ld, ld, DIM, ld, ld, sc, ATTN_BF16, _st()),
                    "rp_attn_bwd_dkdv_ds")
-        if DS_MATMUL and not ATTN_BF16:
-            ds_matmul(ds, b + 4 * DIM, ld, d, ld, Z)                  # dQ = dS K, one streaming launch
-            return dqkv
-        dsf, qf, df = ds.view(-1), qkv.view(-1), dqkv.view(-1)
-        per = N_TOK * N_TOK
-        for h in range(HEADS):
-            gemm(dsf[h * per:], qf[DIM + 64 * h:], N_TOK, 64, N_TOK, b_layout=1, lda=N_TOK, ldb=ld, out=df[64 * h:], ldc=ld,
-                 split_k=1, batch=Z, strides=(HEADS * per, N_TOK * ld, N_TOK * ld))
+        ds_matmul(ds, b + 4 * DIM, ld, d, ld, Z)                  # dQ = dS K: one streaming launch (exact fp32 in every mode)
         return dqkv
     if fork is None or not fork.enabled:
         _lib.check(lib.rp_attn_bwd(P(b), P(b + 4 * DIM), P(b + 8 * DIM), _p(do), _p(lse), _p(delta), P(d), P(d + 4 * DIM),
@@ -707,20 +815,13 @@ def emm_backward(qkv, x, t, rlse, clse, df, Z, single=False, cross=False):
     dqkv = torch.empty_like(qkv)
     ld = qkv.shape[1]
     if EMM_BWD_STORE_DS:
-        # the query-side pass stores scale*dS; dk_z = dS_z^T-major x q_{z^1} is a batched GEMM per (head, pair parity) instead
-        # of a second pass that recomputes S and dA (68 of its 100 MFMAs per tile)
+        # the query-side pass stores scale*dS (tiled); dk_z = dS_z^T-major x q_{z^1} is one rp_ds_matmul instead of a second pass
+        # that recomputes S and dA (68 of its 100 MFMAs per tile)
         ds = _empty(Z, HEADS, N_TOK, N_TOK, like=qkv)
         _lib.check(lib.rp_emm_grad_ds(_p(qkv), ld, _p(x), _p(w), _p(rlse), _p(clse), _p(rho), _p(gam), _p(dqkv), _p(ds), Z,
                                       HEADS, scale, sg, ATTN_BF16, _st()), "rp_emm_grad_ds")
-        dsf, qf, df = ds.view(-1), qkv.view(-1), dqkv.view(-1)
-        per, img = N_TOK * N_TOK, N_TOK * ld
-        if DS_MATMUL and not ATTN_BF16:           # dk_z = dS_z (key-major) x q_{z^1}: one streaming launch
-            ds_matmul(ds, qkv.data_ptr(), ld, dqkv.data_ptr() + 4 * DIM, ld, Z, b_xor=1)
-        for h in (range(HEADS) if not (DS_MATMUL and not ATTN_BF16) else ()):
-            for e in (0, 1):                      # problems z = 2b + e take their queries from image z ^ 1
-                gemm(dsf[(e * HEADS + h) * per:], qf[(1 - e) * img + 64 * h:], N_TOK, 64, N_TOK, b_layout=1, lda=N_TOK, ldb=ld,
-                     out=df[e * img + DIM + 64 * h:], ldc=ld, split_k=1, batch=Z // 2,
-                     strides=(2 * HEADS * per, 2 * img, 2 * img))
+        # dk_z = dS_z (key-major tiles) x q_{z^1}: one streaming launch
+        ds_matmul(ds, qkv.data_ptr(), ld, dqkv.data_ptr() + 4 * DIM, ld, Z, b_xor=1)
     else:
         _lib.check(lib.rp_emm_grad(_p(qkv), ld, _p(x), _p(w), _p(rlse), _p(clse), _p(rho), _p(gam), _p(dqkv), Z, HEADS,
                                    scale, 0, sg, ATTN_BF16, _st()), "rp_emm_grad(q)")
@@ -824,7 +925,7 @@ def mlp_fused_bwd(dy, hpre, w1, w2):
     lib = _lib.load()
     _chk(dy, hpre)
     M = dy.shape[0]
-    w2t, w1t = w2.t().contiguous(), w1.t().contiguous()
+    w2t, w1t = transposed(w2), transposed(w1)
     dhp, dxn = torch.empty_like(hpre), torch.empty_like(dy)
     tiles = -(-M // lib.rp_mlp_fused_bwd_tile_rows())
     colpart = _empty(tiles, hpre.shape[1], like=dy)
@@ -915,6 +1016,7 @@ class BlockFn(_Fn):
         x1 = linear(o, proj_w, proj_b, residual=x2)
         y, xn2, m2, r2, h, hpre = _mlp_block_fwd(x1, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b, train)
         if train:
+            register_transposed(proj_w, fc1_w, fc2_w)
             ctx.save_for_backward(x2, m1, r1, xn1, qkv, o, lse, x1, m2, r2, xn2, h, hpre, n1w, qkv_w, proj_w, n2w,
                                   fc1_w, fc2_w)
             ctx.Z = Z
@@ -930,7 +1032,7 @@ class BlockFn(_Fn):
         # the two LayerNorm backwards read dy / dx1 as their residual-branch operand anyway: they also return its column
         # sums, which ARE the fc2 / proj bias gradients (two 57 MB column-sum passes per block saved).  The block's four column
         # sums (LayerNorm partials x 2, fc1 and qkv bias gradients) run as one batched pair of launches at the end.
-        with colsum_batch():
+        with colsum_batch(), splitk_batch():
             (dx1, dn2w, dn2b, dfc2b), dfc1w, dfc1b, dfc2w, _ = _mlp_bwd(fork, dy, xn2, h, hpre, fc1_w, fc2_w, want_db2=False,
                                                                          ln=(x1, n2w, m2, r2, dy))
             fork.sync_side()
@@ -967,6 +1069,7 @@ class CrossBlockFn(_Fn):
         f = linear(g, pf_wp, pf_b)                                     # [Z*70, 192]
         y, fn, m2, r2, h, hpre = _mlp_block_fwd(f, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b, train)
         if train:
+            register_transposed(fc1_w, fc2_w)
             ctx.save_for_backward(x2, m1, r1, xn, qkv, rlse, clse, xa, t, g, f, m2, r2, fn, h, hpre, n1w, qkv_w, pf_wp,
                                   n2w, fc1_w, fc2_w)
             ctx.Z = Z
@@ -980,7 +1083,7 @@ class CrossBlockFn(_Fn):
         Z = ctx.Z
         dy = dy.contiguous().view(Z * 70, DIM)
         fork = _Fork(dy.device)
-        with colsum_batch():
+        with colsum_batch(), splitk_batch():
             dfn, dfc1w, dfc1b, dfc2w, _ = _mlp_bwd(fork, dy, fn, h, hpre, fc1_w, fc2_w, want_db2=False)
             df_, dn2w, dn2b, dfc2b = layernorm_bwd(dfn, f, n2w, m2, r2, add=dy)       # 4th: colsum(dy) = fc2 bias gradient
             fork.sync_side()
@@ -1180,6 +1283,33 @@ def conv2d(m, x):
     return y.float()
 
 
+_NBT_PENDING = None      # inside `with batches_tracked_batch():` the num_batches_tracked buffers to bump at exit
+
+
+class batches_tracked_batch:
+    """The CNN front-end has 13 BatchNorm layers; `num_batches_tracked += 1` on each was a 5-us launch of its own.  Inside this block
+    the increments are collected and applied as ONE torch._foreach_add_ at exit (same values, same buffers)."""
+
+    def __enter__(self):
+        global _NBT_PENDING
+        self.prev, _NBT_PENDING = _NBT_PENDING, []
+        return self
+
+    def __exit__(self, et, ev, tb):
+        global _NBT_PENDING
+        cur, _NBT_PENDING = _NBT_PENDING, self.prev
+        if et is None and cur:
+            torch._foreach_add_(cur, 1)
+        return False
+
+
+def _bump_batches_tracked(bn):
+    if _NBT_PENDING is not None and bn.num_batches_tracked is not None:
+        _NBT_PENDING.append(bn.num_batches_tracked)
+    else:
+        bn.num_batches_tracked += 1
+
+
 def bn_act(bn, x, residual=None, relu=True):
     """BatchNorm2d module `bn` applied to x, then (+ residual), then ReLU.  GPU tensors take the fused HIP path; CPU tensors
     (only the fixture generator uses the trunk on the CPU, as the reference's torchvision stand-in) take plain PyTorch."""
@@ -1189,7 +1319,7 @@ def bn_act(bn, x, residual=None, relu=True):
             y = y + residual
         return torch.relu(y) if relu else y
     if bn.training and bn.track_running_stats:
-        bn.num_batches_tracked += 1
+        _bump_batches_tracked(bn)
     return BnActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, bn.training, bn.momentum, bn.eps,
                          relu)
 
@@ -1376,7 +1506,7 @@ def bn_relu_maxpool(bn, pool, x, stats=None):
     if not x.is_cuda or not FUSE_STEM_POOL:
         return maxpool3x3s2(pool, bn_act(bn, x))
     if bn.training and bn.track_running_stats:
-        bn.num_batches_tracked += 1
+        _bump_batches_tracked(bn)
     return BnReluPoolFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.momentum, bn.eps, stats)
 
 

@@ -846,3 +846,44 @@ def test_hand_written_stem_convolution(ops, N, H, W):
         assert torch.equal(framed[:, 3:-3, 3:-3, :], plain.permute(0, 2, 3, 1))
         framed[:, 3:-3, 3:-3, :] = 0
         assert float(framed.abs().max()) == 0.0
+
+
+def test_deferred_splitk_reduces_are_bit_identical(ops):
+    """ops.splitk_batch: the weight-gradient GEMMs of a block leave their split-K slabs in a private arena and ONE rp_splitk_reduce_multi
+    finishes all of them (incl. the transposed-store form of fc2) -- same sums in the same order as each GEMM's own reduce."""
+    M = 9 * 576
+    dy1, x1 = rnd(M, 576, seed=1), rnd(M, 192, seed=2)        # qkv-like: [576,192]
+    dy2, x2 = rnd(M, 192, seed=3), rnd(M, 768, seed=4)        # fc2-like: wide-K', reduce writes the transpose
+    dy3, x3 = rnd(M, 192, seed=5), rnd(M, 192, seed=6)
+    keep = ops.SPLITK_BATCHING
+    try:
+        ops.SPLITK_BATCHING = False
+        ref = [ops.linear_dw(dy1, x1), ops.linear_dw(dy2, x2), ops.linear_dw(dy3, x3)]
+        ops.SPLITK_BATCHING = True
+        with ops.splitk_batch():
+            out = [ops.linear_dw(dy1, x1), ops.linear_dw(dy2, x2), ops.linear_dw(dy3, x3)]
+    finally:
+        ops.SPLITK_BATCHING = keep
+    torch.cuda.synchronize()
+    for a, b in zip(out, ref):
+        assert torch.equal(a, b)
+    assert rel(out[0], dy1.double().t() @ x1.double()) < 2e-6
+
+
+def test_transposed_weight_cache_and_batched_transposes(ops):
+    """ops.transposed: W^T of registered weights comes from one rp_transpose_multi launch, is cached on the tensor and follows
+    in-place updates and explicit invalidation (a graph replay)."""
+    ws = [torch.nn.Parameter(rnd(r, c, seed=10 + i)) for i, (r, c) in enumerate([(768, 192), (192, 768), (192, 192), (70, 33)])]
+    ops.register_transposed(*ws)
+    t0 = ops.transposed(ws[0])
+    assert torch.equal(t0, ws[0].detach().t())
+    for w in ws[1:]:                                     # the others were transposed by the same launch
+        assert getattr(w, "_rp_t", None) is not None and torch.equal(w._rp_t[3], w.detach().t())
+        assert ops.transposed(w) is w._rp_t[3]
+    with torch.no_grad():
+        ws[2].mul_(2.0)
+    assert torch.equal(ops.transposed(ws[2]), ws[2].detach().t())
+    stale = ops.transposed(ws[3])
+    ops.invalidate_pad_cache()
+    fresh = ops.transposed(ws[3])
+    assert fresh is not stale and torch.equal(fresh, ws[3].detach().t())

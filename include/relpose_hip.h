@@ -36,8 +36,8 @@ extern "C" {
  * functions this header declares.  rp_abi_version() / rp_abi_export_count() return the values the library was COMPILED with, so a
  * binding (rel_pose_amd/_lib.py parses both macros and counts the declarations) rejects a stale .so at load time instead of
  * failing later on a missing symbol. */
-#define RP_ABI_VERSION 6
-#define RP_ABI_EXPORTS 64
+#define RP_ABI_VERSION 7
+#define RP_ABI_EXPORTS 65
 int rp_abi_version(void);
 int rp_abi_export_count(void);
 const char* rp_target_arch(void);
@@ -372,6 +372,11 @@ int rp_augment_pairs(const unsigned char* images, const float* params, float* ou
  * ------------------------------------------------------------------------------------------- */
 int rp_essential_from_pose(const float* pose, float* E, int n, void* stream);
 int rp_svd3x3(const float* A, float* U, float* S, float* V, int n, void* stream);
+/* rp_pose_from_essential: the decode E -> (R, t) that north_star's "SVD ... produce relative R,t" names (no reference counterpart:
+ * SURVEY.md row a16): per matrix the SVD above, the four candidates (U W V^T | U W^T V^T, +-u_2) and the cheirality vote over P point
+ * correspondences x1[n][P][2] <-> x2[n][P][2] (normalised image coordinates, X2 = R X1 + t).  pose[n][7] = (t unit-norm, q xyzw,
+ * w >= 0); count[n] (optional) = points in front of both cameras for the winning candidate.  One lane per matrix, registers only. */
+int rp_pose_from_essential(const float* E, const float* x1, const float* x2, int P, float* pose, int* count, int n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -125,6 +125,7 @@ _SIGS = {
     "rp_augment_pairs": (c_int, [P, P, P, P, I, I, I, I, I, P]),
     "rp_essential_from_pose": (c_int, [P, P, I, P]),
     "rp_svd3x3": (c_int, [P, P, P, P, I, P]),
+    "rp_pose_from_essential": (c_int, [P, P, P, I, P, P, I, P]),
 }
 EXPORTS = tuple(_SIGS)
 

@@ -22,15 +22,14 @@ RP_DEV void rot(float& a, float& b, float c, float s) {
   b = y;
 }
 
-__global__ __launch_bounds__(64) void svd3x3_kernel(const float* A, float* U, float* S, float* V, int n) {
-  const int i = blockIdx.x * 64 + threadIdx.x;
-  if (i >= n) return;
-  float w[3][3], v[3][3];                       // w[col][row], v[col][row]
+// one 3x3 SVD in registers: A row-major [9] -> u[col][row], sg[3] descending, v[col][row]
+RP_DEV void svd3x3_dev(const float* A, float (&u)[3][3], float (&sg)[3], float (&v)[3][3]) {
+  float w[3][3];                       // w[col][row]
 #pragma unroll
   for (int r = 0; r < 3; ++r)
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      w[c][r] = A[(long long)i * 9 + 3 * r + c];
+      w[c][r] = A[3 * r + c];
       v[c][r] = r == c ? 1.f : 0.f;
     }
 #pragma unroll 1
@@ -53,7 +52,6 @@ __global__ __launch_bounds__(64) void svd3x3_kernel(const float* A, float* U, fl
       }
     }
   }
-  float sg[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) sg[c] = sqrtf(w[c][0] * w[c][0] + w[c][1] * w[c][1] + w[c][2] * w[c][2]);
   // sort columns by singular value, descending (3-element network; swaps carry w and v along)
@@ -67,7 +65,6 @@ __global__ __launch_bounds__(64) void svd3x3_kernel(const float* A, float* U, fl
   }
   RP_CSWAP(0, 1) RP_CSWAP(1, 2) RP_CSWAP(0, 1)
 #undef RP_CSWAP
-  float u[3][3];
   const float tiny = 1e-7f * fmaxf(sg[0], 1e-30f);
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
@@ -89,6 +86,13 @@ __global__ __launch_bounds__(64) void svd3x3_kernel(const float* A, float* U, fl
     u[2][1] = u[0][2] * u[1][0] - u[0][0] * u[1][2];
     u[2][2] = u[0][0] * u[1][1] - u[0][1] * u[1][0];
   }
+}
+
+__global__ __launch_bounds__(64) void svd3x3_kernel(const float* A, float* U, float* S, float* V, int n) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  float u[3][3], sg[3], v[3][3];
+  svd3x3_dev(A + (long long)i * 9, u, sg, v);
 #pragma unroll
   for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -98,6 +102,92 @@ __global__ __launch_bounds__(64) void svd3x3_kernel(const float* A, float* U, fl
     }
 #pragma unroll
   for (int c = 0; c < 3; ++c) S[(long long)i * 3 + c] = sg[c];
+}
+
+// E -> (R, t): the textbook decomposition on top of the SVD above, one lane per matrix.  E = U diag(s, s, 0) V^T gives the two
+// rotations R_a = U W V^T, R_b = U W^T V^T (W = rot_z(90 deg); sign fixed so that det = +1) and t = +-u_2 (unit: the scale of t is not
+// observable from E).  The physically valid one of the four (R, t) is the one that puts the observed points in FRONT of both cameras
+// (cheirality): for every correspondence x1 <-> x2 (normalised image coordinates, X2 = R X1 + t) the two depths of the least-squares
+// triangulation lambda1 R x1 + t = lambda2 x2 must be positive; the candidate with the most such points wins (ties: the first).
+// out pose = (t unit, q xyzw with w >= 0), count = its number of points in front.
+__global__ __launch_bounds__(64) void decode_essential_kernel(const float* E, const float* x1, const float* x2, int P, float* pose,
+                                                              int* count, int n) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  float u[3][3], sg[3], v[3][3];
+  svd3x3_dev(E + (long long)i * 9, u, sg, v);
+  float R[2][3][3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float a = u[1][r] * v[0][c] - u[0][r] * v[1][c], z = u[2][r] * v[2][c];
+      R[0][r][c] = a + z;
+      R[1][r][c] = -a + z;
+    }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const float det = R[k][0][0] * (R[k][1][1] * R[k][2][2] - R[k][1][2] * R[k][2][1]) -
+                      R[k][0][1] * (R[k][1][0] * R[k][2][2] - R[k][1][2] * R[k][2][0]) +
+                      R[k][0][2] * (R[k][1][0] * R[k][2][1] - R[k][1][1] * R[k][2][0]);
+    if (det < 0.f) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) R[k][r][c] = -R[k][r][c];
+    }
+  }
+  const float t0[3] = {u[2][0], u[2][1], u[2][2]};
+  int cnt[4] = {0, 0, 0, 0};
+  for (int p = 0; p < P; ++p) {
+    const float a1 = x1[((long long)i * P + p) * 2], b1 = x1[((long long)i * P + p) * 2 + 1];
+    const float a2 = x2[((long long)i * P + p) * 2], b2 = x2[((long long)i * P + p) * 2 + 1];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      // m = R x1;  solve [m, -x2] (l1, l2)^T = -t in the least-squares sense (normal equations of the 3x2 system)
+      const float m0 = R[k][0][0] * a1 + R[k][0][1] * b1 + R[k][0][2], m1 = R[k][1][0] * a1 + R[k][1][1] * b1 + R[k][1][2],
+                  m2 = R[k][2][0] * a1 + R[k][2][1] * b1 + R[k][2][2];
+      const float mm = m0 * m0 + m1 * m1 + m2 * m2, xx = a2 * a2 + b2 * b2 + 1.f, mx = m0 * a2 + m1 * b2 + m2;
+      const float mt = m0 * t0[0] + m1 * t0[1] + m2 * t0[2], xt = a2 * t0[0] + b2 * t0[1] + t0[2];
+      const float det = mm * xx - mx * mx;
+      if (det <= 1e-12f * mm * xx) continue;
+      // (+t): l1 = (-mt xx + mx xt) / det, l2 = (-mt mx + mm xt) / det ;  (-t): both negated
+      const float l1 = (-mt * xx + mx * xt) / det, l2 = (-mt * mx + mm * xt) / det;
+      cnt[2 * k] += (l1 > 0.f && l2 > 0.f) ? 1 : 0;
+      cnt[2 * k + 1] += (l1 < 0.f && l2 < 0.f) ? 1 : 0;
+    }
+  }
+  int best = 0;
+#pragma unroll
+  for (int k = 1; k < 4; ++k) best = cnt[k] > cnt[best] ? k : best;
+  const int kr = best >> 1;
+  const float sgn = (best & 1) ? -1.f : 1.f;
+  float Rm[3][3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) Rm[r][c] = kr ? R[1][r][c] : R[0][r][c];
+  // rotation matrix -> quaternion (x, y, z, w), the branch with the largest pivot (Shepperd)
+  float qx, qy, qz, qw;
+  const float tr = Rm[0][0] + Rm[1][1] + Rm[2][2];
+  if (tr > 0.f) {
+    const float s_ = sqrtf(tr + 1.f) * 2.f;
+    qw = 0.25f * s_; qx = (Rm[2][1] - Rm[1][2]) / s_; qy = (Rm[0][2] - Rm[2][0]) / s_; qz = (Rm[1][0] - Rm[0][1]) / s_;
+  } else if (Rm[0][0] > Rm[1][1] && Rm[0][0] > Rm[2][2]) {
+    const float s_ = sqrtf(1.f + Rm[0][0] - Rm[1][1] - Rm[2][2]) * 2.f;
+    qw = (Rm[2][1] - Rm[1][2]) / s_; qx = 0.25f * s_; qy = (Rm[0][1] + Rm[1][0]) / s_; qz = (Rm[0][2] + Rm[2][0]) / s_;
+  } else if (Rm[1][1] > Rm[2][2]) {
+    const float s_ = sqrtf(1.f + Rm[1][1] - Rm[0][0] - Rm[2][2]) * 2.f;
+    qw = (Rm[0][2] - Rm[2][0]) / s_; qx = (Rm[0][1] + Rm[1][0]) / s_; qy = 0.25f * s_; qz = (Rm[1][2] + Rm[2][1]) / s_;
+  } else {
+    const float s_ = sqrtf(1.f + Rm[2][2] - Rm[0][0] - Rm[1][1]) * 2.f;
+    qw = (Rm[1][0] - Rm[0][1]) / s_; qx = (Rm[0][2] + Rm[2][0]) / s_; qy = (Rm[1][2] + Rm[2][1]) / s_; qz = 0.25f * s_;
+  }
+  if (qw < 0.f) { qx = -qx; qy = -qy; qz = -qz; qw = -qw; }
+  float* o = pose + (long long)i * 7;
+  o[0] = sgn * t0[0]; o[1] = sgn * t0[1]; o[2] = sgn * t0[2];
+  o[3] = qx; o[4] = qy; o[5] = qz; o[6] = qw;
+  if (count) count[i] = cnt[best];
 }
 
 // E = [t]x R(q): pose = (tx, ty, tz, qx, qy, qz, qw), q normalised here (the regressor's q is already unit, src/model.py:145-152)
@@ -133,6 +223,14 @@ extern "C" int rp_svd3x3(const float* A, float* U, float* S, float* V, int n, vo
 extern "C" int rp_essential_from_pose(const float* pose, float* E, int n, void* stream) {
   if (n <= 0 || !pose || !E) return RP_EBADSHAPE;
   hipLaunchKernelGGL(essential_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, pose, E, n);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
+extern "C" int rp_pose_from_essential(const float* E, const float* x1, const float* x2, int P, float* pose, int* count, int n,
+                                      void* stream) {
+  if (n <= 0 || P <= 0 || !E || !x1 || !x2 || !pose) return RP_EBADSHAPE;
+  hipLaunchKernelGGL(decode_essential_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, E, x1, x2, P, pose, count, n);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }

@@ -610,6 +610,54 @@ def test_svd3x3_and_essential_matrix_vs_lapack(ops):
     report("svd3x3", **worst)
 
 
+def test_pose_from_essential_round_trip(ops):
+    """north_star's "per-pair 3x3 SVD ... produce relative R,t" closed as a round trip (no reference row: SURVEY a16, off
+    ViTEss.forward's path): pose -> E = [t]x R(q) (rp_essential_from_pose) -> SVD + four candidates + cheirality on synthetic points
+    (rp_pose_from_essential) -> the input pose again: rotation angle error <= 2e-3 rad (fp32 SVD of a rank-2 matrix: sqrt(eps)-level
+    sensitivity near 180-degree / degenerate configurations, measured ~1e-4), t direction cosine >= 1 - 1e-6 (t is recovered up to
+    scale, sign fixed by the points), every synthetic point in front of both cameras; and the same decisions as the LAPACK oracle."""
+    from oracle import svd3x3_oracle as SO
+    from rel_pose_amd import geom
+    g = torch.Generator().manual_seed(17)
+    n, P = 300, 12
+    pose = torch.zeros(n, 7)
+    pose[:, :3] = torch.randn(n, 3, generator=g)
+    q = torch.randn(n, 4, generator=g)
+    pose[:, 3:] = q / q.norm(dim=1, keepdim=True) * torch.where(q[:, 3:] < 0, -1.0, 1.0)
+    R = torch.from_numpy(SO.rotation_from_quat(pose[:, 3:].numpy()))
+    t = pose[:, :3].double()
+    # 3-D points in front of camera 1 whose images in camera 2 are in front as well (rejection sampling, deterministic)
+    X1 = torch.empty(n, P, 3, dtype=torch.float64)
+    for i in range(n):
+        got = 0
+        while got < P:
+            cand = torch.cat([torch.randn(64, 2, generator=g, dtype=torch.float64) * 2.0, torch.rand(64, 1, generator=g, dtype=torch.float64) * 6.0 + 1.0], 1)
+            z2 = (cand @ R[i].T + t[i])[:, 2]
+            ok = cand[z2 > 0.5]
+            k = min(P - got, ok.shape[0])
+            X1[i, got:got + k] = ok[:k]
+            got += k
+    X2 = torch.einsum("nij,npj->npi", R, X1) + t[:, None, :]
+    x1 = (X1[..., :2] / X1[..., 2:]).float()
+    x2 = (X2[..., :2] / X2[..., 2:]).float()
+    E = geom.essential_from_pose(pose.cuda())
+    out, count = geom.pose_from_essential(E, x1.cuda(), x2.cuda())
+    out, count = out.cpu().double(), count.cpu()
+    assert bool((count == P).all()), count.min()
+    tn = t / t.norm(dim=1, keepdim=True)
+    cos_t = (out[:, :3] * tn).sum(1)
+    qd = (out[:, 3:] * pose[:, 3:].double()).sum(1).abs().clamp(max=1.0)
+    ang = 2.0 * torch.acos(qd)
+    report("pose_from_essential", max_angle=float(ang.max()), min_cos_t=float(cos_t.min()))
+    assert float(ang.max()) < 2e-3 and float(cos_t.min()) > 1.0 - 1e-6
+    assert float((out[:, :3].norm(dim=1) - 1).abs().max()) < 1e-5 and bool((out[:, 6] >= 0).all())
+    # the LAPACK oracle takes the same decisions on the same E and points
+    Ro, to, co = SO.decode_essential(E.cpu().numpy()[:40], x1.numpy()[:40], x2.numpy()[:40])
+    Rg = torch.from_numpy(SO.rotation_from_quat(out[:40, 3:].numpy()))
+    assert float((Rg - torch.from_numpy(Ro)).abs().max()) < 5e-4 and float((out[:40, :3] - torch.from_numpy(to)).abs().max()) < 5e-4
+    assert bool((torch.from_numpy(co) == P).all())
+
+
 def test_batched_column_sums_equal_individual_ones(ops):
     """rp_colsum_multi: several column sums in one pair of launches give bit-identical results to rp_colsum one by one
     (same stage split, same summation order), incl. a single-stage task, a ragged column count and more than 8 tasks."""

@@ -373,3 +373,30 @@ def test_clip_grad_norm_equals_torch():
         assert torch.equal(ta, tb)
         for p, q in zip(ps, qs):
             assert torch.equal(p.grad, q.grad)
+
+
+def test_essential_decode_oracle_round_trip():
+    """oracle/svd3x3_oracle.decode_essential (the LAPACK pin of rp_pose_from_essential): pose -> E -> four candidates + cheirality ->
+    the input rotation and the direction of t, on points in front of both cameras."""
+    from oracle import svd3x3_oracle as SO
+    rng = np.random.default_rng(5)
+    n, P = 12, 10
+    pose = np.zeros((n, 7))
+    pose[:, :3] = rng.normal(size=(n, 3))
+    q = rng.normal(size=(n, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    pose[:, 3:] = q * np.where(q[:, 3:] < 0, -1, 1)
+    R, t = SO.rotation_from_quat(pose[:, 3:]), pose[:, :3]
+    X1 = np.empty((n, P, 3))
+    for i in range(n):
+        got = 0
+        while got < P:
+            c = np.concatenate([rng.normal(size=(64, 2)) * 2, rng.uniform(1, 7, size=(64, 1))], 1)
+            ok = c[(c @ R[i].T + t[i])[:, 2] > 0.5]
+            k = min(P - got, len(ok))
+            X1[i, got:got + k] = ok[:k]
+            got += k
+    X2 = np.einsum("nij,npj->npi", R, X1) + t[:, None]
+    Ro, to, co = SO.decode_essential(SO.essential_from_pose(pose), X1[..., :2] / X1[..., 2:], X2[..., :2] / X2[..., 2:])
+    assert (co == P).all()
+    assert np.abs(Ro - R).max() < 1e-9 and np.abs(to - t / np.linalg.norm(t, axis=1, keepdims=True)).max() < 1e-9

@@ -622,15 +622,18 @@ def test_pose_from_essential_round_trip(ops):
     n, P = 300, 12
     pose = torch.zeros(n, 7)
     pose[:, :3] = torch.randn(n, 3, generator=g)
-    q = torch.randn(n, 4, generator=g)
-    pose[:, 3:] = q / q.norm(dim=1, keepdim=True) * torch.where(q[:, 3:] < 0, -1.0, 1.0)
+    ax = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=1)
+    half = (torch.rand(n, 1, generator=g) * 2.0 - 1.0)            # rotation angle within +-2 rad: the two cameras never face away from
+    pose[:, 3:6], pose[:, 6:] = ax * torch.sin(half), torch.cos(half)          # each other, so points in front of both always exist
     R = torch.from_numpy(SO.rotation_from_quat(pose[:, 3:].numpy()))
     t = pose[:, :3].double()
     # 3-D points in front of camera 1 whose images in camera 2 are in front as well (rejection sampling, deterministic)
     X1 = torch.empty(n, P, 3, dtype=torch.float64)
     for i in range(n):
-        got = 0
+        got, tries = 0, 0
         while got < P:
+            tries += 1
+            assert tries < 500, "rejection sampling of points in front of both cameras does not terminate"
             cand = torch.cat([torch.randn(64, 2, generator=g, dtype=torch.float64) * 2.0, torch.rand(64, 1, generator=g, dtype=torch.float64) * 6.0 + 1.0], 1)
             z2 = (cand @ R[i].T + t[i])[:, 2]
             ok = cand[z2 > 0.5]

@@ -383,14 +383,17 @@ def test_essential_decode_oracle_round_trip():
     n, P = 12, 10
     pose = np.zeros((n, 7))
     pose[:, :3] = rng.normal(size=(n, 3))
-    q = rng.normal(size=(n, 4))
-    q /= np.linalg.norm(q, axis=1, keepdims=True)
-    pose[:, 3:] = q * np.where(q[:, 3:] < 0, -1, 1)
+    ax = rng.normal(size=(n, 3))
+    ax /= np.linalg.norm(ax, axis=1, keepdims=True)
+    half = rng.uniform(-1.0, 1.0, size=(n, 1))          # rotation angle within +-2 rad: points in front of both cameras always exist
+    pose[:, 3:6], pose[:, 6:] = ax * np.sin(half), np.cos(half)
     R, t = SO.rotation_from_quat(pose[:, 3:]), pose[:, :3]
     X1 = np.empty((n, P, 3))
     for i in range(n):
-        got = 0
+        got, tries = 0, 0
         while got < P:
+            tries += 1
+            assert tries < 500
             c = np.concatenate([rng.normal(size=(64, 2)) * 2, rng.uniform(1, 7, size=(64, 1))], 1)
             ok = c[(c @ R[i].T + t[i])[:, 2] > 0.5]
             k = min(P - got, len(ok))

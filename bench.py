@@ -282,7 +282,7 @@ def main():
     model.train(train)
     net = model
     if (world > 1 or force_dist) and train and not args.graph:
-        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], find_unused_parameters=False)
+        net = parallel.wrap(model, device_ids=[local_rank])
         # (reference train.py:66-67; bucketed all-reduce of the 19.26 M trainable grads overlaps the backward)
     elif world > 1:
         for t in list(model.parameters()) + list(model.buffers()):      # what DDP's constructor does: rank 0's replica everywhere

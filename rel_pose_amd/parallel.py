@@ -49,9 +49,37 @@ def shard_pairs(num_pairs, rank, world_size):
     return idx
 
 
+# Gradient buckets.  The backward of this model hands gradients over at 8 points only (one autograd Function per module: head, CrossBlock,
+# 5 Blocks, then the CNN's convolutions one by one), in this order and size: pose_regressor 56.1 MB (ready first, ~1 ms into the
+# backward), the ViT + EMM 11.1 MB (ready over the next ~12 ms), the CNN front-end 9.8 MB (ready last; resnet.conv1's 37 KB at the very
+# end).  DDP fills buckets in reverse registration order ~ this order; the 56 MB tensor is a bucket of its own whatever the cap, so its
+# all-reduce (the bulk of the 77 MB) overlaps ~20 ms of backward.  What is EXPOSED is the last bucket, which cannot start before the
+# stem's weight gradient exists: with the default 25 MB cap that is ~21 MB (ViT + CNN together), with 8 MB it is the front-end's last
+# ~6 MB -- per-link ring time 2 * 7/8 * 6 MB / ~45 GB/s effective per xGMI link ~ 0.25 ms instead of ~0.8 ms.  UNMEASURED on hardware
+# (no multi-GPU node has been available to this build); the reasoning is the 7 x ~153 GB/s point-to-point links of
+# MI355X_MICROARCH.md, not a measurement.  gradient_as_bucket_view: .grad tensors are views into the buckets, so the 77 MB
+# copy-in / copy-out around the collective disappears.
+BUCKET_CAP_MB = int(os.environ.get("RP_DDP_BUCKET_MB", "8"))
+
+
 def wrap(model, device_ids=None):
-    """DDP with the reference's settings (train.py:66-67)."""
-    return torch.nn.parallel.DistributedDataParallel(model, device_ids=device_ids, find_unused_parameters=False)
+    """DDP with the reference's settings (train.py:66-67: find_unused_parameters=False, buffers broadcast from rank 0 every forward)
+    plus bucket views and the bucket cap reasoned above."""
+    return torch.nn.parallel.DistributedDataParallel(model, device_ids=device_ids, find_unused_parameters=False,
+                                                     gradient_as_bucket_view=True, bucket_cap_mb=BUCKET_CAP_MB)
+
+
+def loader_workers(requested, local_world, reserve=1):
+    """DataLoader workers PER RANK that do not oversubscribe the host: every rank of a node runs its own worker pool, and a decode
+    worker keeps a core busy (profiles/r2_loader_bench.txt: 125 pairs/s per core, ~14 cores feed one GPU).  Returns
+    min(requested, (usable cores // ranks on this node) - reserve) (>= 0), where usable cores = the affinity mask of this process (the
+    cgroup / taskset view), not the machine's core count."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cores = os.cpu_count() or 1
+    per_rank = max(cores // max(int(local_world), 1) - reserve, 0)
+    return max(min(int(requested), per_rank), 0)
 
 
 def allreduce_mean_(tensors):

@@ -84,3 +84,26 @@ def test_spawn_starts_one_rank_per_gpu_like_the_reference(tmp_path):
     parallel.spawn(_spawn_body, 2, (str(tmp_path),), master_port=_free_port())
     got = sorted(open(str(tmp_path / ("rank%d.txt" % r))).read() for r in range(2))
     assert got == ["0 2 3.0", "1 2 3.0"]
+
+
+def test_loader_workers_do_not_oversubscribe_the_host():
+    """Every rank of a node runs its own DataLoader worker pool (train.py): the per-rank worker count is capped so that all ranks
+    together stay within the cores this process may use."""
+    from rel_pose_amd import parallel
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cores = os.cpu_count() or 1
+    for world in (1, 2, 8):
+        nw = parallel.loader_workers(64, world)
+        assert 0 <= nw <= 64 and nw * world + world <= max(cores, world)          # workers + one main thread per rank
+        assert parallel.loader_workers(0, world) == 0
+    assert parallel.loader_workers(1, 1) == min(1, max(cores - 1, 0))
+    assert parallel.loader_workers(4, 10 ** 6) == 0                                 # more ranks than cores: load in the main process
+
+
+def test_ddp_wrapper_uses_bucket_views_and_the_documented_cap():
+    from rel_pose_amd import parallel
+    import inspect
+    src = inspect.getsource(parallel.wrap)
+    assert "gradient_as_bucket_view=True" in src and "bucket_cap_mb=BUCKET_CAP_MB" in src and parallel.BUCKET_CAP_MB == 8

@@ -139,8 +139,13 @@ def run(args):
                                  raw=device_augment)
         smp = (torch.utils.data.distributed.DistributedSampler(db, num_replicas=world, rank=rank, shuffle=is_training)
                if ddp else None)
+        # every rank runs its own worker pool: cap it so that the ranks of this node together do not oversubscribe the host cores
+        nw = parallel.loader_workers(args.num_workers, world if ddp else 1)
+        if nw < args.num_workers and rank == 0 and subepoch == 0:
+            print("note: --num_workers %d capped to %d per rank (%d ranks share this host's cores; ~14 decode cores feed one GPU, "
+                  "README.md)" % (args.num_workers, nw, world if ddp else 1))
         ld = torch.utils.data.DataLoader(db, batch_size=args.batch, sampler=smp, shuffle=(smp is None and is_training),
-                                         num_workers=args.num_workers, pin_memory=True, drop_last=is_training)
+                                         num_workers=nw, pin_memory=True, drop_last=is_training)
         return ld, smp, is_training
 
     # Input pipeline: with --device_augment (default on a GPU) the workers only decode; colour jitter, resize

@@ -36,7 +36,7 @@ extern "C" {
  * functions this header declares.  rp_abi_version() / rp_abi_export_count() return the values the library was COMPILED with, so a
  * binding (rel_pose_amd/_lib.py parses both macros and counts the declarations) rejects a stale .so at load time instead of
  * failing later on a missing symbol. */
-#define RP_ABI_VERSION 7
+#define RP_ABI_VERSION 8
 #define RP_ABI_EXPORTS 65
 int rp_abi_version(void);
 int rp_abi_export_count(void);
@@ -144,23 +144,27 @@ int rp_transpose_multi(const RpTransposeTask* tasks, int n, void* stream);
  *                    from x, bit-identically -- y then need not be kept);  dbeta = sum g;  dgamma = sum g * xhat;
  *                    training: dx = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat));  eval: dx = gamma*rstd*g;
  *                    dres != NULL: g is also stored there (gradient of the residual branch).  c12: [2][C] floats scratch.
+ * `bf16` (these and the pool entry points below): 0 = the activation tensors (x, y, residual, dy, dx, dres, the pooled tensors) are
+ * fp32; 1 = they are bf16 in memory (2 bytes per element, the storage MIOpen's bf16 convolutions of the bf16 configuration read and
+ * write -- BASELINE.json configs[4]), widened exactly on load and rounded to nearest-even on store.  Statistics, per-channel
+ * parameters and all arithmetic are fp32 / double in both cases.
  * ------------------------------------------------------------------------------------------- */
 int rp_bn_partial_blocks(long long R);
-int rp_bn_stats(const float* x, long long R, int C, double* partial, float* mean, float* rstd, float* running_mean,
-                float* running_var, float momentum, float eps, void* stream);
+int rp_bn_stats(const void* x, long long R, int C, double* partial, float* mean, float* rstd, float* running_mean,
+                float* running_var, float momentum, float eps, int bf16, void* stream);
 int rp_bn_stats_from_partials(const double* partial, int nblk, long long R, int C, const float* pivot, float* mean, float* rstd,
                               float* running_mean, float* running_var, float momentum, float eps, void* stream);
-int rp_bn_apply_fwd(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                    const float* residual, float* y, long long R, int C, int relu, void* stream);
-int rp_bn_bwd(const float* dy, const float* y, const float* x, const float* mean, const float* rstd, const float* gamma,
-              const float* beta, float* dx, float* dres, float* dgamma, float* dbeta, double* partial, float* c12, long long R, int C, int relu,
-              int training, void* stream);
+int rp_bn_apply_fwd(const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                    const void* residual, void* y, long long R, int C, int relu, int bf16, void* stream);
+int rp_bn_bwd(const void* dy, const void* y, const void* x, const float* mean, const float* rstd, const float* gamma,
+              const float* beta, void* dx, void* dres, float* dgamma, float* dbeta, double* partial, float* c12, long long R, int C, int relu,
+              int training, int bf16, void* stream);
 
 /* 3x3 / stride 2 / pad 1 max-pool (torchvision resnet.maxpool as driven by src/model.py:130), channels-last:
  * x [N,H,W,C] -> y [N,OH,OW,C], OH = (H-1)/2+1; idx (bytes, same shape as y) = window position 0..8 of the first maximum in scan
  * order (PyTorch's tie rule); backward gathers dy through idx into dx [N,H,W,C] (no atomics). */
-int rp_maxpool3x3s2_fwd(const float* x, float* y, unsigned char* idx, int N, int H, int W, int C, void* stream);
-int rp_maxpool3x3s2_bwd(const float* dy, const unsigned char* idx, float* dx, int N, int H, int W, int C, void* stream);
+int rp_maxpool3x3s2_fwd(const void* x, void* y, unsigned char* idx, int N, int H, int W, int C, int bf16, void* stream);
+int rp_maxpool3x3s2_bwd(const void* dy, const unsigned char* idx, void* dx, int N, int H, int W, int C, int bf16, void* stream);
 
 /* The stem convolution (torchvision resnet.conv1: 7x7, stride 2, pad 3, 3 -> 64, no bias; src/model.py:127), forward, hand-written
  * implicit GEMM (csrc/conv_stem.hip).  x_padded [N, H+6, W+6, 3]: the channels-last image inside a 3-pixel zero frame; w [64,7,7,3]
@@ -176,11 +180,11 @@ int rp_conv_stem_fwd(const float* x_padded, const float* w, float* y, double* st
  * position (0..8) of the first maximum, bit-identical to rp_bn_apply_fwd(relu) + rp_maxpool3x3s2_fwd.  Backward: dp = gradient of y,
  * dx = gradient of the BatchNorm input, dgamma / dbeta; equal to rp_maxpool3x3s2_bwd + rp_bn_bwd up to fp32 summation order (the
  * column sums run window-major over dp, the dx pass gathers the pool gradient on the fly; the pool-backward tensor never exists).  partial: rp_bn_partial_blocks(N*H*W) * 2 * C doubles; c12: 2 * C floats. */
-int rp_bn_relu_pool_fwd(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, float* y,
-                        unsigned char* idx, int N, int H, int W, int C, void* stream);
-int rp_bn_relu_pool_bwd(const float* dp, const unsigned char* idx, const float* x, const float* mean, const float* rstd,
-                        const float* gamma, const float* beta, float* dx, float* dgamma, float* dbeta, double* partial, float* c12,
-                        int N, int H, int W, int C, int training, void* stream);
+int rp_bn_relu_pool_fwd(const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta, void* y,
+                        unsigned char* idx, int N, int H, int W, int C, int bf16, void* stream);
+int rp_bn_relu_pool_bwd(const void* dp, const unsigned char* idx, const void* x, const float* mean, const float* rstd,
+                        const float* gamma, const float* beta, void* dx, float* dgamma, float* dbeta, double* partial, float* c12,
+                        int N, int H, int W, int C, int training, int bf16, void* stream);
 
 /* Geodesic pose loss of the training step (reference src/geom/losses.py:3-21; SE(3) arithmetic as restated in
  * rel_pose_amd/se3.py since lietorch is not vendored): Ps, Gs [B,2,7] (t, q xyzw);

@@ -68,13 +68,13 @@ _SIGS = {
     "rp_gemm_workspace_bytes": (c_size_t, [I, I, I]),
     "rp_splitk_reduce_multi": (c_int, [POINTER(RpSplitkTask), I, P]),
     "rp_transpose_multi": (c_int, [POINTER(RpTransposeTask), I, P]),
-    "rp_maxpool3x3s2_fwd": (c_int, [P, P, P, I, I, I, I, P]),
-    "rp_maxpool3x3s2_bwd": (c_int, [P, P, P, I, I, I, I, P]),
+    "rp_maxpool3x3s2_fwd": (c_int, [P, P, P, I, I, I, I, I, P]),
+    "rp_maxpool3x3s2_bwd": (c_int, [P, P, P, I, I, I, I, I, P]),
     "rp_geodesic_loss": (c_int, [P, P, P, P, P, I, P]),
     "rp_bn_partial_blocks": (c_int, [L]),
-    "rp_bn_stats": (c_int, [P, L, I, P, P, P, P, P, F, F, P]),
-    "rp_bn_apply_fwd": (c_int, [P, P, P, P, P, P, P, L, I, I, P]),
-    "rp_bn_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, P]),
+    "rp_bn_stats": (c_int, [P, L, I, P, P, P, P, P, F, F, I, P]),
+    "rp_bn_apply_fwd": (c_int, [P, P, P, P, P, P, P, L, I, I, I, P]),
+    "rp_bn_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, P]),
     "rp_layernorm_fwd": (c_int, [P, P, P, P, P, P, I, I, F, P]),
     "rp_layernorm_bwd_blocks": (c_int, [I]),
     "rp_layernorm_bwd": (c_int, [P, P, P, P, P, P, P, P, P, I, I, P]),
@@ -109,8 +109,8 @@ _SIGS = {
     "rp_conv_stem_blocks": (c_int, [I, I, I]),
     "rp_conv_stem_fwd": (c_int, [P, P, P, P, I, I, I, P]),
     "rp_bn_stats_from_partials": (c_int, [P, I, L, I, P, P, P, P, P, F, F, P]),
-    "rp_bn_relu_pool_fwd": (c_int, [P, P, P, P, P, P, P, I, I, I, I, P]),
-    "rp_bn_relu_pool_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
+    "rp_bn_relu_pool_fwd": (c_int, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
+    "rp_bn_relu_pool_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
     "rp_event_create": (c_void_p, []),
     "rp_event_destroy": (None, [P]),
     "rp_event_elapsed_ms": (c_float, [P, P]),

@@ -18,6 +18,27 @@ namespace {
 
 constexpr int BN_MAXC = 256;
 
+// Element type of the ACTIVATIONS and their gradients (x, y, residual, dy, dx, the pooled tensors): float, or bf16 storage for the
+// bf16 configuration (BASELINE.json configs[4]: MIOpen's bf16 convolutions read and write bf16 channels-last tensors; keeping the
+// BatchNorm / ReLU / pool passes between them in bf16 halves their HBM traffic and removes the fp32 <-> bf16 cast kernels around every
+// convolution -- 6.3 ms of the 34 ms step at 128 pairs, profiles/r2_bf16_128pairs_full_step_summary.txt).  All arithmetic, the
+// statistics and the per-channel parameters stay fp32 / double; bf16 values are widened exactly on load and rounded to nearest-even
+// on store.
+typedef unsigned short bf16s;      // storage only
+template <typename T> RP_DEV float4 ldv(const T* p);
+template <> RP_DEV float4 ldv<float>(const float* p) { return ld4(p); }
+template <> RP_DEV float4 ldv<bf16s>(const bf16s* p) {
+  const uint2 w = *reinterpret_cast<const uint2*>(p);
+  return make_float4(__builtin_bit_cast(float, w.x << 16), __builtin_bit_cast(float, w.x & 0xffff0000u),
+                     __builtin_bit_cast(float, w.y << 16), __builtin_bit_cast(float, w.y & 0xffff0000u));
+}
+template <typename T> RP_DEV void stv(T* p, float4 v);
+template <> RP_DEV void stv<float>(float* p, float4 v) { st4(p, v); }
+template <> RP_DEV void stv<bf16s>(bf16s* p, float4 v) { *reinterpret_cast<uint2*>(p) = make_uint2(pk_bf16(v.x, v.y), pk_bf16(v.z, v.w)); }
+template <typename T> RP_DEV float ld1(const T* p);
+template <> RP_DEV float ld1<float>(const float* p) { return *p; }
+template <> RP_DEV float ld1<bf16s>(const bf16s* p) { return __builtin_bit_cast(float, (unsigned)(*p) << 16); }
+
 // the normalisation, written with explicit fmas: the backward kernels re-evaluate it to rebuild the ReLU mask from x alone
 // (no residual), and must get bit-identical values
 RP_DEV float4 bn_affine(const float4 xv, const float4 mu, const float4 rs, const float4 ga, const float4 be) {
@@ -38,11 +59,12 @@ inline int bn_rows_per_block(long long R) {
 // gradient dp [N,OH,OW,C] through the stored window positions (every pixel looks at the <= 4 windows that contain it: exactly
 // maxpool_bwd_kernel's sum, same order), so the [N,H,W,C] pool-backward tensor is never written nor re-read twice.
 struct PoolSrc {
-  const float* dp;
+  const void* dp;
   const unsigned char* idx;
   int H, W, OH, OW;
 };
 
+template <typename T>
 RP_DEV float4 pool_gather(const PoolSrc& ps, unsigned row, int C, int c) {     // row = (n * H + ih) * W + iw (< 2^31), c = first of 4 channels
   const unsigned t = row / (unsigned)ps.W;                                       // 32-bit index arithmetic: these run per element
   const int iw = (int)(row - t * (unsigned)ps.W);
@@ -62,7 +84,7 @@ RP_DEV float4 pool_gather(const PoolSrc& ps, unsigned row, int C, int c) {     /
       if (ow >= ps.OW || kw < 0 || kw > 2) continue;
       const unsigned o = (((unsigned)n * ps.OH + oh) * ps.OW + ow) * C + c;       // pooled tensor < 2^32 elements (checked by the host)
       const uchar4 k4 = *reinterpret_cast<const uchar4*>(ps.idx + o);
-      const float4 d = ld4(ps.dp + o);
+      const float4 d = ldv<T>(static_cast<const T*>(ps.dp) + o);
       const int k = kh * 3 + kw;
       if (k4.x == k) g.x += d.x;
       if (k4.y == k) g.y += d.y;
@@ -75,11 +97,11 @@ RP_DEV float4 pool_gather(const PoolSrc& ps, unsigned row, int C, int c) {     /
 
 // stage 1: column sums of (a, b) over this block's rows.  MODE 0: a = x, b = x*x.
 // MODE 1: g = dy * (relu ? y > 0 : 1); a = g, b = g * xhat, xhat = (x - mean) * rstd; optionally stores g.
-template <int MODE, bool POOL = false>
-__global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                        const float* __restrict__ y, const float* __restrict__ mean,
+template <int MODE, bool POOL, typename T>
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                        const T* __restrict__ y, const float* __restrict__ mean,
                                                         const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, float* __restrict__ gout,
+                                                        const float* __restrict__ beta, T* __restrict__ gout,
                                                         double* __restrict__ partial, long long R, int C, int rpb, int relu,
                                                         PoolSrc ps = PoolSrc{}) {
   __shared__ double red[2][256][4];
@@ -92,7 +114,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
     if (MODE == 1) { mu = ld4(mean + 4 * cg); rs = ld4(rstd + 4 * cg); }
     // MODE 0 sums (x - pivot) and (x - pivot)^2 with pivot = row 0 of the tensor: E[d^2] - E[d]^2 then has no cancellation
     // even when |mean| >> std (d is O(std) whenever the data are concentrated anywhere)
-    const float4 pv = MODE == 0 ? ld4(x + 4 * cg) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 pv = MODE == 0 ? ldv<T>(x + 4 * cg) : make_float4(0.f, 0.f, 0.f, 0.f);
     const bool remask = MODE == 1 && relu && y == nullptr;       // ReLU mask rebuilt from x (no residual was added)
     if (remask) { ga = ld4(gamma + 4 * cg); be = ld4(beta + 4 * cg); }
     float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa;
@@ -119,10 +141,10 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const long long off = (r + (long long)u * nrl) * C + 4 * cg;
-        xv[u] = ld4(x + off);
+        xv[u] = ldv<T>(x + off);
         if (MODE == 1) {
-          g[u] = POOL ? pool_gather(ps, (unsigned)(r + (long long)u * nrl), C, 4 * cg) : ld4(dy + off);
-          if (relu && !remask) yv[u] = ld4(y + off);
+          g[u] = POOL ? pool_gather<T>(ps, (unsigned)(r + (long long)u * nrl), C, 4 * cg) : ldv<T>(dy + off);
+          if (relu && !remask) yv[u] = ldv<T>(y + off);
         }
       }
 #pragma unroll
@@ -130,7 +152,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
         if (MODE == 1) {
           if (remask) yv[u] = bn_affine(xv[u], mu, rs, ga, be);
           if (relu) g[u] = mask(g[u], yv[u]);
-          if (gout) st4(gout + (r + (long long)u * nrl) * C + 4 * cg, g[u]);
+          if (gout) stv<T>(gout + (r + (long long)u * nrl) * C + 4 * cg, g[u]);
         }
         acc1(xv[u], g[u], yv[u]);
       }
@@ -143,12 +165,12 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
     }
     for (; r < r1; r += nrl) {
       const long long off = r * C + 4 * cg;
-      const float4 xv = ld4(x + off);
+      const float4 xv = ldv<T>(x + off);
       float4 g = make_float4(0.f, 0.f, 0.f, 0.f), yv = g;
       if (MODE == 1) {
-        g = POOL ? pool_gather(ps, (unsigned)r, C, 4 * cg) : ld4(dy + off);
-        if (relu) { yv = remask ? bn_affine(xv, mu, rs, ga, be) : ld4(y + off); g = mask(g, yv); }
-        if (gout) st4(gout + off, g);
+        g = POOL ? pool_gather<T>(ps, (unsigned)r, C, 4 * cg) : ldv<T>(dy + off);
+        if (relu) { yv = remask ? bn_affine(xv, mu, rs, ga, be) : ldv<T>(y + off); g = mask(g, yv); }
+        if (gout) stv<T>(gout + off, g);
       }
       acc1(xv, g, yv);
     }
@@ -172,12 +194,12 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
 // independent and in flight together -- the round-2 form walked 64 partials per lane behind each other and took 11 us, 26 times per
 // step), then the 64 lane sums of a channel are combined through LDS in a fixed order (8 x 8), all in double.
 // MODE 0: mean, rstd (+ running statistics update).  MODE 1: dbeta, dgamma and the two means of the dx pass.
-template <int MODE>
+template <int MODE, typename TP = float>
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const double* __restrict__ partial, int nblk, int C, long long R,
                                                            float* __restrict__ o0, float* __restrict__ o1,
                                                            float* __restrict__ run_mean, float* __restrict__ run_var,
                                                            float momentum, float eps, float* __restrict__ c12,
-                                                           const float* __restrict__ pivot) {
+                                                           const TP* __restrict__ pivot) {
   __shared__ double red[2][64][16];
   const int cl = threadIdx.x & 15, lane = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl;
@@ -215,7 +237,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const double* __restr
     const double md = a / (double)R;                 // mean of (x - pivot)
     double var = b / (double)R - md * md;
     if (var < 0.0) var = 0.0;
-    const double m = md + (double)pivot[c];
+    const double m = md + (double)ld1<TP>(pivot + c);
     o0[c] = (float)m;
     o1[c] = (float)(1.0 / sqrt(var + (double)eps));
     if (run_mean) {
@@ -232,45 +254,46 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const double* __restr
 }
 
 // y = relu?((x - mean) * rstd * gamma + beta (+ residual))
-__global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const T* __restrict__ x, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, const float* __restrict__ res,
-                                                           float* __restrict__ y, long long n4, int c4n, int relu) {
+                                                           const float* __restrict__ beta, const T* __restrict__ res,
+                                                           T* __restrict__ y, long long n4, int c4n, int relu) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
     const int c = 4 * (int)(i % c4n);
-    const float4 xv = ld4(x + 4 * i), mu = ld4(mean + c), rs = ld4(rstd + c), ga = ld4(gamma + c), be = ld4(beta + c);
+    const float4 xv = ldv<T>(x + 4 * i), mu = ld4(mean + c), rs = ld4(rstd + c), ga = ld4(gamma + c), be = ld4(beta + c);
     float4 v;
     v = bn_affine(xv, mu, rs, ga, be);
     if (res) {
-      const float4 r = ld4(res + 4 * i);
+      const float4 r = ldv<T>(res + 4 * i);
       v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
     }
     if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-    st4(y + 4 * i, v);
+    stv<T>(y + 4 * i, v);
   }
 }
 
 // dx = gamma * rstd * (g - c1 - xhat * c2)   (training);   dx = gamma * rstd * g   (eval: c12 == nullptr)
 // g is read from `g` when given (it was stored by the reduce pass for the residual branch), else recomputed from dy, y
-template <bool POOL = false>
-__global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                                           const float* __restrict__ gin, const float* __restrict__ x,
+template <bool POOL, typename T>
+__global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y,
+                                                           const T* __restrict__ gin, const T* __restrict__ x,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           const float* __restrict__ c12, float* __restrict__ dx, long long n4,
+                                                           const float* __restrict__ c12, T* __restrict__ dx, long long n4,
                                                            int c4n, int relu, PoolSrc ps = PoolSrc{}) {
   const int C = 4 * c4n;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
     const int c = 4 * (int)(i % c4n);
     const float4 rs = ld4(rstd + c), ga = ld4(gamma + c), mu = ld4(mean + c);
-    const float4 xv = ld4(x + 4 * i);
+    const float4 xv = ldv<T>(x + 4 * i);
     float4 g;
     if (gin) {
-      g = ld4(gin + 4 * i);
+      g = ldv<T>(gin + 4 * i);
     } else {
-      g = POOL ? pool_gather(ps, (unsigned)i / (unsigned)c4n, C, c) : ld4(dy + 4 * i);
+      g = POOL ? pool_gather<T>(ps, (unsigned)i / (unsigned)c4n, C, c) : ldv<T>(dy + 4 * i);
       if (relu) {
-        const float4 yv = y ? ld4(y + 4 * i) : bn_affine(xv, mu, rs, ga, ld4(beta + c));
+        const float4 yv = y ? ldv<T>(y + 4 * i) : bn_affine(xv, mu, rs, ga, ld4(beta + c));
         g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f; g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
       }
     }
@@ -284,7 +307,7 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float* __restri
     } else {
       v.x = ga.x * rs.x * g.x; v.y = ga.y * rs.y * g.y; v.z = ga.z * rs.z * g.z; v.w = ga.w * rs.w * g.w;
     }
-    st4(dx + 4 * i, v);
+    stv<T>(dx + 4 * i, v);
   }
 }
 
@@ -304,18 +327,24 @@ extern "C" int rp_bn_partial_blocks(long long R) {
   return (int)((R + rpb - 1) / rpb);
 }
 
-extern "C" int rp_bn_stats(const float* x, long long R, int C, double* partial, float* mean, float* rstd, float* running_mean,
-                           float* running_var, float momentum, float eps, void* stream) {
-  if (int e = bn_check(R, C)) return e;
-  hipStream_t st = (hipStream_t)stream;
+template <typename T>
+static int bn_stats_t(const T* x, long long R, int C, double* partial, float* mean, float* rstd, float* running_mean,
+                      float* running_var, float momentum, float eps, hipStream_t st) {
   const int rpb = bn_rows_per_block(R), nblk = (int)((R + rpb - 1) / rpb);
-  hipLaunchKernelGGL((bn_reduce_kernel<0, false>), dim3(nblk), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                     nullptr, partial, R, C, rpb, 0, PoolSrc{});
+  hipLaunchKernelGGL((bn_reduce_kernel<0, false, T>), dim3(nblk), dim3(256), 0, st, x, (const T*)nullptr, (const T*)nullptr, nullptr, nullptr,
+                     nullptr, nullptr, (T*)nullptr, partial, R, C, rpb, 0, PoolSrc{});
   RP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3((C + 15) / 16), dim3(1024), 0, st, (const double*)partial, nblk, C, R, mean,
+  hipLaunchKernelGGL((bn_finalize_kernel<0, T>), dim3((C + 15) / 16), dim3(1024), 0, st, (const double*)partial, nblk, C, R, mean,
                      rstd, running_mean, running_var, momentum, eps, nullptr, x);
   RP_CHECK_LAUNCH();
   return RP_OK;
+}
+
+extern "C" int rp_bn_stats(const void* x, long long R, int C, double* partial, float* mean, float* rstd, float* running_mean,
+                           float* running_var, float momentum, float eps, int bf16, void* stream) {
+  if (int e = bn_check(R, C)) return e;
+  if (bf16) return bn_stats_t((const bf16s*)x, R, C, partial, mean, rstd, running_mean, running_var, momentum, eps, (hipStream_t)stream);
+  return bn_stats_t((const float*)x, R, C, partial, mean, rstd, running_mean, running_var, momentum, eps, (hipStream_t)stream);
 }
 
 // statistics from per-block partial sums produced elsewhere (rp_conv_stem_fwd's epilogue): partial [nblk][2][C] doubles =
@@ -325,40 +354,51 @@ extern "C" int rp_bn_stats_from_partials(const double* partial, int nblk, long l
                                          void* stream) {
   if (int e = bn_check(R, C)) return e;
   if (nblk <= 0 || !partial || !pivot) return RP_EBADSHAPE;
-  hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3((C + 15) / 16), dim3(1024), 0, (hipStream_t)stream, partial, nblk, C, R, mean, rstd,
+  hipLaunchKernelGGL((bn_finalize_kernel<0, float>), dim3((C + 15) / 16), dim3(1024), 0, (hipStream_t)stream, partial, nblk, C, R, mean, rstd,
                      running_mean, running_var, momentum, eps, nullptr, pivot);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }
 
-extern "C" int rp_bn_apply_fwd(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                               const float* residual, float* y, long long R, int C, int relu, void* stream) {
+extern "C" int rp_bn_apply_fwd(const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                               const void* residual, void* y, long long R, int C, int relu, int bf16, void* stream) {
   if (int e = bn_check(R, C)) return e;
   const long long n4 = R * C / 4;
-  hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(apply_grid(n4)), dim3(256), 0, (hipStream_t)stream, x, mean, rstd, gamma, beta,
-                     residual, y, n4, C / 4, relu);
+  if (bf16) hipLaunchKernelGGL(bn_apply_fwd_kernel<bf16s>, dim3(apply_grid(n4)), dim3(256), 0, (hipStream_t)stream, (const bf16s*)x, mean, rstd,
+                               gamma, beta, (const bf16s*)residual, (bf16s*)y, n4, C / 4, relu);
+  else hipLaunchKernelGGL(bn_apply_fwd_kernel<float>, dim3(apply_grid(n4)), dim3(256), 0, (hipStream_t)stream, (const float*)x, mean, rstd, gamma,
+                          beta, (const float*)residual, (float*)y, n4, C / 4, relu);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }
 
-extern "C" int rp_bn_bwd(const float* dy, const float* y, const float* x, const float* mean, const float* rstd,
-                         const float* gamma, const float* beta, float* dx, float* dres, float* dgamma, float* dbeta,
-                         double* partial, float* c12, long long R, int C, int relu, int training, void* stream) {
-  if (int e = bn_check(R, C)) return e;
-  if (relu && !y && !beta) return RP_EBADSHAPE;
-  hipStream_t st = (hipStream_t)stream;
+template <typename T>
+static int bn_bwd_t(const T* dy, const T* y, const T* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                    T* dx, T* dres, float* dgamma, float* dbeta, double* partial, float* c12, long long R, int C, int relu, int training,
+                    hipStream_t st) {
   const int rpb = bn_rows_per_block(R), nblk = (int)((R + rpb - 1) / rpb);
-  hipLaunchKernelGGL((bn_reduce_kernel<1, false>), dim3(nblk), dim3(256), 0, st, x, dy, y, mean, rstd, gamma, beta, dres, partial, R, C, rpb,
+  hipLaunchKernelGGL((bn_reduce_kernel<1, false, T>), dim3(nblk), dim3(256), 0, st, x, dy, y, mean, rstd, gamma, beta, dres, partial, R, C, rpb,
                      relu, PoolSrc{});
   RP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3((C + 15) / 16), dim3(1024), 0, st, (const double*)partial, nblk, C, R, dbeta,
+  hipLaunchKernelGGL((bn_finalize_kernel<1, float>), dim3((C + 15) / 16), dim3(1024), 0, st, (const double*)partial, nblk, C, R, dbeta,
                      dgamma, nullptr, nullptr, 0.f, 0.f, c12, nullptr);
   RP_CHECK_LAUNCH();
   const long long n4 = R * C / 4;
-  hipLaunchKernelGGL(bn_apply_bwd_kernel<false>, dim3(apply_grid(n4)), dim3(256), 0, st, dy, y, (const float*)dres, x, mean, rstd, gamma,
+  hipLaunchKernelGGL((bn_apply_bwd_kernel<false, T>), dim3(apply_grid(n4)), dim3(256), 0, st, dy, y, (const T*)dres, x, mean, rstd, gamma,
                      beta, training ? (const float*)c12 : nullptr, dx, n4, C / 4, relu, PoolSrc{});
   RP_CHECK_LAUNCH();
   return RP_OK;
+}
+
+extern "C" int rp_bn_bwd(const void* dy, const void* y, const void* x, const float* mean, const float* rstd,
+                         const float* gamma, const float* beta, void* dx, void* dres, float* dgamma, float* dbeta,
+                         double* partial, float* c12, long long R, int C, int relu, int training, int bf16, void* stream) {
+  if (int e = bn_check(R, C)) return e;
+  if (relu && !y && !beta) return RP_EBADSHAPE;
+  if (bf16) return bn_bwd_t((const bf16s*)dy, (const bf16s*)y, (const bf16s*)x, mean, rstd, gamma, beta, (bf16s*)dx, (bf16s*)dres, dgamma, dbeta,
+                            partial, c12, R, C, relu, training, (hipStream_t)stream);
+  return bn_bwd_t((const float*)dy, (const float*)y, (const float*)x, mean, rstd, gamma, beta, (float*)dx, (float*)dres, dgamma, dbeta, partial,
+                  c12, R, C, relu, training, (hipStream_t)stream);
 }
 
 // ---- 3x3 / stride 2 / pad 1 max-pool of the stem (torchvision resnet.maxpool), channels-last --------------------------
@@ -368,7 +408,8 @@ extern "C" int rp_bn_bwd(const float* dy, const float* y, const float* x, const 
 // is a gather (every input pixel looks at the <= 4 windows that contain it), no atomics.
 namespace {
 
-__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                           unsigned char* __restrict__ idx, int N, int H, int W, int C, int OH,
                                                           int OW) {
   const int c4n = C >> 2;
@@ -389,7 +430,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
       for (int kw = 0; kw < 3; ++kw) {
         const int iw = 2 * ow - 1 + kw;
         if (iw < 0 || iw >= W) continue;
-        const float4 v = ld4(x + (((long long)n * H + ih) * W + iw) * C + 4 * c4);
+        const float4 v = ldv<T>(x + (((long long)n * H + ih) * W + iw) * C + 4 * c4);
         const int k = kh * 3 + kw;
         if (v.x > m.x) { m.x = v.x; kx = k; }
         if (v.y > m.y) { m.y = v.y; ky = k; }
@@ -397,13 +438,14 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
         if (v.w > m.w) { m.w = v.w; kw_ = k; }
       }
     }
-    st4(y + 4 * i, m);
+    stv<T>(y + 4 * i, m);
     *reinterpret_cast<uchar4*>(idx + 4 * i) = make_uchar4((unsigned char)kx, (unsigned char)ky, (unsigned char)kz, (unsigned char)kw_);
   }
 }
 
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ idx,
-                                                          float* __restrict__ dx, int N, int H, int W, int C, int OH, int OW) {
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dy, const unsigned char* __restrict__ idx,
+                                                          T* __restrict__ dx, int N, int H, int W, int C, int OH, int OW) {
   const int c4n = C >> 2;
   const long long total = (long long)N * H * W * c4n;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -427,7 +469,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
         if (ow >= OW || kw < 0 || kw > 2) continue;
         const long long o = ((((long long)n * OH + oh) * OW + ow) * c4n + c4) * 4;
         const uchar4 k4 = *reinterpret_cast<const uchar4*>(idx + o);
-        const float4 d = ld4(dy + o);
+        const float4 d = ldv<T>(dy + o);
         const int k = kh * 3 + kw;
         if (k4.x == k) g.x += d.x;
         if (k4.y == k) g.y += d.y;
@@ -435,26 +477,32 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
         if (k4.w == k) g.w += d.w;
       }
     }
-    st4(dx + 4 * i, g);
+    stv<T>(dx + 4 * i, g);
   }
 }
 
 }  // namespace
 
-extern "C" int rp_maxpool3x3s2_fwd(const float* x, float* y, unsigned char* idx, int N, int H, int W, int C, void* stream) {
+extern "C" int rp_maxpool3x3s2_fwd(const void* x, void* y, unsigned char* idx, int N, int H, int W, int C, int bf16, void* stream) {
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return RP_EBADSHAPE;
   const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
   const long long total = (long long)N * OH * OW * (C / 4);
-  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(apply_grid(total)), dim3(256), 0, (hipStream_t)stream, x, y, idx, N, H, W, C, OH, OW);
+  if (bf16) hipLaunchKernelGGL(maxpool_fwd_kernel<bf16s>, dim3(apply_grid(total)), dim3(256), 0, (hipStream_t)stream, (const bf16s*)x, (bf16s*)y, idx,
+                               N, H, W, C, OH, OW);
+  else hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(apply_grid(total)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, idx, N, H,
+                          W, C, OH, OW);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }
 
-extern "C" int rp_maxpool3x3s2_bwd(const float* dy, const unsigned char* idx, float* dx, int N, int H, int W, int C, void* stream) {
+extern "C" int rp_maxpool3x3s2_bwd(const void* dy, const unsigned char* idx, void* dx, int N, int H, int W, int C, int bf16, void* stream) {
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return RP_EBADSHAPE;
   const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
   const long long total = (long long)N * H * W * (C / 4);
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(apply_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, idx, dx, N, H, W, C, OH, OW);
+  if (bf16) hipLaunchKernelGGL(maxpool_bwd_kernel<bf16s>, dim3(apply_grid(total)), dim3(256), 0, (hipStream_t)stream, (const bf16s*)dy, idx, (bf16s*)dx,
+                               N, H, W, C, OH, OW);
+  else hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(apply_grid(total)), dim3(256), 0, (hipStream_t)stream, (const float*)dy, idx, (float*)dx, N,
+                          H, W, C, OH, OW);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }
@@ -465,9 +513,10 @@ namespace {
 
 // pooled[n,oh,ow,c] = max over the window of relu(bn(x)); idx = window position of the FIRST maximum (strict >), i.e. exactly
 // maxpool_fwd_kernel applied to bn_apply_fwd_kernel's output, which is never written
-__global__ __launch_bounds__(256) void bn_pool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_pool_fwd_kernel(const T* __restrict__ x, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, float* __restrict__ y,
+                                                          const float* __restrict__ beta, T* __restrict__ y,
                                                           unsigned char* __restrict__ idx, int N, int H, int W, int C, int OH, int OW) {
   const int c4n = C >> 2;
   const long long total = (long long)N * OH * OW * c4n;
@@ -488,7 +537,7 @@ __global__ __launch_bounds__(256) void bn_pool_fwd_kernel(const float* __restric
       for (int kw = 0; kw < 3; ++kw) {
         const int iw = 2 * ow - 1 + kw;
         if (iw < 0 || iw >= W) continue;
-        float4 v = bn_affine(ld4(x + (((long long)n * H + ih) * W + iw) * C + 4 * c4), mu, rs, ga, be);
+        float4 v = bn_affine(ldv<T>(x + (((long long)n * H + ih) * W + iw) * C + 4 * c4), mu, rs, ga, be);
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         const int k = kh * 3 + kw;
         if (v.x > m.x) { m.x = v.x; kx = k; }
@@ -497,7 +546,7 @@ __global__ __launch_bounds__(256) void bn_pool_fwd_kernel(const float* __restric
         if (v.w > m.w) { m.w = v.w; kw_ = k; }
       }
     }
-    st4(y + 4 * i, m);
+    stv<T>(y + 4 * i, m);
     *reinterpret_cast<uchar4*>(idx + 4 * i) = make_uchar4((unsigned char)kx, (unsigned char)ky, (unsigned char)kz, (unsigned char)kw_);
   }
 }
@@ -506,7 +555,8 @@ __global__ __launch_bounds__(256) void bn_pool_fwd_kernel(const float* __restric
 // position), so the column sums  a = sum g,  b = sum g * xhat  over the [N,H,W,C] pixels are sums over the [N,OH,OW,C] windows of
 // dp * [relu active at the arg-max pixel] (* xhat there): a quarter of the iterations of the pixel-major pass and no window search.
 // (Same sums as bn_reduce_kernel<1>, different order: agrees to fp32 rounding, not bitwise.)
-__global__ __launch_bounds__(256) void bn_pool_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dp,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_pool_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dp,
                                                              const unsigned char* __restrict__ idx, const float* __restrict__ mean,
                                                              const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, double* __restrict__ partial, long long RO,
@@ -527,10 +577,10 @@ __global__ __launch_bounds__(256) void bn_pool_reduce_kernel(const float* __rest
       const unsigned nn = t / (unsigned)OH;
       const int oh = (int)(t - nn * (unsigned)OH);
       const unsigned o = ur * (unsigned)C + 4 * cg;
-      const float4 d = ld4(dp + o);
+      const float4 d = ldv<T>(dp + o);
       const uchar4 k4 = *reinterpret_cast<const uchar4*>(idx + o);
-      const float* xb = x + (((long long)nn * H + (2 * oh - 1)) * W + (2 * ow - 1)) * C + 4 * cg;     // window origin (may be off-image;
-      auto at = [&](int k, int e) { return xb[((k / 3) * W + (k % 3)) * C + e]; };                      //  the arg-max never is)
+      const T* xb = x + (((long long)nn * H + (2 * oh - 1)) * W + (2 * ow - 1)) * C + 4 * cg;         // window origin (may be off-image;
+      auto at = [&](int k, int e) { return ld1<T>(xb + ((k / 3) * W + (k % 3)) * C + e); };             //  the arg-max never is)
       const float xv[4] = {at(k4.x, 0), at(k4.y, 1), at(k4.z, 2), at(k4.w, 3)};
       const float dv[4] = {d.x, d.y, d.z, d.w};
       const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, rsv[4] = {rs.x, rs.y, rs.z, rs.w}, gav[4] = {ga.x, ga.y, ga.z, ga.w},
@@ -568,49 +618,61 @@ __global__ __launch_bounds__(256) void bn_pool_reduce_kernel(const float* __rest
 
 }  // namespace
 
-extern "C" int rp_bn_relu_pool_fwd(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                                   float* y, unsigned char* idx, int N, int H, int W, int C, void* stream) {
+extern "C" int rp_bn_relu_pool_fwd(const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                   void* y, unsigned char* idx, int N, int H, int W, int C, int bf16, void* stream) {
   if (N <= 0 || H <= 0 || W <= 0) return RP_EBADSHAPE;
   if (int e = bn_check((long long)N * H * W, C)) return e;
   const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
   const long long total = (long long)N * OH * OW * (C / 4);
-  hipLaunchKernelGGL(bn_pool_fwd_kernel, dim3(apply_grid(total)), dim3(256), 0, (hipStream_t)stream, x, mean, rstd, gamma, beta, y,
-                     idx, N, H, W, C, OH, OW);
+  if (bf16) hipLaunchKernelGGL(bn_pool_fwd_kernel<bf16s>, dim3(apply_grid(total)), dim3(256), 0, (hipStream_t)stream, (const bf16s*)x, mean, rstd, gamma,
+                               beta, (bf16s*)y, idx, N, H, W, C, OH, OW);
+  else hipLaunchKernelGGL(bn_pool_fwd_kernel<float>, dim3(apply_grid(total)), dim3(256), 0, (hipStream_t)stream, (const float*)x, mean, rstd, gamma,
+                          beta, (float*)y, idx, N, H, W, C, OH, OW);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }
 
-// backward of the same chain: dp = gradient of the pooled output [N,OH,OW,C]; dx = gradient of the BatchNorm INPUT [N,H,W,C]
-extern "C" int rp_bn_relu_pool_bwd(const float* dp, const unsigned char* idx, const float* x, const float* mean, const float* rstd,
-                                   const float* gamma, const float* beta, float* dx, float* dgamma, float* dbeta, double* partial,
-                                   float* c12, int N, int H, int W, int C, int training, void* stream) {
-  if (N <= 0 || H <= 0 || W <= 0 || !dp || !idx || !beta) return RP_EBADSHAPE;
+template <typename T>
+static int bn_relu_pool_bwd_t(const T* dp, const unsigned char* idx, const T* x, const float* mean, const float* rstd, const float* gamma,
+                              const float* beta, T* dx, float* dgamma, float* dbeta, double* partial, float* c12, int N, int H, int W,
+                              int C, int training, hipStream_t st) {
   const long long R = (long long)N * H * W;
-  if (int e = bn_check(R, C)) return e;
-  if (R * C >= (1LL << 32)) return RP_EBADSHAPE;                     // 32-bit element indices in the gather
-  hipStream_t st = (hipStream_t)stream;
   const PoolSrc ps{dp, idx, H, W, (H - 1) / 2 + 1, (W - 1) / 2 + 1};
   int nblk;
   static const bool pixel_major = getenv("RP_BN_POOL_PIXEL_MAJOR") != nullptr;     // A/B aid: the bit-identical pixel-major stage 1
   if (pixel_major) {
     const int rpb = bn_rows_per_block(R);
     nblk = (int)((R + rpb - 1) / rpb);
-    hipLaunchKernelGGL((bn_reduce_kernel<1, true>), dim3(nblk), dim3(256), 0, st, x, nullptr, nullptr, mean, rstd, gamma, beta, nullptr,
-                       partial, R, C, rpb, 1, ps);
+    hipLaunchKernelGGL((bn_reduce_kernel<1, true, T>), dim3(nblk), dim3(256), 0, st, x, (const T*)nullptr, (const T*)nullptr, mean, rstd, gamma, beta,
+                       (T*)nullptr, partial, R, C, rpb, 1, ps);
   } else {
     const long long RO = (long long)N * ps.OH * ps.OW;
     const int rpb = bn_rows_per_block(RO);
     nblk = (int)((RO + rpb - 1) / rpb);                                            // <= the buffer sized for R rows
-    hipLaunchKernelGGL(bn_pool_reduce_kernel, dim3(nblk), dim3(256), 0, st, x, dp, idx, mean, rstd, gamma, beta, partial, RO, C, rpb,
+    hipLaunchKernelGGL(bn_pool_reduce_kernel<T>, dim3(nblk), dim3(256), 0, st, x, dp, idx, mean, rstd, gamma, beta, partial, RO, C, rpb,
                        H, W, ps.OH, ps.OW);
   }
   RP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3((C + 15) / 16), dim3(1024), 0, st, (const double*)partial, nblk, C, R, dbeta,
+  hipLaunchKernelGGL((bn_finalize_kernel<1, float>), dim3((C + 15) / 16), dim3(1024), 0, st, (const double*)partial, nblk, C, R, dbeta,
                      dgamma, nullptr, nullptr, 0.f, 0.f, c12, nullptr);
   RP_CHECK_LAUNCH();
   const long long n4 = R * C / 4;
-  hipLaunchKernelGGL(bn_apply_bwd_kernel<true>, dim3(apply_grid(n4)), dim3(256), 0, st, nullptr, nullptr, nullptr, x, mean, rstd,
-                     gamma, beta, training ? (const float*)c12 : nullptr, dx, n4, C / 4, 1, ps);
+  hipLaunchKernelGGL((bn_apply_bwd_kernel<true, T>), dim3(apply_grid(n4)), dim3(256), 0, st, (const T*)nullptr, (const T*)nullptr, (const T*)nullptr, x,
+                     mean, rstd, gamma, beta, training ? (const float*)c12 : nullptr, dx, n4, C / 4, 1, ps);
   RP_CHECK_LAUNCH();
   return RP_OK;
+}
+
+// backward of the same chain: dp = gradient of the pooled output [N,OH,OW,C]; dx = gradient of the BatchNorm INPUT [N,H,W,C]
+extern "C" int rp_bn_relu_pool_bwd(const void* dp, const unsigned char* idx, const void* x, const float* mean, const float* rstd,
+                                   const float* gamma, const float* beta, void* dx, float* dgamma, float* dbeta, double* partial,
+                                   float* c12, int N, int H, int W, int C, int training, int bf16, void* stream) {
+  if (N <= 0 || H <= 0 || W <= 0 || !dp || !idx || !beta) return RP_EBADSHAPE;
+  const long long R = (long long)N * H * W;
+  if (int e = bn_check(R, C)) return e;
+  if (R * C >= (1LL << 32)) return RP_EBADSHAPE;                     // 32-bit element indices in the gather
+  if (bf16) return bn_relu_pool_bwd_t((const bf16s*)dp, idx, (const bf16s*)x, mean, rstd, gamma, beta, (bf16s*)dx, dgamma, dbeta, partial, c12, N, H,
+                                      W, C, training, (hipStream_t)stream);
+  return bn_relu_pool_bwd_t((const float*)dp, idx, (const float*)x, mean, rstd, gamma, beta, (float*)dx, dgamma, dbeta, partial, c12, N, H, W, C,
+                            training, (hipStream_t)stream);
 }

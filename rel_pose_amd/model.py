@@ -112,12 +112,16 @@ class ViTEss(nn.Module):
     def extract_features(self, images, intrinsics=None):
         """tokens [2B,576,192] WITHOUT pos_embed (reference return value, src/model.py:136-143)."""
         fmap, intrinsics = self.cnn_map(images, intrinsics)
+        if fmap.dtype != torch.float32:
+            fmap = fmap.float()
         zero_pe = torch.zeros_like(self.fusion_transformer.pos_embed[0])
         return ops.TokensFn.apply(fmap, zero_pe), intrinsics
 
     def forward_tokens(self, fmap, Gs_data, intrinsics=None):
         """hot path: CNN map [2B,192,24,24] (or [2B,192,576]) -> normalised poses [B,2,7]."""
         ft = self.fusion_transformer
+        if fmap.dtype != torch.float32:            # bf16 CNN front-end (the bf16 configuration): the token stream is fp32
+            fmap = fmap.float()
         x = ops.TokensFn.apply(fmap, ft.pos_embed[0])
         for layer in range(self.transformer_depth):
             x = ft.blocks[layer](x, intrinsics=intrinsics)

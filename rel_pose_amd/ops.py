@@ -44,6 +44,22 @@ def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+def _chk_act(*ts):
+    """activation tensors of the CNN front-end kernels: contiguous, on the GPU, all fp32 or all bf16 (the bf16 configuration keeps the
+    tensors between MIOpen's bf16 convolutions in bf16).  Returns 1 for bf16, 0 for fp32."""
+    dt = None
+    for t in ts:
+        if t is None:
+            continue
+        if not (t.is_cuda and t.is_contiguous() and t.dtype in (torch.float32, torch.bfloat16)):
+            raise RuntimeError("rel_pose_amd CNN ops need contiguous fp32 / bf16 GPU tensors; got %s %s contiguous=%s"
+                               % (t.device, t.dtype, t.is_contiguous()))
+        if dt is not None and t.dtype != dt:
+            raise RuntimeError("rel_pose_amd CNN ops: mixed activation dtypes %s / %s" % (dt, t.dtype))
+        dt = t.dtype
+    return 1 if dt == torch.bfloat16 else 0
+
+
 def _st():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -1221,18 +1237,19 @@ class BnActFn(_Fn):
             rr = residual.permute(0, 2, 3, 1)
             if not rr.is_contiguous():
                 rr = rr.contiguous()
-        _chk(xr, gamma, beta, rr)
+        _chk(gamma, beta)
+        bf = _chk_act(xr, rr)
         R = N * H * W
         y = torch.empty_like(xr)
         if training:
             mean, rstd = _empty(C, like=xr), _empty(C, like=xr)
             part = torch.empty(lib.rp_bn_partial_blocks(R) * 2 * C, device=x.device, dtype=torch.float64)
             _lib.check(lib.rp_bn_stats(_p(xr), R, C, _p(part), _p(mean), _p(rstd), _p(running_mean), _p(running_var),
-                                       float(momentum), float(eps), _st()), "rp_bn_stats")
+                                       float(momentum), float(eps), bf, _st()), "rp_bn_stats")
         else:
             mean, rstd = running_mean, torch.rsqrt(running_var + eps)
         _lib.check(lib.rp_bn_apply_fwd(_p(xr), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(rr), _p(y), R, C, 1 if relu else 0,
-                                       _st()), "rp_bn_apply_fwd")
+                                       bf, _st()), "rp_bn_apply_fwd")
         if _train(ctx):
             # without a residual the ReLU mask is re-evaluated from x in the backward: y is not kept alive for it
             keep_y = y if (relu and residual is not None) else None
@@ -1248,13 +1265,15 @@ class BnActFn(_Fn):
         dyr = dy.permute(0, 2, 3, 1)
         if not dyr.is_contiguous():
             dyr = dyr.contiguous()
-        _chk(dyr)
+        if dyr.dtype != xr.dtype:
+            dyr = dyr.to(xr.dtype)
+        bf = _chk_act(dyr, xr, y)
         dx = torch.empty_like(xr)
         dres = torch.empty_like(xr) if has_res and ctx.needs_input_grad[5] else None
         dgamma, dbeta, c12 = _empty(C, like=xr), _empty(C, like=xr), _empty(2 * C, like=xr)
         part = torch.empty(lib.rp_bn_partial_blocks(R) * 2 * C, device=xr.device, dtype=torch.float64)
         _lib.check(lib.rp_bn_bwd(_p(dyr), _p(y), _p(xr), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dx), _p(dres), _p(dgamma), _p(dbeta),
-                                 _p(part), _p(c12), R, C, 1 if relu else 0, 1 if training else 0, _st()), "rp_bn_bwd")
+                                 _p(part), _p(c12), R, C, 1 if relu else 0, 1 if training else 0, bf, _st()), "rp_bn_bwd")
         return (dx.permute(0, 3, 1, 2), dgamma, dbeta, None, None,
                 None if dres is None else dres.permute(0, 3, 1, 2), None, None, None, None)
 
@@ -1262,7 +1281,8 @@ class BnActFn(_Fn):
 # Convolution operand precision of the CNN front-end (MIOpen through PyTorch-ROCm): 0 = fp32 (the parity path),
 # 1 = bf16 operands / fp32 accumulate -- part of the bf16 configuration (BASELINE.json configs[4], `bench.py --precision bf16`):
 # the fp32 convolutions are 62 % of that configuration's step otherwise (profiles/r2_conv_probe*.txt: 14.3 -> 4.0 ms per 64 pairs).
-# BatchNorm / residual / ReLU (csrc/batchnorm.hip) stay fp32: activations are cast on the way into and out of each convolution.
+# Round 3: the activations between the convolutions STAY bf16 (csrc/batchnorm.hip takes bf16 storage: statistics and arithmetic in
+# fp32 / double): no cast kernels around the convolutions, half the BatchNorm / ReLU / pool traffic.
 CNN_PRECISION = int(os.environ.get("RP_CNN_PRECISION", "0"))
 
 
@@ -1278,9 +1298,10 @@ def conv2d(m, x):
     if CNN_PRECISION == 0 or not x.is_cuda:
         return m(x)
     bf = torch.bfloat16
-    y = torch.nn.functional.conv2d(x.to(bf), m.weight.to(bf), None if m.bias is None else m.bias.to(bf), m.stride, m.padding,
-                                   m.dilation, m.groups)
-    return y.float()
+    # activations STAY bf16 between the convolutions (the BatchNorm / ReLU / pool kernels of csrc/batchnorm.hip take bf16 storage):
+    # only the first convolution's input and the small weights are cast
+    return torch.nn.functional.conv2d(x if x.dtype == bf else x.to(bf), m.weight.to(bf), None if m.bias is None else m.bias.to(bf),
+                                      m.stride, m.padding, m.dilation, m.groups)
 
 
 _NBT_PENDING = None      # inside `with batches_tracked_batch():` the num_batches_tracked buffers to bump at exit
@@ -1358,11 +1379,11 @@ class MaxPool3x3s2Fn(_Fn):
         xr = x.permute(0, 2, 3, 1)
         if not xr.is_contiguous():
             xr = xr.contiguous()
-        _chk(xr)
+        bf = _chk_act(xr)
         OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-        y = torch.empty(N, OH, OW, C, device=x.device, dtype=torch.float32)
+        y = torch.empty(N, OH, OW, C, device=x.device, dtype=xr.dtype)
         idx = torch.empty(N, OH, OW, C, device=x.device, dtype=torch.uint8)
-        _lib.check(lib.rp_maxpool3x3s2_fwd(_p(xr), _p(y), ctypes.c_void_p(idx.data_ptr()), N, H, W, C, _st()), "rp_maxpool3x3s2_fwd")
+        _lib.check(lib.rp_maxpool3x3s2_fwd(_p(xr), _p(y), ctypes.c_void_p(idx.data_ptr()), N, H, W, C, bf, _st()), "rp_maxpool3x3s2_fwd")
         ctx.save_for_backward(idx)
         ctx.shape = (N, C, H, W)
         return y.permute(0, 3, 1, 2)
@@ -1375,9 +1396,9 @@ class MaxPool3x3s2Fn(_Fn):
         dyr = dy.permute(0, 2, 3, 1)
         if not dyr.is_contiguous():
             dyr = dyr.contiguous()
-        _chk(dyr)
-        dx = torch.empty(N, H, W, C, device=dy.device, dtype=torch.float32)
-        _lib.check(lib.rp_maxpool3x3s2_bwd(_p(dyr), ctypes.c_void_p(idx.data_ptr()), _p(dx), N, H, W, C, _st()), "rp_maxpool3x3s2_bwd")
+        bf = _chk_act(dyr)
+        dx = torch.empty(N, H, W, C, device=dy.device, dtype=dyr.dtype)
+        _lib.check(lib.rp_maxpool3x3s2_bwd(_p(dyr), ctypes.c_void_p(idx.data_ptr()), _p(dx), N, H, W, C, bf, _st()), "rp_maxpool3x3s2_bwd")
         return dx.permute(0, 3, 1, 2)
 
 
@@ -1449,7 +1470,8 @@ class BnReluPoolFn(_Fn):
         xr = x.permute(0, 2, 3, 1)
         if not xr.is_contiguous():
             xr = xr.contiguous()
-        _chk(xr, gamma, beta)
+        _chk(gamma, beta)
+        bf = _chk_act(xr)
         R = N * H * W
         if training and stats is not None:
             mean, rstd = _empty(C, like=xr), _empty(C, like=xr)
@@ -1460,14 +1482,14 @@ class BnReluPoolFn(_Fn):
             mean, rstd = _empty(C, like=xr), _empty(C, like=xr)
             part = torch.empty(lib.rp_bn_partial_blocks(R) * 2 * C, device=x.device, dtype=torch.float64)
             _lib.check(lib.rp_bn_stats(_p(xr), R, C, _p(part), _p(mean), _p(rstd), _p(running_mean), _p(running_var),
-                                       float(momentum), float(eps), _st()), "rp_bn_stats")
+                                       float(momentum), float(eps), bf, _st()), "rp_bn_stats")
         else:
             mean, rstd = running_mean, torch.rsqrt(running_var + eps)
         OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-        y = torch.empty(N, OH, OW, C, device=x.device, dtype=torch.float32)
+        y = torch.empty(N, OH, OW, C, device=x.device, dtype=xr.dtype)
         idx = torch.empty(N, OH, OW, C, device=x.device, dtype=torch.uint8)
         _lib.check(lib.rp_bn_relu_pool_fwd(_p(xr), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(y), ctypes.c_void_p(idx.data_ptr()),
-                                           N, H, W, C, _st()), "rp_bn_relu_pool_fwd")
+                                           N, H, W, C, bf, _st()), "rp_bn_relu_pool_fwd")
         if _train(ctx):
             ctx.save_for_backward(xr, idx, mean, rstd, gamma, beta)
             ctx.cfg = (N, C, H, W, bool(training))
@@ -1481,12 +1503,14 @@ class BnReluPoolFn(_Fn):
         dyr = dy.permute(0, 2, 3, 1)
         if not dyr.is_contiguous():
             dyr = dyr.contiguous()
-        _chk(dyr)
+        if dyr.dtype != xr.dtype:
+            dyr = dyr.to(xr.dtype)
+        bf = _chk_act(dyr, xr)
         dx = torch.empty_like(xr)
         dgamma, dbeta, c12 = _empty(C, like=xr), _empty(C, like=xr), _empty(2 * C, like=xr)
         part = torch.empty(lib.rp_bn_partial_blocks(N * H * W) * 2 * C, device=xr.device, dtype=torch.float64)
         _lib.check(lib.rp_bn_relu_pool_bwd(_p(dyr), ctypes.c_void_p(idx.data_ptr()), _p(xr), _p(mean), _p(rstd), _p(gamma), _p(beta),
-                                           _p(dx), _p(dgamma), _p(dbeta), _p(part), _p(c12), N, H, W, C, 1 if training else 0, _st()),
+                                           _p(dx), _p(dgamma), _p(dbeta), _p(part), _p(c12), N, H, W, C, 1 if training else 0, bf, _st()),
                    "rp_bn_relu_pool_bwd")
         return dx.permute(0, 3, 1, 2), dgamma, dbeta, None, None, None, None, None, None
 

@@ -450,6 +450,75 @@ def test_fused_batchnorm_add_relu(ops, shape, training, with_res, relu):
     assert int(bn.num_batches_tracked) == (1 if training else 0)
 
 
+@pytest.mark.parametrize("with_res,relu", [(False, True), (True, True), (True, False)])
+def test_fused_batchnorm_bf16_storage(ops, with_res, relu):
+    """The bf16 storage mode of csrc/batchnorm.hip (the bf16 configuration keeps the tensors between MIOpen's bf16 convolutions in
+    bf16): same kernels, activations widened exactly on load and rounded to nearest-even on store, statistics / arithmetic fp32.
+    Against fp64 torch.nn.BatchNorm2d ON THE SAME bf16-rounded inputs: outputs and input gradients agree to bf16 rounding (<= 2^-8
+    of the tensor maximum: one rounding on store), the parameter gradients and running statistics -- fp32 outputs of fp32 sums -- to
+    1e-5 (training mode; the ReLU mask is taken from the bf16-rounded stored y when a residual was added, like the fp32 path does from
+    its y); also the fused stem chain bn -> relu -> maxpool(3,2,1)."""
+    N, C, H, W = 6, 64, 28, 28
+    bf = torch.bfloat16
+    g = torch.Generator(device="cpu").manual_seed(11)
+    x = (torch.randn(N, C, H, W, generator=g) * 1.7 + 0.6).to(bf)
+    res = torch.randn(N, C, H, W, generator=g).to(bf) if with_res else None
+    cot = torch.randn(N, C, H, W, generator=g).to(bf)
+    bn = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=g) * 0.3)
+    ref_bn = torch.nn.BatchNorm2d(C).double()
+    ref_bn.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in bn.state_dict().items()})
+    bn = bn.cuda().train()
+    xr = x.double().requires_grad_(True)
+    rr = None if res is None else res.double().requires_grad_(True)
+    yr = ref_bn(xr)
+    if rr is not None:
+        yr = yr + rr
+    if relu:
+        yr = yr.relu()
+    (yr * cot.double()).sum().backward()
+    xg = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    rg = None if res is None else res.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = ops.bn_act(bn, xg, residual=rg, relu=relu)
+    assert y.dtype == bf and y.is_contiguous(memory_format=torch.channels_last)
+    (y.float() * cot.cuda().float()).sum().backward()
+    assert xg.grad.dtype == bf
+    errs = dict(y=rel(y.float(), yr), dx=rel(xg.grad.float(), xr.grad), dgamma=rel(bn.weight.grad, ref_bn.weight.grad),
+                dbeta=rel(bn.bias.grad, ref_bn.bias.grad), rmean=rel(bn.running_mean, ref_bn.running_mean),
+                rvar=rel(bn.running_var, ref_bn.running_var))
+    if rg is not None:
+        errs["dres"] = rel(rg.grad.float(), rr.grad)
+    report("bn_act_bf16[res=%d|relu=%d]" % (with_res, relu), **errs)
+    assert max(errs["y"], errs["dx"], errs.get("dres", 0.0)) < 2.0 ** -8
+    # dgamma / dbeta sum the MASKED cotangent: a y within bf16 rounding of 0 may take the other side of the ReLU than the fp64 value
+    assert max(errs["dgamma"], errs["dbeta"]) < (2e-3 if relu else 1e-5) and max(errs["rmean"], errs["rvar"]) < 1e-5
+    if with_res or not relu:
+        return
+    # fused stem chain in bf16 storage == the separate bf16 kernels, bit for bit (forward) / to summation order (backward)
+    pool = torch.nn.MaxPool2d(3, 2, 1)
+    bn2 = torch.nn.BatchNorm2d(C).cuda().train()
+    bn2.load_state_dict(ref_bn.state_dict())
+    bn3 = torch.nn.BatchNorm2d(C).cuda().train()
+    bn3.load_state_dict(ref_bn.state_dict())
+    x1 = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    x2 = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    keep = ops.FUSE_STEM_POOL
+    try:
+        ops.FUSE_STEM_POOL = True
+        ya = ops.bn_relu_maxpool(bn2, pool, x1)
+        ops.FUSE_STEM_POOL = False
+        yb = ops.bn_relu_maxpool(bn3, pool, x2)
+    finally:
+        ops.FUSE_STEM_POOL = keep
+    assert ya.dtype == bf and torch.equal(ya, yb)
+    c2 = torch.randn(ya.shape, generator=g).to(bf).cuda()
+    (ya.float() * c2.float()).sum().backward()
+    (yb.float() * c2.float()).sum().backward()
+    assert rel(x1.grad.float(), x2.grad.float()) < 2.0 ** -7 and rel(bn2.weight.grad, bn3.weight.grad) < 1e-4
+
+
 def test_fused_geodesic_loss_matches_se3_autograd(ops):
     """csrc/se3loss.hip against the PyTorch SE(3) formulation (rel_pose_amd/se3.py) in fp64, value and gradient, including an
     exact-identity relative pose (zero rotation / translation branches) and a rotation beyond 90 degrees (w < 0 branch)."""

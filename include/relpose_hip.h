@@ -91,7 +91,7 @@ typedef struct RpGemm {
    * ln_part [ceil(M/64)][np*192] (np = 3 with a residual, else 2) receives per-64-row-tile column sums of
    * P * xhat (-> d gamma), P (-> d beta) and residual (-> the bias gradient of the Linear that produced that branch); one
    * rp_colsum over it finishes them.  Requirements: N == 192 == ldc, ln_x / residual contiguous [M,192], no bias / act / aux,
-   * split_k = batch = 1, precision 0.  Replaces reference autograd of vision_transformer.py:352-353 (LayerNorm backward). */
+   * split_k = batch = 1 (any operand precision: the epilogue arithmetic is fp32).  Replaces reference autograd of vision_transformer.py:352-353 (LayerNorm backward). */
   const float* ln_x;
   const float* ln_mean;
   const float* ln_rstd;

@@ -443,7 +443,7 @@ extern "C" int rp_gemm(const RpGemm* g, void* stream) {
   if (lnbwd) {
     if (!g->ln_mean || !g->ln_rstd || !g->ln_gamma || !g->ln_part) return RP_EBADSHAPE;
     if (g->N != 192 || g->ldc != 192 || split > 1 || batch > 1 || g->bias || g->pre_out || g->act || g->dact || g->aux ||
-        g->colsum_part || g->trans_c || g->precision != 0 || (g->a_layout == 1 && g->b_layout == 1))
+        g->colsum_part || g->trans_c || (g->a_layout == 1 && g->b_layout == 1))
       return RP_EUNSUPPORTED;
     p.epi_mode = EPI_LNBWD;
   }

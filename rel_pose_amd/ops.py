@@ -532,7 +532,7 @@ FUSE_LN_BWD = os.environ.get("RP_FUSE_LN_BWD", "1") == "1"
 def linear_dx_lnbwd(dy, W, x, gamma, mean, rstd, add=None):
     """The pair  dxn = dy W ; (dx, dgamma, dbeta[, colsum(add)]) = layernorm_bwd(dxn, x, gamma, mean, rstd, add)  as ONE
     GEMM: dxn (the gradient of the LayerNorm output, [M,192]) never goes to memory.  dy [M,N], W [N,192]."""
-    if not FUSE_LN_BWD or GEMM_PRECISION != 0 or W.shape[1] != DIM:
+    if not FUSE_LN_BWD or W.shape[1] != DIM:
         return layernorm_bwd(linear_dx(dy, W), x, gamma, mean, rstd, add=add)
     M, N = dy.shape
     np_ = 3 if add is not None else 2

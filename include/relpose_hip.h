@@ -36,7 +36,7 @@ extern "C" {
  * functions this header declares.  rp_abi_version() / rp_abi_export_count() return the values the library was COMPILED with, so a
  * binding (rel_pose_amd/_lib.py parses both macros and counts the declarations) rejects a stale .so at load time instead of
  * failing later on a missing symbol. */
-#define RP_ABI_VERSION 8
+#define RP_ABI_VERSION 9
 #define RP_ABI_EXPORTS 65
 int rp_abi_version(void);
 int rp_abi_export_count(void);
@@ -101,6 +101,10 @@ typedef struct RpGemm {
    * reduce): bench.py's per-launch timing of one kernel instance.  NULL: nothing recorded. */
   void* ev_start;
   void* ev_stop;
+  int io_bf16; /* precision 1 only (the bf16 configuration): bf16 STORAGE of activation-sized tensors, a bit mask -- 1: A holds bf16
+                * (lda in elements), 2: C and pre_out are written as bf16, 4: aux holds bf16.  The MFMA operands are bf16 in this
+                * precision anyway; reading / writing them as bf16 halves the bytes of these HBM-bound launches.  Bit 2 needs the plain /
+                * bias / GELU / GELU' epilogues without split-K, residual or ln_*; B, bias, residual stay fp32. */
   int defer_reduce; /* split_k > 1 with no epilogue operands only: launch the main kernel and leave the partial slabs in `workspace`
                      * (which the caller then keeps alive and private to this call); the caller finishes C later with ONE
                      * rp_splitk_reduce_multi over several such calls -- the four weight-gradient GEMMs of a transformer block end in

@@ -41,7 +41,7 @@ class RpGemm(Structure):
                 ("aux", c_void_p), ("residual", c_void_p), ("trans_c", c_int), ("precision", c_int),
                 ("colsum_part", c_void_p),
                 ("ln_x", c_void_p), ("ln_mean", c_void_p), ("ln_rstd", c_void_p), ("ln_gamma", c_void_p), ("ln_part", c_void_p),
-                ("ev_start", c_void_p), ("ev_stop", c_void_p), ("defer_reduce", c_int)]
+                ("ev_start", c_void_p), ("ev_stop", c_void_p), ("io_bf16", c_int), ("defer_reduce", c_int)]
 
 
 class RpColsumTask(Structure):

@@ -171,14 +171,16 @@ __global__ __launch_bounds__(256, NL > 0 ? 2 : 1) void gemm_kernel(GemmP p) {
 
   float4 ra[NA], rb[NB];
   const bool mn_inside = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+  const bool a_bf = NL == 1 && (p.io_bf16 & 1);           // A is bf16 in memory (the bf16 configuration's activations)
+  auto lda4 = [&](long long off) { return NL == 1 ? ld4_io(A, off, a_bf) : ld4(A + off); };
   auto gload = [&](int kt) {
     const int k0 = kbeg + kt * BK;
     if (mn_inside && k0 + BK <= kend) {      // wave-uniform fast path: no per-lane guards
 #pragma unroll
       for (int j = 0; j < NA; ++j) {
         const int f = tid + 256 * j;
-        if (ALAY == 0) ra[j] = ld4(A + (long long)(m0 + (f >> 3)) * p.lda + k0 + (f & 7) * 4);
-        else ra[j] = ld4(A + (long long)(k0 + mnk<BM, NL>(tid, j)) * p.lda + m0 + mnc<BM, NL>(tid, j));
+        if (ALAY == 0) ra[j] = lda4((long long)(m0 + (f >> 3)) * p.lda + k0 + (f & 7) * 4);
+        else ra[j] = lda4((long long)(k0 + mnk<BM, NL>(tid, j)) * p.lda + m0 + mnc<BM, NL>(tid, j));
       }
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
@@ -194,10 +196,10 @@ __global__ __launch_bounds__(256, NL > 0 ? 2 : 1) void gemm_kernel(GemmP p) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (ALAY == 0) {
         const int gm = m0 + (f >> 3), gk = k0 + (f & 7) * 4;
-        if (gm < p.M && gk < kend) v = ld4(A + (long long)gm * p.lda + gk);
+        if (gm < p.M && gk < kend) v = lda4((long long)gm * p.lda + gk);
       } else {
         const int gk = k0 + mnk<BM, NL>(tid, j), gm = m0 + mnc<BM, NL>(tid, j);
-        if (gk < kend && gm < p.M) v = ld4(A + (long long)gk * p.lda + gm);
+        if (gk < kend && gm < p.M) v = lda4((long long)gk * p.lda + gm);
       }
       ra[j] = v;
     }
@@ -324,7 +326,7 @@ __global__ __launch_bounds__(256, NL > 0 ? 2 : 1) void gemm_kernel(GemmP p) {
     }
   }
 
-  tile_epilogue<TM, TN, STAGED>(p, acc, lds, m0, n0, mt, zb, zid);
+  tile_epilogue<TM, TN, STAGED, NL == 1>(p, acc, lds, m0, n0, mt, zb, zid);
 }
 
 // Fixed-order reduction of the split-K slabs [split][M][N] + epilogue (+ optional transposed store).  A weight gradient is
@@ -439,6 +441,14 @@ extern "C" int rp_gemm(const RpGemm* g, void* stream) {
   p.limbs = g->precision;
   p.colsum_part = g->colsum_part;
   p.ln_x = g->ln_x; p.ln_mean = g->ln_mean; p.ln_rstd = g->ln_rstd; p.ln_gamma = g->ln_gamma; p.ln_part = g->ln_part;
+  p.io_bf16 = g->io_bf16;
+  if (p.io_bf16) {
+    // bf16 storage: only with bf16 operand precision, single batch, 4-element-aligned everything; C / pre_out in bf16 need the
+    // LDS-staged epilogue of a plain, bias, GELU or GELU' mode (not the LayerNorm-backward or transposed-slab forms)
+    if (g->precision != 1 || batch > 1 || (p.io_bf16 & ~7)) return RP_EUNSUPPORTED;
+    if ((p.io_bf16 & 2) && (split > 1 || g->ln_x || g->residual || (g->N & 3) || (g->a_layout == 1 && g->b_layout == 1))) return RP_EUNSUPPORTED;
+    if ((p.io_bf16 & 4) && !g->aux) return RP_EBADSHAPE;
+  }
   const bool lnbwd = g->ln_x != nullptr;
   if (lnbwd) {
     if (!g->ln_mean || !g->ln_rstd || !g->ln_gamma || !g->ln_part) return RP_EBADSHAPE;

@@ -30,7 +30,26 @@ struct GemmP {
   // backward and stores the gradient of its INPUT (+ residual) -- see lnbwd_epilogue
   const float* ln_x; const float* ln_mean; const float* ln_rstd; const float* ln_gamma;
   float* ln_part;
+  // bf16 STORAGE of activation-sized operands (precision 1 = the bf16 configuration only; RpGemm.io_bf16): bit 0 = A holds bf16
+  // (2 bytes per element, lda in elements), bit 1 = C and pre_out are written as bf16 (round to nearest even), bit 2 = aux holds bf16.
+  // The operands are rounded to bf16 for the MFMA in this precision anyway, so reading them as bf16 changes no arithmetic when the
+  // producer stored bf16 -- it halves the bytes of the HBM-bound Linear launches.
+  int io_bf16;
 };
+
+RP_DEV float4 widen_bf16x4(uint2 w) {
+  return make_float4(__builtin_bit_cast(float, w.x << 16), __builtin_bit_cast(float, w.x & 0xffff0000u),
+                     __builtin_bit_cast(float, w.y << 16), __builtin_bit_cast(float, w.y & 0xffff0000u));
+}
+// 4 consecutive elements at element offset `off` of a tensor that is fp32 or (bf = true) bf16 in memory
+RP_DEV float4 ld4_io(const float* base, long long off, bool bf) {
+  if (bf) return widen_bf16x4(*reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + off));
+  return ld4(base + off);
+}
+RP_DEV void st4_io(float* base, long long off, float4 v, bool bf) {
+  if (bf) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base) + off) = make_uint2(pk_bf16(v.x, v.y), pk_bf16(v.z, v.w));
+  else st4(base + off, v);
+}
 
 RP_DEV float epilogue(float v, int m, int n, const GemmP& p) {
   if (p.bias) v += p.bias[n];
@@ -53,9 +72,10 @@ RP_DEV float epilogue(float v, int m, int n, const GemmP& p) {
 // tested the mode per element group and waited vmcnt(0) after each operand load, i.e. also for the previous store: one
 // store -> load -> store round trip per row group, 8-12 per tile.)  Out-of-range rows / columns load from clamped addresses
 // and are masked at the store only, so edge tiles run the same code.
-template <int TM, int TN, int MODE>
+template <int TM, int TN, int MODE, bool BFIO = false>
 RP_DEV void staged_epilogue(const GemmP& p, f32x16 (&acc)[TM][TN], float* lds, int m0, int n0, int mt, float* C, int ldc,
                             const float* bias, float* pre_out, const float* aux, const float* res, bool partial) {
+  const bool c_bf = BFIO && !partial && (p.io_bf16 & 2), aux_bf = BFIO && (p.io_bf16 & 4);
   constexpr int CST = 32 * TN + 4;
   constexpr int C4 = 8 * TN;             // float4 per staged row
   constexpr int NIT = (32 * TM * C4) / 64;
@@ -75,7 +95,7 @@ RP_DEV void staged_epilogue(const GemmP& p, f32x16 (&acc)[TM][TN], float* lds, i
     const int row = idx / C4, c4 = idx % C4;
     const int mc = min(m0 + wm0 + row, p.M - 1), nc = min(n0 + wn0 + 4 * c4, p.N - 4);
     if (HAS_BIAS && (it == 0 || !LANE_COL)) b4[LANE_COL ? 0 : it] = ld4(bias + nc);
-    if (HAS_RES || HAS_AUX) o4[it] = ld4(mn + (long long)mc * ldc + nc);
+    if (HAS_RES || HAS_AUX) o4[it] = ld4_io(mn, (long long)mc * ldc + nc, HAS_AUX && aux_bf);
   }
   float* cs = lds + wave * (32 * TM * CST);
 #pragma unroll
@@ -99,7 +119,7 @@ RP_DEV void staged_epilogue(const GemmP& p, f32x16 (&acc)[TM][TN], float* lds, i
       const float4 b = b4[LANE_COL ? 0 : it];
       v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
     }
-    if (MODE == EPI_BIAS_GELU_PRE && ok) st4(pre_out + off, v);
+    if (MODE == EPI_BIAS_GELU_PRE && ok) st4_io(pre_out, off, v, c_bf);
     if (MODE == EPI_BIAS_GELU || MODE == EPI_BIAS_GELU_PRE) {
       v.x = gelu_exact(v.x); v.y = gelu_exact(v.y); v.z = gelu_exact(v.z); v.w = gelu_exact(v.w);
     } else if (MODE == EPI_BIAS_RELU) {
@@ -116,7 +136,7 @@ RP_DEV void staged_epilogue(const GemmP& p, f32x16 (&acc)[TM][TN], float* lds, i
       v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
     }
     if (ok) {
-      st4(C + off, v);
+      st4_io(C, off, v, c_bf);
       if (want_cs) { csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w; }
     }
   }
@@ -238,7 +258,7 @@ RP_DEV void lnbwd_epilogue(const GemmP& p, f32x16 (&acc)[1][3], float* lds, int 
 // Tile epilogue.  acc: the wave's (32 TM) x (32 TN) accumulators (lane = column, register = row); lds: the workgroup's LDS
 // (>= 4 * 32 * TM * (32 TN + 4) floats when STAGED), free to overwrite; (m0, n0) tile origin, (mt) row-panel index,
 // zb / zid batch / split indices as in the kernels.
-template <int TM, int TN, bool STAGED>
+template <int TM, int TN, bool STAGED, bool BFIO = false>
 RP_DEV void tile_epilogue(const GemmP& p, f32x16 (&acc)[TM][TN], float* lds, int m0, int n0, int mt, int zb, int zid) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   constexpr int CST = 32 * TN + 4;
@@ -264,15 +284,15 @@ RP_DEV void tile_epilogue(const GemmP& p, f32x16 (&acc)[TM][TN], float* lds, int
   if (STAGED && (p.N & 3) == 0 && mode != EPI_GENERIC) {
     // LDS-staged epilogue, one straight-line instance per mode (wave-uniform switch outside every loop): see staged_epilogue
     switch (mode) {
-      case EPI_RAW: staged_epilogue<TM, TN, EPI_RAW>(p, acc, lds, m0, n0, mt, C, ldc, bias, pre_out, aux, res, partial); break;
-      case EPI_BIAS: staged_epilogue<TM, TN, EPI_BIAS>(p, acc, lds, m0, n0, mt, C, ldc, bias, pre_out, aux, res, partial); break;
-      case EPI_BIAS_RES: staged_epilogue<TM, TN, EPI_BIAS_RES>(p, acc, lds, m0, n0, mt, C, ldc, bias, pre_out, aux, res, partial); break;
-      case EPI_RES: staged_epilogue<TM, TN, EPI_RES>(p, acc, lds, m0, n0, mt, C, ldc, bias, pre_out, aux, res, partial); break;
-      case EPI_BIAS_GELU: staged_epilogue<TM, TN, EPI_BIAS_GELU>(p, acc, lds, m0, n0, mt, C, ldc, bias, pre_out, aux, res, partial); break;
-      case EPI_BIAS_GELU_PRE: staged_epilogue<TM, TN, EPI_BIAS_GELU_PRE>(p, acc, lds, m0, n0, mt, C, ldc, bias, pre_out, aux, res, partial); break;
-      case EPI_BIAS_RELU: staged_epilogue<TM, TN, EPI_BIAS_RELU>(p, acc, lds, m0, n0, mt, C, ldc, bias, pre_out, aux, res, partial); break;
-      case EPI_DGELU: staged_epilogue<TM, TN, EPI_DGELU>(p, acc, lds, m0, n0, mt, C, ldc, bias, pre_out, aux, res, partial); break;
-      default: staged_epilogue<TM, TN, EPI_DRELU>(p, acc, lds, m0, n0, mt, C, ldc, bias, pre_out, aux, res, partial); break;
+      case EPI_RAW: staged_epilogue<TM, TN, EPI_RAW, BFIO>(p, acc, lds, m0, n0, mt, C, ldc, bias, pre_out, aux, res, partial); break;
+      case EPI_BIAS: staged_epilogue<TM, TN, EPI_BIAS, BFIO>(p, acc, lds, m0, n0, mt, C, ldc, bias, pre_out, aux, res, partial); break;
+      case EPI_BIAS_RES: staged_epilogue<TM, TN, EPI_BIAS_RES, BFIO>(p, acc, lds, m0, n0, mt, C, ldc, bias, pre_out, aux, res, partial); break;
+      case EPI_RES: staged_epilogue<TM, TN, EPI_RES, BFIO>(p, acc, lds, m0, n0, mt, C, ldc, bias, pre_out, aux, res, partial); break;
+      case EPI_BIAS_GELU: staged_epilogue<TM, TN, EPI_BIAS_GELU, BFIO>(p, acc, lds, m0, n0, mt, C, ldc, bias, pre_out, aux, res, partial); break;
+      case EPI_BIAS_GELU_PRE: staged_epilogue<TM, TN, EPI_BIAS_GELU_PRE, BFIO>(p, acc, lds, m0, n0, mt, C, ldc, bias, pre_out, aux, res, partial); break;
+      case EPI_BIAS_RELU: staged_epilogue<TM, TN, EPI_BIAS_RELU, BFIO>(p, acc, lds, m0, n0, mt, C, ldc, bias, pre_out, aux, res, partial); break;
+      case EPI_DGELU: staged_epilogue<TM, TN, EPI_DGELU, BFIO>(p, acc, lds, m0, n0, mt, C, ldc, bias, pre_out, aux, res, partial); break;
+      default: staged_epilogue<TM, TN, EPI_DRELU, BFIO>(p, acc, lds, m0, n0, mt, C, ldc, bias, pre_out, aux, res, partial); break;
     }
   } else {
 #define RP_EPI_LOOP(BODY)                                                              \

@@ -81,6 +81,17 @@ def set_gemm_precision(p):
     GEMM_PRECISION = p
 
 
+# bf16 STORAGE of the MLP's hidden tensors in the bf16 configuration (operand precision 1): h = GELU(fc1), its pre-activation and the
+# gradient of the pre-activation are [tokens, 768] -- four times the model width and 60 % of a Block's HBM traffic; the Linear kernels are
+# HBM-bound there (profiles/r2_bf16_128pairs_full_step_summary.txt), and their MFMA operands are rounded to bf16 anyway.  fc1 writes them as
+# bf16, fc2 / the weight-gradient / input-gradient GEMMs read bf16 (RpGemm.io_bf16).  Never in the fp32 configurations.
+ACT_BF16 = os.environ.get("RP_ACT_BF16", "1") == "1"
+
+
+def _act_bf16():
+    return ACT_BF16 and GEMM_PRECISION == 1
+
+
 # operand precision of the attention / EMM contractions (rp_attn_*, rp_emm_*: the `bf16` argument): 0 exact fp32 MFMA (default,
 # the parity path), 1 bf16 operands on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- BASELINE.json configs[4]
 ATTN_BF16 = 1 if os.environ.get("RP_ATTN_BF16", "0") == "1" else 0
@@ -319,17 +330,35 @@ def gemm_instance(M, N, a_layout, b_layout, reads_mn=False):
 
 def gemm(A, B, M, N, K, *, a_layout=0, b_layout=0, lda=None, ldb=None, out=None, ldc=None, bias=None, act=0,
          pre_out=None, dact=0, aux=None, residual=None, split_k=None, batch=1, strides=(0, 0, 0), trans_c=False,
-         precision=None, want_colsum=False, ln=None):
+         precision=None, want_colsum=False, ln=None, out_dtype=None):
     """C[M,N] = epilogue(op(A) op(B)); see RpGemm in include/relpose_hip.h.
-    ln = (x, mean, rstd, gamma, part): LayerNorm backward fused into the epilogue (RpGemm.ln_*)."""
+    ln = (x, mean, rstd, gamma, part): LayerNorm backward fused into the epilogue (RpGemm.ln_*).
+    bf16 storage (RpGemm.io_bf16, operand precision 1 only): A and aux may be bf16 tensors; out_dtype=torch.bfloat16 makes C (and
+    pre_out) bf16."""
     lib = _lib.load()
-    _chk(A, B, out, bias, pre_out, aux, residual)
+    _chk(B, bias, residual)
+    io = 0
+    bfd = torch.bfloat16
+    if A.dtype == bfd:
+        io |= 1
+    if (out_dtype == bfd) or (out is not None and out.dtype == bfd):
+        io |= 2
+    if aux is not None and aux.dtype == bfd:
+        io |= 4
+    for t, bit in ((A, 1), (out, 2), (pre_out, 2), (aux, 4)):
+        if t is None:
+            continue
+        want = bfd if io & bit else torch.float32
+        if not (t.is_cuda and t.is_contiguous() and t.dtype == want):
+            raise RuntimeError("rp_gemm operand: expected a contiguous %s GPU tensor, got %s %s" % (want, t.device, t.dtype))
+    if io and (GEMM_PRECISION if precision is None else precision) != 1:
+        raise RuntimeError("bf16-stored GEMM operands need operand precision 1 (the bf16 configuration)")
     if lda is None:
         lda = K if a_layout == 0 else M
     if ldb is None:
         ldb = K if b_layout == 0 else N
     if out is None:
-        out = _empty(*((batch, M, N) if batch > 1 else (M, N)), like=A)
+        out = torch.empty((batch, M, N) if batch > 1 else (M, N), device=A.device, dtype=bfd if io & 2 else torch.float32)
     if ldc is None:
         ldc = N
     if split_k is None:
@@ -361,6 +390,7 @@ def gemm(A, B, M, N, K, *, a_layout=0, b_layout=0, lda=None, ldb=None, out=None,
     g.residual = None if residual is None else residual.data_ptr()
     g.trans_c = 1 if trans_c else 0
     g.precision = GEMM_PRECISION if precision is None else precision
+    g.io_bf16 = io
     if ln is not None:
         _chk(*ln)
         g.ln_x, g.ln_mean, g.ln_rstd, g.ln_gamma, g.ln_part = (t.data_ptr() for t in ln)
@@ -491,38 +521,40 @@ def linear_rows(x, W, b=None, act=0, want_pre=False, residual=None, ln=None, wan
     return out[0] if len(out) == 1 else out
 
 
-def ln_linear(x, gamma, beta, W, b, act=0, want_pre=False, train=True):
+def ln_linear(x, gamma, beta, W, b, act=0, want_pre=False, train=True, out_dtype=None):
     """(y [, pre], xn, mean, rstd) of  act(LayerNorm(x) W^T + b): one kernel when the row-resident path applies (xn / stats are
     None at inference), LayerNorm kernel + GEMM otherwise."""
-    if _rows_ok(x, W):
+    if _rows_ok(x, W) and out_dtype is None:
         r = linear_rows(x, W, b, act=act, want_pre=want_pre, ln=(gamma, beta), want_ln_out=train)
         r = r if isinstance(r, tuple) else (r,)
         return r if train else r + (None, None, None)
     xn, m, rs = layernorm_fwd(x, gamma, beta)
-    r = linear(xn, W, b, act=act, want_pre=want_pre)
+    r = linear(xn, W, b, act=act, want_pre=want_pre, out_dtype=out_dtype)
     return (r if isinstance(r, tuple) else (r,)) + (xn, m, rs)
 
 
-def linear(x, W, b=None, act=0, want_pre=False, residual=None):
-    """y = act(x W^T + b) (+ residual); x [M,K], W [N,K]."""
-    if _rows_ok(x, W) and (residual is None or residual.is_contiguous()):
+def linear(x, W, b=None, act=0, want_pre=False, residual=None, out_dtype=None):
+    """y = act(x W^T + b) (+ residual); x [M,K], W [N,K].  out_dtype=torch.bfloat16: y (and the pre-activation) stored as bf16
+    (bf16 configuration only)."""
+    if _rows_ok(x, W) and (residual is None or residual.is_contiguous()) and out_dtype is None and x.dtype == torch.float32:
         return linear_rows(x, W, b, act=act, want_pre=want_pre, residual=residual)
     M, K = x.shape
     N = W.shape[0]
-    pre = _empty(M, N, like=x) if want_pre else None
-    y = gemm(x, W, M, N, K, bias=b, act=act, pre_out=pre, residual=residual)
+    pre = torch.empty(M, N, device=x.device, dtype=out_dtype or torch.float32) if want_pre else None
+    y = gemm(x, W, M, N, K, bias=b, act=act, pre_out=pre, residual=residual, out_dtype=out_dtype)
     return (y, pre) if want_pre else y
 
 
-def linear_dx(dy, W, dact=0, aux=None, want_colsum=False):
+def linear_dx(dy, W, dact=0, aux=None, want_colsum=False, out_dtype=None):
     """dx = (dy W) o act'(aux); dy [M,N], W [N,K] -> [M,K].  want_colsum: also sum_m dx[m][:] (the bias gradient of the
     layer below when dx is its pre-activation gradient), from the epilogue."""
     M, N = dy.shape
     K = W.shape[1]
-    if ROWS_DX and N == DIM and K % 32 == 0 and K <= 1024 and GEMM_PRECISION == 0 and dy.is_contiguous() and dact in (0, 1):
+    if (ROWS_DX and N == DIM and K % 32 == 0 and K <= 1024 and GEMM_PRECISION == 0 and dy.is_contiguous() and dact in (0, 1)
+            and out_dtype is None):
         # contraction over the layer's 192 outputs: the row-resident kernel on the transposed weight (a 0.1-0.6 MB copy)
         return linear_rows(dy, transposed(W), dact_aux=aux if dact else None, want_colsum=want_colsum)
-    return gemm(dy, W, M, K, N, b_layout=1, dact=dact, aux=aux, want_colsum=want_colsum)
+    return gemm(dy, W, M, K, N, b_layout=1, dact=dact, aux=aux, want_colsum=want_colsum, out_dtype=out_dtype)
 
 
 # LayerNorm backward fused into the epilogue of the input-gradient GEMM that feeds it (RpGemm.ln_*): the exact-fp32 GEMM only
@@ -548,6 +580,10 @@ def linear_dw(dy, x):
     """dW = dy^T x; dy [M,N], x [M,K] -> [N,K]  (reduction over the M token rows, split-K)."""
     M, N = dy.shape
     K = x.shape[1]
+    if x.dtype != torch.float32 and not (K > N and M >= 4096):
+        x = x.float()              # (only the A operand of rp_gemm may be bf16-stored; small launches are not worth a second form)
+    if dy.dtype != torch.float32 and K > N and M >= 4096:
+        dy = dy.float()
     if K > N and M >= 4096:
         # wide-K' weight (fc2: [192,768]): contract as (x^T dy) so the long extent is the row-panel dimension, and let
         # the split-K reduce write the transpose
@@ -959,10 +995,11 @@ def _mlp_block_fwd(x1, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b, train):
     if (not train and FUSE_MLP and GEMM_PRECISION == 0 and x1.shape[1] == DIM and tuple(fc1_w.shape) == (4 * DIM, DIM)
             and tuple(fc2_w.shape) == (DIM, 4 * DIM)):
         return mlp_fused(x1, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b), None, None, None, None, None
+    hd = torch.bfloat16 if _act_bf16() else None          # bf16 configuration: the [tokens, 768] hidden tensors live in bf16
     if train:
-        h, hpre, xn2, m2, r2 = ln_linear(x1, n2w, n2b, fc1_w, fc1_b, act=1, want_pre=True, train=True)
+        h, hpre, xn2, m2, r2 = ln_linear(x1, n2w, n2b, fc1_w, fc1_b, act=1, want_pre=True, train=True, out_dtype=hd)
     else:
-        h, xn2, m2, r2 = ln_linear(x1, n2w, n2b, fc1_w, fc1_b, act=1, train=False)
+        h, xn2, m2, r2 = ln_linear(x1, n2w, n2b, fc1_w, fc1_b, act=1, train=False, out_dtype=hd)
         hpre = None
     y = linear(h, fc2_w, fc2_b, residual=x1)
     return y, xn2, m2, r2, h, hpre
@@ -1006,7 +1043,7 @@ def _mlp_bwd(fork, dy, xn, h, hpre, w1, w2, want_db2=True, ln=None):
             return layernorm_bwd(dxn, x_, gamma_, mean_, rstd_, add=add_), dw1, db1, dw2, db2
         return dxn, dw1, db1, dw2, db2
     # grad wrt fc1 pre-activation (GELU' fused) and, from the same epilogue, its column sums = the fc1 bias gradient
-    dh, db1 = linear_dx(dy, w2, dact=1, aux=hpre, want_colsum=True)
+    dh, db1 = linear_dx(dy, w2, dact=1, aux=hpre, want_colsum=True, out_dtype=torch.bfloat16 if hpre.dtype == torch.bfloat16 else None)
     fork.sync_side()
     dw1 = fork.on_side(lambda: linear_dw(dh, xn))
     if ln is not None:      # (x, gamma, mean, rstd, add): LayerNorm backward fused into the fc1 input-gradient GEMM

@@ -163,6 +163,40 @@ def test_gemm_epilogue_column_sums(ops, prec):
         ops.gemm(dy, Wt, M, 192, K, b_layout=0, a_layout=0, want_colsum=True, split_k=2)
 
 
+def test_gemm_bf16_storage_of_activation_operands(ops):
+    """RpGemm.io_bf16 (bf16 configuration, operand precision 1): A / aux read as bf16, C / pre_out written as bf16.  The MFMA operands
+    are bf16 in this precision anyway, so with bf16-representable inputs the bf16-stored launch must equal the fp32-stored one BIT FOR
+    BIT, and a bf16 output must be the round-to-nearest-even of the fp32 output -- for the K-contiguous and the MN-contiguous A layout,
+    the GELU + pre-activation and the GELU' epilogues, and ragged M."""
+    bf = torch.bfloat16
+    M, K, N = 1000, 192, 768
+    x, W, b = rnd(M, K, seed=1).to(bf), rnd(N, K, seed=2) * 0.07, rnd(N, seed=3) * 0.1
+    # fc1-like: GELU + pre-activation, outputs in bf16
+    pre32 = torch.empty(M, N, device="cuda")
+    y32 = ops.gemm(x.float(), W, M, N, K, bias=b, act=1, pre_out=pre32, precision=1)
+    pre16 = torch.empty(M, N, device="cuda", dtype=bf)
+    y16 = ops.gemm(x, W, M, N, K, bias=b, act=1, pre_out=pre16, precision=1, out_dtype=bf)
+    assert y16.dtype == bf and torch.equal(y16, y32.to(bf)) and torch.equal(pre16, pre32.to(bf))
+    # fc2-like: A = h (bf16, K-contiguous), fp32 output + residual
+    W2, res = rnd(K, N, seed=4) * 0.05, rnd(M, K, seed=5)
+    a = ops.gemm(y16, W2, M, K, N, residual=res, precision=1)
+    b_ = ops.gemm(y16.float(), W2, M, K, N, residual=res, precision=1)
+    assert a.dtype == torch.float32 and torch.equal(a, b_)
+    # input gradient with GELU'(aux): aux bf16, output bf16
+    dy = rnd(M, K, seed=6)
+    d32 = ops.gemm(dy, W2, M, N, K, b_layout=1, dact=1, aux=pre16.float(), precision=1)
+    d16 = ops.gemm(dy, W2, M, N, K, b_layout=1, dact=1, aux=pre16, precision=1, out_dtype=bf)
+    assert torch.equal(d16, d32.to(bf))
+    # weight gradient: A = dh (bf16, MN-contiguous), split-K
+    xn = rnd(M, K, seed=7)
+    w32 = ops.gemm(d16.float(), xn, N, K, M, a_layout=1, b_layout=1, precision=1, split_k=4)
+    w16 = ops.gemm(d16, xn, N, K, M, a_layout=1, b_layout=1, precision=1, split_k=4)
+    assert torch.equal(w16, w32)
+    assert rel(w16, d16.double().t() @ xn.double()) < 2e-2
+    with pytest.raises(RuntimeError):
+        ops.gemm(x, W, M, N, K, precision=0)          # bf16-stored operands only exist in the bf16 configuration
+
+
 def test_gemm_errors_are_loud(ops):
     A = rnd(64, 30)
     with pytest.raises(RuntimeError):

@@ -45,4 +45,4 @@ if len(sys.argv) == 1:
 else:
     ta = timeit(lambda: ops.attn_bwd(qkv, o, lse, do, Z), n=30)
     te = timeit(lambda: ops.emm_backward(qkv, X, tt, rlse, clse, df, Z), n=20)
-    print("RP_DSMM=%s REV=%s: attn_bwd %8.1f us   emm_backward %8.1f us" % (os.environ["RP_DSMM"], os.environ["RP_DSMM_REV"], ta, te))
+    print("RP_DSMM=%s REV=%s: attn_bwd %8.1f us   emm_backward %8.1f us" % (os.environ.get("RP_DSMM"), os.environ.get("RP_DSMM_REV"), ta, te))

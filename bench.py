@@ -327,6 +327,8 @@ def main():
     ops.TIMER = timer
     eager_step = step
     eager_step()          # untimed priming step, even with --warmup 0: lazy init and MIOpen's solver search never fall in the timed steps
+    if rank == 0 and not hot:
+        rel_pose_amd._env.check_db()          # warns when the shipped MIOpen solver db does not belong to the loaded MIOpen
     if graphed:
         from rel_pose_amd.graph import GraphedTrainStep
         fwd = (lambda im, G, it: net(im, G, intrinsics=it))

@@ -33,4 +33,44 @@ def setup():
         pass            # read-only temp dir: MIOpen falls back to its defaults
 
 
+_WARNED = False
+
+
+def check_db(warn=True):
+    """Does the shipped solver db belong to the MIOpen that is actually loaded?  The db file names carry MIOpen's version string
+    (gfx950100.HIP.<major>_<minor>_<patch>_<build>.ufdb.txt); another MIOpen build looks for other names, finds nothing and silently
+    falls back to its heuristic solvers (the 43.0 vs 41.3 ms gap of round 1).  Call after the first convolution has run.  Checks
+    (a) the major_minor_patch of the shipped names against torch.backends.cudnn.version() (MIOpen's own number under ROCm) and
+    (b) whether MIOpen has started db files under OTHER names in the user-db directory.  Returns a list of findings (empty = ok)
+    and prints one warning per process."""
+    global _WARNED
+    import re
+    findings = []
+    if not os.path.isdir(MIOPEN_DB):
+        return findings
+    shipped = [f for f in os.listdir(MIOPEN_DB) if f.endswith(".txt")]
+    vers = {m.group(1) for f in shipped for m in [re.search(r"\.HIP\.(\d+_\d+_\d+)_", f)] if m}
+    try:
+        import torch
+        v = int(torch.backends.cudnn.version() or 0)
+        have = "%d_%d_%d" % (v // 1000000, (v // 1000) % 1000, v % 1000) if v else None
+    except Exception:
+        have = None
+    if have and vers and have not in vers:
+        findings.append("shipped MIOpen solver db is for MIOpen %s, the loaded MIOpen reports %s" % (sorted(vers), have))
+    dst = os.environ.get("MIOPEN_USER_DB_PATH")
+    if dst and os.path.isdir(dst):
+        known = {re.sub(r"^batchnorm_", "", f).rsplit(".", 2)[0] for f in shipped}
+        other = sorted({f for f in os.listdir(dst) if f.endswith((".udb.txt", ".ufdb.txt"))
+                        and re.sub(r"^batchnorm_", "", f).rsplit(".", 2)[0] not in known})
+        if other:
+            findings.append("MIOpen opened db files the shipped set does not contain: %s" % other[:3])
+    if findings and warn and not _WARNED:
+        _WARNED = True
+        import warnings
+        warnings.warn("rel_pose_amd: " + "; ".join(findings) + " -- the CNN front-end's convolutions run on MIOpen's heuristic solvers "
+                      "(a few % slower); re-run tools/tune_miopen.sh on this ROCm to regenerate rel_pose_amd/miopen_db/", RuntimeWarning)
+    return findings
+
+
 setup()

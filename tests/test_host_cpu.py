@@ -403,3 +403,20 @@ def test_essential_decode_oracle_round_trip():
     Ro, to, co = SO.decode_essential(SO.essential_from_pose(pose), X1[..., :2] / X1[..., 2:], X2[..., :2] / X2[..., 2:])
     assert (co == P).all()
     assert np.abs(Ro - R).max() < 1e-9 and np.abs(to - t / np.linalg.norm(t, axis=1, keepdims=True)).max() < 1e-9
+
+
+def test_miopen_db_check_reports_a_foreign_miopen(tmp_path, monkeypatch):
+    """rel_pose_amd._env.check_db: a db file under a name the shipped set does not contain (= another MIOpen build looked for its own
+    file) is reported; the shipped names alone are not."""
+    from rel_pose_amd import _env
+    d = tmp_path / "udb"
+    d.mkdir()
+    for f in os.listdir(_env.MIOPEN_DB):
+        if f.endswith(".txt"):
+            (d / f).write_text("")
+    monkeypatch.setenv("MIOPEN_USER_DB_PATH", str(d))
+    base = [m for m in _env.check_db(warn=False) if "opened db files" in m]
+    assert base == []
+    (d / "gfx950100.HIP.9_9_9_deadbeef.ufdb.txt").write_text("")
+    found = [m for m in _env.check_db(warn=False) if "opened db files" in m]
+    assert len(found) == 1 and "9_9_9_deadbeef" in found[0]

@@ -308,8 +308,17 @@ struct AttnBwdP {
                 // dK/dV pass, so dQ = dS K is one streaming rp_ds_matmul
 };
 
+#ifdef RP_DKDV_PROBE
+__device__ unsigned long long g_probe[16];
+#define STAMP(i) { const unsigned long long now_ = __builtin_readcyclecounter(); acc_[i] += now_ - last_; last_ = now_; }
+#else
+#define STAMP(i)
+#endif
 template <int NW, int WPS, bool BF>
 __global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dkdv_kernel(AttnBwdP p) {
+#ifdef RP_DKDV_PROBE
+  unsigned long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_readcyclecounter();
+#endif
   constexpr int NT = NW * 64;
   constexpr int NPF = (512 + NT - 1) / NT;
   __shared__ __attribute__((aligned(16))) float Qs[2][32 * KST];
@@ -337,21 +346,32 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dkdv_kernel(AttnBwdP p)
   float lpre = 0.f;
   tile_gload<NT>(qb, p.ldq, tid, qpre);
   tile_gload<NT>(dob, p.lddo, tid, dpre);
-  if (tid < 64) lpre = tid < 32 ? lseb[tid] * RP_LOG2E : delb[tid - 32];
+  // lse (scaled to log2 units) and delta of the query tile: loaded by EVERY thread, branch-free (lane & 63 picks the value) -- an
+  // exec-masked `if (tid < 64)` load here became its own basic block and hipcc joined it with s_waitcnt vmcnt(0), i.e. every tile waited
+  // for its own just-issued Q / dO prefetch at the top of the loop (tools/dkdv_probe.py: 4 k cycles per tile)
+  const float* lsrc = (lane & 32) ? delb + (lane & 31) : lseb + (lane & 31);
+  const float lmul = (lane & 32) ? 1.0f : RP_LOG2E;
+  lpre = lsrc[0] * lmul;
   tile_sstore<NT, KST>(Qs[0], tid, qpre);
   tile_sstore<NT, KST>(Ds[0], tid, dpre);
   if (tid < 64) Ls[0][tid] = lpre;
   __syncthreads();
 
+  STAMP(0)
   for (int t = 0; t < NTILE; ++t) {
     const int cur = t & 1;
     if (t + 1 < NTILE) {
       tile_gload<NT>(qb + (long long)(t + 1) * 32 * p.ldq, p.ldq, tid, qpre);
       tile_gload<NT>(dob + (long long)(t + 1) * 32 * p.lddo, p.lddo, tid, dpre);
-      if (tid < 64) lpre = tid < 32 ? lseb[(t + 1) * 32 + tid] * RP_LOG2E : delb[(t + 1) * 32 + tid - 32];
+      lpre = lsrc[(t + 1) * 32] * lmul;
     }
+    STAMP(1)
     f32x16 s = score_tile<BF>(Qs[cur], l31, hi, kreg, kpk);     // rows = queries acc_row(r,hi), lane = key
     f32x16 dp = score_tile<BF>(Ds[cur], l31, hi, vreg, vpk);
+#ifdef RP_DKDV_PROBE
+    asm volatile("" : "+v"(s), "+v"(dp));
+#endif
+    STAMP(2)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int qi = acc_row(r, hi);
@@ -359,21 +379,33 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dkdv_kernel(AttnBwdP p)
       s[r] = pr;
       dp[r] = pr * (dp[r] - Ls[cur][32 + qi]);
     }
+#ifdef RP_DKDV_PROBE
+    asm volatile("" : "+v"(s), "+v"(dp));
+#endif
+    STAMP(3)
     if (p.ds) {      // TILED: tile (query block t, key block) = this wave's register image [16 r][64 lanes], 4 KB contiguous, fully
       // coalesced 256-byte stores; rp_ds_matmul (below) reads it -- the dQ pass then needs neither S nor dP again
-      float* dsb = p.ds + ((((long long)zq * p.H + h) * NTILE + t) * NTILE + (k0 >> 5)) * 1024 + lane;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dsb[r * 64] = dp[r] * p.scale;
+      store_acc_image(p.ds + ((((long long)zq * p.H + h) * NTILE + t) * NTILE + (k0 >> 5)) * 1024, dp, p.scale, lane);
     }
+    STAMP(4)
     accum_tile<KST, BF>(Ds[cur], l31, hi, s, dv0, dv1);     // dV^T += dO^T P
     accum_tile<KST, BF>(Qs[cur], l31, hi, dp, dk0, dk1);    // dK^T += Q^T dS
+#ifdef RP_DKDV_PROBE
+    asm volatile("" : "+v"(dv0), "+v"(dv1), "+v"(dk0), "+v"(dk1));
+#endif
+    STAMP(5)
     if (t + 1 < NTILE) {
       tile_sstore<NT, KST>(Qs[cur ^ 1], tid, qpre);
       tile_sstore<NT, KST>(Ds[cur ^ 1], tid, dpre);
       if (tid < 64) Ls[cur ^ 1][tid] = lpre;
     }
+    STAMP(6)
     __syncthreads();
+    STAMP(7)
   }
+#ifdef RP_DKDV_PROBE
+  if (lane == 0) { for (int i = 0; i < 8; ++i) atomicAdd(&g_probe[i], acc_[i]); atomicAdd(&g_probe[8], 1ull); }
+#endif
   store_ownerT(p.dv + ((long long)z * NTOK + k0 + l31) * p.lddv + h * 64, hi, dv0, dv1, 1.0f);
   store_ownerT(p.dk + ((long long)z * NTOK + k0 + l31) * p.lddk + h * 64, hi, dk0, dk1, p.scale);
 }
@@ -716,3 +748,12 @@ extern "C" int rp_ds_matmul(const float* ds, const float* b, float* out, int Z, 
   RP_CHECK_LAUNCH();
   return RP_OK;
 }
+
+#ifdef RP_DKDV_PROBE
+extern "C" int rp_debug_probe(unsigned long long* out, int reset) {
+  unsigned long long z[16] = {0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_probe), sizeof(z)) != hipSuccess) return 1;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_probe), z, sizeof(z)) != hipSuccess) return 2;
+  return 0;
+}
+#endif

@@ -114,6 +114,35 @@ RP_DEV float row16_sum(float v) {
   return v;
 }
 
+// 4 x 4 transpose across the four lanes of a DPP quad: before, lane q (= lane & 3) holds a[0..3]; after, it holds b[e] = (a of lane e)[q].
+// Two 2 x 2 stages (quad_perm [1,0,3,2], then [2,3,0,1]), 16 VALU operations, no LDS.  Used to turn four 4-byte-per-lane stores of an
+// accumulator image into one 16-byte-per-lane store (the stored-dS tiles): lanes 4Q..4Q+3 each end up with four CONSECUTIVE lanes' values
+// of one register.
+RP_DEV void quad_transpose4(float (&a)[4], int q) {
+  const bool o1 = q & 1, o2 = q & 2;
+  const float s01 = o1 ? a[0] : a[1], s23 = o1 ? a[2] : a[3];
+  const float r01 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s01), 0xB1, 0xF, 0xF, true));
+  const float r23 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s23), 0xB1, 0xF, 0xF, true));
+  if (o1) { a[0] = r01; a[2] = r23; } else { a[1] = r01; a[3] = r23; }
+  const float s02 = o2 ? a[0] : a[2], s13 = o2 ? a[1] : a[3];
+  const float r02 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s02), 0x4E, 0xF, 0xF, true));
+  const float r13 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s13), 0x4E, 0xF, 0xF, true));
+  if (o2) { a[0] = r02; a[1] = r13; } else { a[2] = r02; a[3] = r13; }
+}
+
+// store a wave's 32 x 32 accumulator tile (16 registers per lane) as its [16 r][64 lanes] image (4 KB at `tile`), values scaled by `mul`:
+// four 16-byte stores per lane (1 KiB per wave instruction, contiguous) instead of sixteen 4-byte ones -- the dword form spent ~2700
+// cycles per tile issuing stores in attn_bwd_dkdv and backed the load queue up behind them (tools/dkdv_probe.py)
+RP_DEV void store_acc_image(float* tile, const f32x16& v, float mul, int lane) {
+  const int q = lane & 3;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float a[4] = {v[4 * g] * mul, v[4 * g + 1] * mul, v[4 * g + 2] * mul, v[4 * g + 3] * mul};
+    quad_transpose4(a, q);
+    *reinterpret_cast<float4*>(tile + (4 * g + q) * 64 + (lane & ~3)) = make_float4(a[0], a[1], a[2], a[3]);
+  }
+}
+
 // XCD-aware work order for the (image, head) x row-block kernels: workgroup b runs on XCD b % 8 (private 4 MB L2), so
 // XCD x takes the (image, head) problems zh = x (mod 8) and runs all NQ row-block workgroups of one problem back to
 // back: the K/V (or Q/dO) tiles every one of them streams are then fetched into ONE L2 once.  Measured before: the

@@ -132,7 +132,10 @@ __global__ __launch_bounds__(NT, 3) void emm_apply_kernel(EmmP p) {
   };
   kv_gload<NT>(lb, p.ld, tid, kpre);
   x_gload(0);
-  if (tid < 32) cpre = loop_lse[tid] * RP_LOG2E;
+  // branch-free (every thread loads; lane & 31 picks the value): an exec-masked load here made hipcc wait vmcnt(0) -- for the tile
+  // prefetch just issued -- at the top of every iteration (see attn_bwd_dkdv_kernel)
+  const float* csrc = loop_lse + (tid & 31);
+  cpre = csrc[0] * RP_LOG2E;
   kv_sstore<NT>(Ks, tid, kpre);
   x_sstore(Xs);
   if (tid < 32) Cl[tid] = cpre;
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(NT, 3) void emm_apply_kernel(EmmP p) {
     if (t + 1 < NTILE) {
       kv_gload<NT>(lb + (long long)(t + 1) * 32 * p.ld, p.ld, tid, kpre);
       x_gload(t + 1);
-      if (tid < 32) cpre = loop_lse[(t + 1) * 32 + tid] * RP_LOG2E;
+      cpre = csrc[(t + 1) * 32] * RP_LOG2E;
     }
     f32x16 s = score_tile<BF>(Ks + cur * 32 * KST, l31, hi, oreg, opk);   // S^T[loop][owner]
     const float* cl = Cl + cur * 32;
@@ -302,7 +305,9 @@ __global__ __launch_bounds__(GT, 2) void emm_grad_kernel(EmmP p) {
   };
   kv_gload<GT>(lb, p.ld, tid, kpre);
   x_gload(0);
-  if (tid < 64) lpre = tid < 32 ? loop_lse[tid] * RP_LOG2E : loop_g[tid - 32];
+  const float* lsrc = (tid & 32) ? loop_g + (tid & 31) : loop_lse + (tid & 31);      // branch-free, see emm_apply_kernel
+  const float lmul = (tid & 32) ? 1.0f : RP_LOG2E;
+  lpre = lsrc[0] * lmul;
   kv_sstore<GT>(Ks[0], tid, kpre);
   x_sstore(Xs[0]);
   if (tid < 64) Ll[0][tid] = lpre;
@@ -313,7 +318,7 @@ __global__ __launch_bounds__(GT, 2) void emm_grad_kernel(EmmP p) {
     if (t + 1 < NTILE) {
       kv_gload<GT>(lb + (long long)(t + 1) * 32 * p.ld, p.ld, tid, kpre);
       x_gload(t + 1);
-      if (tid < 64) lpre = tid < 32 ? loop_lse[(t + 1) * 32 + tid] * RP_LOG2E : loop_g[(t + 1) * 32 + tid - 32];
+      lpre = lsrc[(t + 1) * 32] * lmul;
     }
     f32x16 s = score_tile<BF>(Ks[cur], l31, hi, oreg, opk);      // S^T[loop][owner]
     f32x16 da = zero16();                                // dA^T[loop][owner] = sum_c X[loop][c] W[owner][c]
@@ -352,9 +357,7 @@ __global__ __launch_bounds__(GT, 2) void emm_grad_kernel(EmmP p) {
     }
     if (p.ds) {      // (owner = query pass only) TILED: tile (loop block t, owner block) = this wave's register image [16 r][64 lanes],
       // 4 KB contiguous, rows = loop index j, columns = owners i: fully coalesced 256-byte stores; rp_ds_matmul reads it (attention.hip)
-      float* dsb = p.ds + ((zh * (NTOK / 32) + t) * (NTOK / 32) + (o0 >> 5)) * 1024 + lane;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dsb[r * 64] = s[r] * p.scale;
+      store_acc_image(p.ds + ((zh * (NTOK / 32) + t) * (NTOK / 32) + (o0 >> 5)) * 1024, s, p.scale, lane);
     }
     // d owner^T[d][owner] += sum_loop other[loop][d] dS^T[loop][owner]
     if (BF) {

@@ -17,10 +17,11 @@ def run(cmd, cwd):
 
 def test_train_steps_checkpoint_and_resume(tmp_path):
     args = [os.path.join(ROOT, "train.py"), "--name", "t0", "--batch", "4", "--steps", "6", "--warmup", "2", "--fusion_transformer",
-            "--image_size", "256", "320", "--num_workers", "0"]
+            "--image_size", "256", "320", "--num_workers", "0", "--dataset", "synthetic"]
+    # (--gpus is left at the reference's default of 4: train.py clamps it to the one visible GPU and says so)
     r = run(args, str(tmp_path))
     assert r.returncode == 0, r.stderr[-2000:]
-    assert "finished training!" in r.stdout
+    assert "finished training!" in r.stdout and "GPU(s) visible" in r.stdout
     ck = tmp_path / "output" / "t0" / "checkpoints" / "000006.pth"
     assert ck.exists()
     import torch

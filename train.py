@@ -217,7 +217,7 @@ def parser():
     ap.add_argument("--no_device_augment", dest="device_augment", action="store_false",
                     help="the reference's per-sample CPU augmentation inside the DataLoader workers")
     ap.add_argument("--no_ddp", action="store_true", default=False)
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=4)              # reference train.py:229 (clamped to the visible GPUs, with a note)
     ap.add_argument("--ckpt", help="checkpoint to restore")
     ap.add_argument("--name", default="bla")
     ap.add_argument("--datapath")
@@ -225,7 +225,8 @@ def parser():
     ap.add_argument("--exp")
     ap.add_argument("--use_mini_dataset", action="store_true")
     ap.add_argument("--streetlearn_interiornet_type", default="", choices=("", "T"))
-    ap.add_argument("--dataset", default="synthetic", choices=("synthetic", "matterport", "interiornet", "streetlearn"))
+    ap.add_argument("--dataset", default="matterport", choices=("matterport", "interiornet", "streetlearn", "synthetic"))   # reference
+    # train.py:238; "synthetic" (random 8-bit pairs of --image_size, no files) is this repo's addition for smoke runs / benchmarks
     for flag in ("no_pos_encoding", "noess", "cross_features", "use_single_softmax", "l1_pos_encoding", "fusion_transformer"):
         ap.add_argument("--" + flag, action="store_true")
     ap.add_argument("--fc_hidden_size", type=int, default=512)
@@ -244,6 +245,10 @@ if __name__ == "__main__":
             f.write("%s  %s\n" % (k, v))
     if a.resnet_weights:
         os.environ["RELPOSE_RESNET18_WEIGHTS"] = a.resnet_weights
+    if "WORLD_SIZE" not in os.environ and not a.no_ddp and torch.cuda.is_available() and a.gpus > torch.cuda.device_count():
+        # the reference would fail in mp.spawn here; a default of 4 on a smaller box is more useful clamped (deviation, stated)
+        print("note: --gpus %d but %d GPU(s) visible: running %d rank(s)" % (a.gpus, torch.cuda.device_count(), torch.cuda.device_count()))
+        a.gpus = torch.cuda.device_count()
     if "WORLD_SIZE" in os.environ or a.no_ddp or a.gpus <= 1:
         run(a)                      # under a launcher (one rank per process already), or a single GPU
     else:

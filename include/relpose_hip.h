@@ -36,7 +36,7 @@ extern "C" {
  * functions this header declares.  rp_abi_version() / rp_abi_export_count() return the values the library was COMPILED with, so a
  * binding (rel_pose_amd/_lib.py parses both macros and counts the declarations) rejects a stale .so at load time instead of
  * failing later on a missing symbol. */
-#define RP_ABI_VERSION 9
+#define RP_ABI_VERSION 10
 #define RP_ABI_EXPORTS 65
 int rp_abi_version(void);
 int rp_abi_export_count(void);
@@ -268,15 +268,18 @@ int rp_attn_bwd_dkdv(const float* q, const float* k, const float* v, const float
 /* dK/dV pass that also stores scale * dS ([Z,H,576,576] floats) TILED: ds[z][h][i >> 5][j >> 5][r][lane] with, inside a 32x32 tile,
  * i & 31 = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) and j & 31 = lane & 31 (the producing wave's MFMA accumulator image: 4 KB contiguous per
  * tile, coalesced 256-byte stores).  dQ = ds K is then ONE rp_ds_matmul instead of the dQ pass, which would recompute S and dP
- * (5 executed GEMMs instead of 7) */
+ * (5 executed GEMMs instead of 7).  bf16 != 0 (the bf16 configuration): the tiles are stored as BF16 in the same image (2 KB per
+ * tile, ds then holds Z*H*576*576 bf16) -- pass ds_bf16 = 1 to rp_ds_matmul */
 int rp_attn_bwd_dkdv_ds(const float* q, const float* k, const float* v, const float* dout, const float* lse,
                         const float* delta, float* dk, float* dv, float* ds, int Z, int H, int ldq, int ldk, int ldv, int lddo,
                         int lddk, int lddv, float scale, int bf16, void* stream);
 /* out[z][i][h*64 + d] = sum_j ds[z*H + h][i][j] * b[z ^ b_xor][j][h*64 + d] for the [Z,H,576,576] array a stored-dS pass wrote: the
  * dQ = dS K half of Attention's autograd (vision_transformer.py:325-329) after rp_attn_bwd_dkdv_ds, and with b_xor = 1 the
  * dK = dS^T-major x Q(partner image) half of the EMM's (:198-206) after rp_emm_grad_ds.  b / out point at the first of the H*64
- * columns (row strides ldb / ldo floats, 576 rows per image); one launch for all Z*H problems, dS streamed once from memory. */
-int rp_ds_matmul(const float* ds, const float* b, float* out, int Z, int H, int ldb, int ldo, int b_xor, void* stream);
+ * columns (row strides ldb / ldo floats, 576 rows per image); one launch for all Z*H problems, dS streamed once from memory.
+ * ds_bf16: 0 = fp32 tiles, exact fp32 MFMA; 1 = bf16 tiles (what the producers write when their bf16 flag is set): the product
+ * runs on v_mfma_f32_32x32x16_bf16 with b rounded to bf16 on chip, fp32 accumulate and output. */
+int rp_ds_matmul(const float* ds, const float* b, float* out, int Z, int H, int ldb, int ldo, int b_xor, int ds_bf16, void* stream);
 int rp_attn_bwd_dq(const float* q, const float* k, const float* v, const float* dout, const float* lse, const float* delta,
                    float* dq, int Z, int H, int ldq, int ldk, int ldv, int lddo, int lddq, float scale, int bf16, void* stream);
 
@@ -314,7 +317,7 @@ int rp_emm_grad(const float* qkv, int ldqkv, const float* x, const float* w, con
                 int bf16, void* stream);
 /* the owner = query pass (swap = 0) that also stores scale * dS_ij ([Z,H,576,576] floats) key index major and TILED like
  * rp_attn_bwd_dkdv_ds (rows = keys j, columns = queries i): the key-side gradient dk_z = ds_z q_{z^1} is then one
- * rp_ds_matmul(b_xor = 1) instead of the swap = 1 pass */
+ * rp_ds_matmul(b_xor = 1) instead of the swap = 1 pass.  bf16 != 0: bf16 tiles, as for rp_attn_bwd_dkdv_ds */
 int rp_emm_grad_ds(const float* qkv, int ldqkv, const float* x, const float* w, const float* rlse, const float* clse,
                    const float* rho, const float* gamma, float* dqkv, float* ds, int Z, int H, float scale, int single,
                    int bf16, void* stream);
@@ -334,11 +337,17 @@ int rp_pose_normalize_bwd(const float* pred, const float* dout, float* dpred, in
  * [N_in,192] contiguous, dact_aux = the saved pre-activation [M,N] (y is multiplied by GELU'(aux); NULL: none), colsum_part
  * [ceil(M / rp_linear_rows192_tile_rows()), N] (optional) receives the column sums of y per row tile -- summed, they are the
  * bias gradient of the layer below.
+ * precision: 0 exact fp32 MFMA; 1 = the bf16 configuration (operands rounded to bf16, fp32 accumulate:
+ * v_mfma_f32_16x16x32_bf16; LayerNorm, bias, GELU and the residual stay fp32) -- in this precision w points to a BF16 copy of
+ * the weight ([N,192] bf16, contiguous; the caller refreshes it when the fp32 master changes), x stays fp32 and is rounded to
+ * nearest even on chip.  io_bf16 (precision 1 only; RpGemm.io_bf16's bits): bit 1 = y and y_pre are written as bf16, bit 2 =
+ * dact_aux holds bf16.
  * ------------------------------------------------------------------------------------------- */
 int rp_linear_rows192_tile_rows(void);
 int rp_linear_rows192(const float* x, const float* w, const float* bias, const float* residual, const float* ln_gamma,
                       const float* ln_beta, float eps, float* y, float* y_pre, float* xn_out, float* mean_out, float* rstd_out,
-                      const float* dact_aux, float* colsum_part, int M, int N, int K, int act, void* stream);
+                      const float* dact_aux, float* colsum_part, int M, int N, int K, int act, int precision, int io_bf16,
+                      void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused transformer MLP, inference path (vision_transformer.py:353 + vit_layers/mlp.py:20-26):

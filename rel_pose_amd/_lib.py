@@ -90,7 +90,7 @@ _SIGS = {
     "rp_attn_bwd_delta": (c_int, [P, P, P, I, I, I, P]),
     "rp_attn_bwd": (c_int, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, P]),
     "rp_attn_bwd_dkdv_ds": (c_int, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, F, I, P]),
-    "rp_ds_matmul": (c_int, [P, P, P, I, I, I, I, I, P]),
+    "rp_ds_matmul": (c_int, [P, P, P, I, I, I, I, I, I, P]),
     "rp_attn_bwd_cross": (c_int, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, I, P]),
     "rp_attn_bwd_dkdv": (c_int, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, F, I, P]),
     "rp_attn_bwd_dq": (c_int, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, F, I, P]),
@@ -115,7 +115,7 @@ _SIGS = {
     "rp_event_destroy": (None, [P]),
     "rp_event_elapsed_ms": (c_float, [P, P]),
     "rp_linear_rows192_tile_rows": (c_int, []),
-    "rp_linear_rows192": (c_int, [P, P, P, P, P, P, F, P, P, P, P, P, P, P, I, I, I, I, P]),
+    "rp_linear_rows192": (c_int, [P, P, P, P, P, P, F, P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
     "rp_mlp_fused_workspace_bytes": (ctypes.c_size_t, [I]),
     "rp_mlp_fused_fwd": (c_int, [P, P, P, P, P, P, P, P, P, I, I, I, ctypes.c_float, P]),
     "rp_mlp_fused_bwd_workspace_bytes": (ctypes.c_size_t, [I]),

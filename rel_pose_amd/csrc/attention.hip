@@ -385,7 +385,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dkdv_kernel(AttnBwdP p)
     STAMP(3)
     if (p.ds) {      // TILED: tile (query block t, key block) = this wave's register image [16 r][64 lanes], 4 KB contiguous, fully
       // coalesced 256-byte stores; rp_ds_matmul (below) reads it -- the dQ pass then needs neither S nor dP again
-      store_acc_image(p.ds + ((((long long)zq * p.H + h) * NTILE + t) * NTILE + (k0 >> 5)) * 1024, dp, p.scale, lane);
+      const long long tile = (((long long)zq * p.H + h) * NTILE + t) * NTILE + (k0 >> 5);
+      if (BF) store_acc_image_bf16(reinterpret_cast<unsigned short*>(p.ds) + tile * 1024, dp, p.scale, lane);   // bf16 operands downstream: bf16 tiles
+      else store_acc_image(p.ds + tile * 1024, dp, p.scale, lane);
     }
     STAMP(4)
     accum_tile<KST, BF>(Ds[cur], l31, hi, s, dv0, dv1);     // dV^T += dO^T P
@@ -553,6 +555,81 @@ __global__ __launch_bounds__(NW * 64, 4) void ds_matmul_kernel(DsMmP p) {
     if (t + 2 < NSTEP) bload(t + 2);
   };
   for (int t = 0; t < NSTEP; t += 3) {      // NSTEP = 18 or 9: three register sets rotate without copies
+    step(a0, a2, t);
+    step(a1, a0, t + 1);
+    step(a2, a1, t + 2);
+  }
+  store_ownerT(p.out + ((long long)z * NTOK + i0 + l31) * p.ldo + h * 64, hi, o0, o1, 1.0f);
+}
+
+// The bf16 configuration's form: the producer stored bf16 tiles (store_acc_image_bf16: the same [16 r][64 lanes] image, 2 KB), so
+// a lane's 16 bytes at (its row's register row, 16 hi + 8 g) ARE the B operand of one v_mfma_f32_32x32x16_bf16 (k-slots 8 hi + e <->
+// columns j = 16 hi + 8 g + e); the A operand is the same eight rows of the b tile in LDS, rounded to bf16 (nearest even) as it is
+// read.  4 MFMAs of 32 cycles per tile instead of 32 of 64: the launch is the dS stream (half the bytes of the fp32 form).
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 4) void ds_matmul_bf16_kernel(DsMmP p) {
+  constexpr int NT = NW * 64;
+  constexpr int NPF = (512 + NT - 1) / NT;                // float4 per thread per 32 x 64 b tile
+  __shared__ __attribute__((aligned(16))) float Bs[2][32 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  int zh, blk;
+  if (!xcd_problem(NTILE / NW, p.ZH, zh, blk)) return;
+  if (p.reverse) zh = p.ZH - 1 - zh;
+  const int h = zh % p.H, z = zh / p.H;
+  const int i0 = (blk * NW + wave) * 32;
+  const float* bb = p.b + (long long)(z ^ p.b_xor) * NTOK * p.ldb + h * 64;
+  const unsigned short* arow = reinterpret_cast<const unsigned short*>(p.ds) + ((long long)zh * NTILE + (i0 >> 5)) * NTILE * 1024 +
+                               ((l31 & 3) + 4 * (l31 >> 3)) * 64 + 32 * ((l31 >> 2) & 1) + 16 * hi;
+  f32x16 o0 = zero16(), o1 = zero16();
+  float4 bpre[NPF];
+  uint4 a0[2], a1[2], a2[2];
+  auto aload = [&](uint4 (&a)[2], int t) {
+    a[0] = *reinterpret_cast<const uint4*>(arow + 1024 * t);
+    a[1] = *reinterpret_cast<const uint4*>(arow + 1024 * t + 8);
+  };
+  auto bload = [&](int t) {
+#pragma unroll
+    for (int j = 0; j < NPF; ++j) {
+      int f = tid + NT * j;
+      if (512 % NT != 0) f = min(f, 511);
+      bpre[j] = ld4(bb + (long long)(t * 32 + (f >> 4)) * p.ldb + (f & 15) * 4);
+    }
+  };
+  auto bstore = [&](float* dst) {
+#pragma unroll
+    for (int j = 0; j < NPF; ++j) {
+      int f = tid + NT * j;
+      if (512 % NT != 0) f = min(f, 511);
+      st4(dst + f * 4, bpre[j]);
+    }
+  };
+  bload(0);
+  aload(a0, 0);
+  aload(a1, 1);
+  bstore(Bs[0]);
+  __syncthreads();
+  bload(1);
+  auto step = [&](const uint4 (&a)[2], uint4 (&anext)[2], int t) {
+    const float* B = Bs[t & 1];
+    if (t + 2 < NTILE) aload(anext, t + 2);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      float v0[8], v1[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float* br = B + (16 * hi + 8 * g + e) * 64 + l31;
+        v0[e] = br[0];
+        v1[e] = br[32];
+      }
+      const bf16x8 dsf = __builtin_bit_cast(bf16x8, a[g]);
+      o0 = mfma_bf(pack8(v0), dsf, o0);
+      o1 = mfma_bf(pack8(v1), dsf, o1);
+    }
+    if (t + 1 < NTILE) bstore(Bs[(t & 1) ^ 1]);
+    __syncthreads();
+    if (t + 2 < NTILE) bload(t + 2);
+  };
+  for (int t = 0; t < NTILE; t += 3) {
     step(a0, a2, t);
     step(a1, a0, t + 1);
     step(a2, a1, t + 2);
@@ -734,7 +811,8 @@ extern "C" int rp_attn_bwd_dq(const float* q, const float* k, const float* v, co
 
 // out[z][i][h*64 + d] = sum_j ds[z*H + h][i][j] * b[z ^ b_xor][j][h*64 + d]: the product that follows a stored-dS pass
 // (rp_attn_bwd_dkdv_ds: dQ = ds K;  rp_emm_grad_ds: dK = ds Q of the partner image, b_xor = 1), one launch for all Z*H problems
-extern "C" int rp_ds_matmul(const float* ds, const float* b, float* out, int Z, int H, int ldb, int ldo, int b_xor, void* stream) {
+extern "C" int rp_ds_matmul(const float* ds, const float* b, float* out, int Z, int H, int ldb, int ldo, int b_xor, int ds_bf16,
+                            void* stream) {
   if (Z <= 0 || H <= 0 || !ds || !b || !out || (b_xor & ~1) || (b_xor && (Z & 1))) return RP_EBADSHAPE;
   if ((ldb | ldo) & 3) return RP_EALIGN;
   const char* rv = getenv("RP_DSMM_REV");
@@ -743,7 +821,8 @@ extern "C" int rp_ds_matmul(const float* ds, const float* b, float* out, int Z, 
   // the MFMA form, is what bounds this kernel -- profiles/r3_ds_matmul.txt)
   const char* ov = getenv("RP_DSMM");
   hipStream_t st = (hipStream_t)stream;
-  if (ov && ov[0] == '1') hipLaunchKernelGGL((ds_matmul16_kernel<3>), dim3(xcd_grid(NTILE / 3, Z * H)), dim3(192), 0, st, p);
+  if (ds_bf16) hipLaunchKernelGGL((ds_matmul_bf16_kernel<3>), dim3(xcd_grid(NTILE / 3, Z * H)), dim3(192), 0, st, p);
+  else if (ov && ov[0] == '1') hipLaunchKernelGGL((ds_matmul16_kernel<3>), dim3(xcd_grid(NTILE / 3, Z * H)), dim3(192), 0, st, p);
   else hipLaunchKernelGGL((ds_matmul_kernel<3>), dim3(xcd_grid(NTILE / 3, Z * H)), dim3(192), 0, st, p);
   RP_CHECK_LAUNCH();
   return RP_OK;

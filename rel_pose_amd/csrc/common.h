@@ -143,6 +143,18 @@ RP_DEV void store_acc_image(float* tile, const f32x16& v, float mul, int lane) {
   }
 }
 
+// the same image with bf16 elements (2 KB per tile; the bf16 configuration's stored dS): after the quad transpose a lane holds four
+// consecutive lanes' values of one register row = 8 bytes; every store instruction still covers four whole 128-byte rows
+RP_DEV void store_acc_image_bf16(unsigned short* tile, const f32x16& v, float mul, int lane) {
+  const int q = lane & 3;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float a[4] = {v[4 * g] * mul, v[4 * g + 1] * mul, v[4 * g + 2] * mul, v[4 * g + 3] * mul};
+    quad_transpose4(a, q);
+    *reinterpret_cast<uint2*>(tile + (4 * g + q) * 64 + (lane & ~3)) = make_uint2(pk_bf16(a[0], a[1]), pk_bf16(a[2], a[3]));
+  }
+}
+
 // XCD-aware work order for the (image, head) x row-block kernels: workgroup b runs on XCD b % 8 (private 4 MB L2), so
 // XCD x takes the (image, head) problems zh = x (mod 8) and runs all NQ row-block workgroups of one problem back to
 // back: the K/V (or Q/dO) tiles every one of them streams are then fetched into ONE L2 once.  Measured before: the

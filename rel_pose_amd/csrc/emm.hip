@@ -357,7 +357,9 @@ __global__ __launch_bounds__(GT, 2) void emm_grad_kernel(EmmP p) {
     }
     if (p.ds) {      // (owner = query pass only) TILED: tile (loop block t, owner block) = this wave's register image [16 r][64 lanes],
       // 4 KB contiguous, rows = loop index j, columns = owners i: fully coalesced 256-byte stores; rp_ds_matmul reads it (attention.hip)
-      store_acc_image(p.ds + ((zh * (NTOK / 32) + t) * (NTOK / 32) + (o0 >> 5)) * 1024, s, p.scale, lane);
+      const long long tile = (zh * (NTOK / 32) + t) * (NTOK / 32) + (o0 >> 5);
+      if (BF) store_acc_image_bf16(reinterpret_cast<unsigned short*>(p.ds) + tile * 1024, s, p.scale, lane);
+      else store_acc_image(p.ds + tile * 1024, s, p.scale, lane);
     }
     // d owner^T[d][owner] += sum_loop other[loop][d] dS^T[loop][owner]
     if (BF) {

@@ -21,6 +21,36 @@ namespace {
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 RP_DEV f32x4v mfma16(float a, float b, f32x4v c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+// bf16 operand precision (BF = true, the bf16 configuration): v_mfma_f32_16x16x32_bf16.  Lane (j, q) of a 32-wide k block u supplies
+// the 8 CONSECUTIVE values k = 32 u + 8 q .. + 7 of its row: the weights arrive as bf16 (the host keeps a bf16 copy, refreshed when
+// the fp32 master changes), so a staged chunk is [32 units][192] bf16 = 12 KB (half the DMA and LDS traffic of the fp32 form) and
+// one ds_read_b128 IS one A operand -- no conversion in the loop; the x rows are rounded to bf16 (nearest even) once per row tile.
+// The accumulator layout, and so the whole epilogue, is that of the fp32 form.  LDS image of a chunk: 24 slots of 16 B per unit
+// row (384 B = 1.5 bank rows), slot index XOR-swizzled within its group of 8 by (row >> 1) & 7: the 16 lanes of a read then cover
+// 16 distinct 16-byte slots of the 256-byte bank row.
+RP_DEV float4 widen4(uint2 w) {          // 4 bf16 -> fp32 (exact)
+  return make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16), __uint_as_float(w.y & 0xffff0000u));
+}
+// lane (j, q) holds units 4q..4q+3 of a 32-unit chunk's first 16 (v0) and second 16 (v1); after swapping halves with lane q ^ 1
+// (lane ^ 16) it stores 8 consecutive bf16: even q -> [own v0 | partner's v0], odd q -> [partner's v1 | own v1]
+RP_DEV void st_bf16x8(unsigned short* dst, float4 v0, float4 v1, int q) {
+  const unsigned a0 = pk_bf16(v0.x, v0.y), a1 = pk_bf16(v0.z, v0.w), b0 = pk_bf16(v1.x, v1.y), b1 = pk_bf16(v1.z, v1.w);
+  const bool odd = q & 1;
+  const unsigned s0 = odd ? a0 : b0, s1 = odd ? a1 : b1;
+  const unsigned r0 = __shfl_xor(s0, 16, 64), r1 = __shfl_xor(s1, 16, 64);
+  const uint4 w = odd ? make_uint4(r0, r1, b0, b1) : make_uint4(a0, a1, r0, r1);
+  *reinterpret_cast<uint4*>(dst) = w;
+}
+// the inverse for a bf16 aux row: one 16-byte load of 8 consecutive units per lane, halves swapped back into (v0, v1)
+RP_DEV void ld_bf16x8(const unsigned short* src, float4& v0, float4& v1, int q) {
+  const uint4 w = *reinterpret_cast<const uint4*>(src);
+  const bool odd = q & 1;
+  const unsigned s0 = odd ? w.x : w.z, s1 = odd ? w.y : w.w;          // even q sends the partner's v0 half, odd q the partner's v1 half
+  const unsigned r0 = __shfl_xor(s0, 16, 64), r1 = __shfl_xor(s1, 16, 64);
+  v0 = odd ? widen4(make_uint2(r0, r1)) : widen4(make_uint2(w.x, w.y));
+  v1 = odd ? widen4(make_uint2(w.z, w.w)) : widen4(make_uint2(r0, r1));
+}
+RP_DEV f32x4v mfma16bf(bf16x8 a, bf16x8 b, f32x4v c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 
 constexpr int C = 192, CH = 32, WT = CH * C;               // 6144 floats = 24 KB per staged weight chunk
 constexpr int NW = 4, NT = NW * 64, ROWS = NW * 16, DMA = (WT / 4) / NT;   // 6 LDS-DMA rounds per chunk
@@ -35,6 +65,7 @@ struct RowsP {
   float eps;
   int act;                   // 0 none, 1 GELU
   int nchunk, tiles, base, rem;
+  int io_bf16;               // BF only: bit 1 = y / ypre stored as bf16, bit 2 = aux holds bf16 (RpGemm.io_bf16's meaning)
 #ifdef RP_ROWS_PROBE
   long long* probe;          // tools/lab/rows_probe: shader-clock stamps [block][chunk][wave][5]
 #endif
@@ -48,9 +79,14 @@ struct RowsP {
 #define RP_STAMP(k)
 #endif
 
-template <bool LN>
+template <bool LN, bool BF = false>
 __global__ __launch_bounds__(NT, 3) void linear_rows_kernel(RowsP p) {
-  __shared__ __attribute__((aligned(16))) float wt[2][WT];
+  constexpr int WTB = BF ? WT / 2 : WT;             // floats per staged chunk (bf16 weights: half)
+  constexpr int NDMA = BF ? DMA / 2 : DMA;
+  // bf16 form: FOUR 12 KB stages (the same 48 KB), the weight DMA runs up to three chunks ahead with a counted vmcnt -- its chunk costs
+  // 12 MFMAs of 16 cycles instead of 96 of 32, so nothing hides a DMA issued only one chunk ahead
+  constexpr int NS = BF ? 4 : 2;
+  __shared__ __attribute__((aligned(16))) float wt[NS][WTB];
   // 1.5 KB shared by two uses that never coincide: gamma | beta of the fused LayerNorm (forward), or the per-wave column sums of a
   // chunk by chunk parity (input-gradient form; readers of chunk k never meet writers of k + 1).  Kept this small on purpose: with
   // 53 KB per workgroup only two, not three, workgroups are resident per CU (measured: tools/lab/rows_probe; the occupancy API still reports three).
@@ -65,18 +101,26 @@ __global__ __launch_bounds__(NT, 3) void linear_rows_kernel(RowsP p) {
     __syncthreads();
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, q = lane >> 4;
-  unsigned off[DMA];
+  unsigned off[NDMA];
 #pragma unroll
-  for (int r = 0; r < DMA; ++r) {
-    const int pp = r * NT + tid, row = pp / 48, ch = (pp % 48) ^ (row & 15);
-    off[r] = (unsigned)((row * C + ch * 4) * 4);
+  for (int r = 0; r < NDMA; ++r) {
+    const int pp = r * NT + tid;
+    if (BF) {
+      const int row = pp / 24, sl = pp % 24, ch = (sl & ~7) | ((sl & 7) ^ ((row >> 1) & 7));
+      off[r] = (unsigned)(row * C * 2 + ch * 16);
+    } else {
+      const int row = pp / 48, ch = (pp % 48) ^ (row & 15);
+      off[r] = (unsigned)((row * C + ch * 4) * 4);
+    }
   }
   const unsigned l0 = lds_byte_addr(&wt[0][0]) + wave * 1024;
   auto issue = [&](int c, int buf) {
-    const float* src = uniform_ptr(p.w + (long long)c * CH * C);
+    const float* src = uniform_ptr(BF ? p.w + (long long)c * CH * (C / 2) : p.w + (long long)c * CH * C);   // (bf16 weights: C/2 floats per row)
 #pragma unroll
-    for (int r = 0; r < DMA; ++r) glds16(src, off[r], l0 + buf * (WT * 4) + r * NT * 16);
+    for (int r = 0; r < NDMA; ++r) glds16(src, off[r], l0 + buf * (WTB * 4) + r * NT * 16);
   };
+  // column of the first of the 4 consecutive row elements register group t (0..11) of lane (j, q) holds
+  auto colof = [&](int t) { return BF ? 32 * (t >> 1) + 8 * q + 4 * (t & 1) : 16 * t + 4 * q; };
   const int b = blockIdx.x;
   int it = b * p.base + min(b, p.rem);
   const int end = it + p.base + (b < p.rem ? 1 : 0);
@@ -89,17 +133,23 @@ __global__ __launch_bounds__(NT, 3) void linear_rows_kernel(RowsP p) {
   }
 #endif
   if (it < end) issue(it % p.nchunk, 0);
+  if constexpr (BF) {
+#pragma unroll
+    for (int s = 1; s < NS - 1; ++s)
+      if (it + s < end) issue((it + s) % p.nchunk, s);
+  }
+  int par = 0;               // parity of the column-sum scratch
   const bool has_bias = p.bias != nullptr, pre = p.ypre != nullptr, has_res = p.res != nullptr, has_aux = p.aux != nullptr, want_cs = p.colpart != nullptr;
   while (it < end) {
     const int tile = it / p.nchunk, c0 = it % p.nchunk, c1 = min(p.nchunk, c0 + end - it);
     const int row = tile * ROWS + wave * 16 + j;
     const bool live = row < p.M;
     const long long rclamp = min(row, p.M - 1);
-    const float* xr = p.x + rclamp * C + 4 * q;
+    const float* xr = p.x + rclamp * C;
     float xn[48];
 #pragma unroll
     for (int t = 0; t < 12; ++t) {
-      const float4 v = ld4(xr + 16 * t);
+      const float4 v = ld4(xr + colof(t));
       xn[4 * t] = v.x; xn[4 * t + 1] = v.y; xn[4 * t + 2] = v.z; xn[4 * t + 3] = v.w;
     }
     if (LN) {
@@ -121,18 +171,24 @@ __global__ __launch_bounds__(NT, 3) void linear_rows_kernel(RowsP p) {
       const bool owner = c0 == 0 && live;                            // the range holding the tile's first chunk writes xn / stats
 #pragma unroll
       for (int t = 0; t < 12; ++t) {
-        const float4 g = ld4(aux_lds + 16 * t + 4 * q), bb = ld4(aux_lds + C + 16 * t + 4 * q);
+        const float4 g = ld4(aux_lds + colof(t)), bb = ld4(aux_lds + C + colof(t));
         xn[4 * t] = (xn[4 * t] - mu) * rs * g.x + bb.x;
         xn[4 * t + 1] = (xn[4 * t + 1] - mu) * rs * g.y + bb.y;
         xn[4 * t + 2] = (xn[4 * t + 2] - mu) * rs * g.z + bb.z;
         xn[4 * t + 3] = (xn[4 * t + 3] - mu) * rs * g.w + bb.w;
-        if (p.xn && owner) st4(p.xn + (long long)row * C + 16 * t + 4 * q, make_float4(xn[4 * t], xn[4 * t + 1], xn[4 * t + 2], xn[4 * t + 3]));
+        if (p.xn && owner) st4(p.xn + (long long)row * C + colof(t), make_float4(xn[4 * t], xn[4 * t + 1], xn[4 * t + 2], xn[4 * t + 3]));
       }
       if (owner && q == 0) {
         if (p.mean) p.mean[row] = mu;
         if (p.rstd) p.rstd[row] = rs;
       }
     }
+    bf16x8 xb[BF ? 6 : 1];
+    if constexpr (BF) {
+#pragma unroll
+      for (int u = 0; u < 6; ++u) xb[u] = pack8(xn + 8 * u);
+    }
+    const bool y_bf = BF && (p.io_bf16 & 2), aux_bf = BF && (p.io_bf16 & 4);
     // The stores of chunk c are issued after the barrier of chunk c + 1, BEFORE the next weight DMA: loads and stores retire in
     // order on one counter, so the barrier's vmcnt(0) then waits for a DMA issued a whole chunk ago and for stores older still.
     float4 pv0, pv1, pp0, pp1;
@@ -147,23 +203,43 @@ __global__ __launch_bounds__(NT, 3) void linear_rows_kernel(RowsP p) {
         p.colpart[(long long)cs_tile * p.N + cs_chunk * CH + tid] = sum;
       }
       if (pending && live) {
-        if (pre) {
-          st4(p.ypre + po, pp0);
-          st4(p.ypre + po + 16, pp1);
+        if (y_bf) {
+          // bf16 rows: a lane's 4 + 4 units would be two 8-byte stores; lanes q and q ^ 1 swap halves instead so that every lane owns 8
+          // CONSECUTIVE units (even q: units 4q .. 4q+7 of the first 16, odd q: 16 + 4(q-1) .. + 7) = one 16-byte store, 64 contiguous
+          // bytes per row and instruction like the fp32 form (the memory system is bound by requests here, not bytes)
+          const long long pb16 = po - 4 * q + ((q & 1) ? 16 + 4 * (q - 1) : 4 * q);
+          if (pre) st_bf16x8(reinterpret_cast<unsigned short*>(p.ypre) + pb16, pp0, pp1, q);
+          st_bf16x8(reinterpret_cast<unsigned short*>(p.y) + pb16, pv0, pv1, q);
+        } else {
+          if (pre) {
+            st4(p.ypre + po, pp0);
+            st4(p.ypre + po + 16, pp1);
+          }
+          st4(p.y + po, pv0);
+          st4(p.y + po + 16, pv1);
         }
-        st4(p.y + po, pv0);
-        st4(p.y + po + 16, pv1);
       }
       pending = false;
     };
     for (int c = c0; c < c1; ++c, ++it) {
       RP_STAMP(0);
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      if constexpr (BF) {
+        // chunk `it` must have landed; the DMAs of the (up to NS - 2) chunks after it are the youngest VM operations of this wave
+        // (order per iteration: epilogue-operand loads, stores of the previous chunk, DMA) and may stay in flight
+        const int younger = min(NS - 2, end - 1 - it);
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NDMA) : "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NDMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      }
       RP_STAMP(1);
-      asm volatile("s_barrier" ::: "memory");                                       // W(c) landed; other buffer free
+      asm volatile("s_barrier" ::: "memory");                                       // W(c) landed; the stage refilled below is free
       RP_STAMP(2);
-      flush();
-      if (it + 1 < end) issue((it + 1) % p.nchunk, buf ^ 1);
+      if constexpr (!BF) {
+        flush();
+        if (it + 1 < end) issue((it + 1) % p.nchunk, buf ^ 1);
+      }
       const long long o = rclamp * p.N + c * CH + 4 * q;
       float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, g0 = r0, g1 = r0, ba = r0, bb = r0;
       if (has_bias) {          // (from L2; staging the bias in LDS costs the third resident workgroup per CU)
@@ -175,13 +251,33 @@ __global__ __launch_bounds__(NT, 3) void linear_rows_kernel(RowsP p) {
         r1 = ld4(p.res + o + 16);
       }
       if (has_aux) {
-        g0 = ld4(p.aux + o);
-        g1 = ld4(p.aux + o + 16);
+        if (aux_bf) {
+          ld_bf16x8(reinterpret_cast<const unsigned short*>(p.aux) + o - 4 * q + ((q & 1) ? 16 + 4 * (q - 1) : 4 * q), g0, g1, q);
+        } else {
+          g0 = ld4(p.aux + o);
+          g1 = ld4(p.aux + o + 16);
+        }
         asm volatile("" ::: "memory");
+      }
+      if constexpr (BF) {
+        flush();
+        if (it + NS - 1 < end) issue((it + NS - 1) % p.nchunk, buf == 0 ? NS - 1 : buf - 1);
       }
       f32x4v h0 = {0.f, 0.f, 0.f, 0.f}, h1 = {0.f, 0.f, 0.f, 0.f};
       const float* a0p = &wt[buf][0] + j * C;
       const float* a1p = a0p + 16 * C;
+      if constexpr (BF) {
+        const float* w0 = &wt[buf][0] + j * (C / 2);            // unit row j of the chunk, in floats (2 bf16 each)
+        const float* w1 = w0 + 16 * (C / 2);
+        const int key = (j >> 1) & 7;
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+          const int sl = 4 * u + q, ch = ((sl & ~7) | ((sl & 7) ^ key)) * 4;
+          const float4 l = ld4(w0 + ch), m = ld4(w1 + ch);
+          h0 = mfma16bf(__builtin_bit_cast(bf16x8, l), xb[u], h0);
+          h1 = mfma16bf(__builtin_bit_cast(bf16x8, m), xb[u], h1);
+        }
+      } else {
       float4 a0 = ld4(a0p + ((q ^ j) * 4)), a1 = ld4(a1p + ((q ^ j) * 4));
       __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
@@ -205,6 +301,7 @@ __global__ __launch_bounds__(NT, 3) void linear_rows_kernel(RowsP p) {
         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
       }
+      }
       RP_STAMP(3);
       float4 v0 = make_float4(h0[0] + ba.x, h0[1] + ba.y, h0[2] + ba.z, h0[3] + ba.w);
       float4 v1 = make_float4(h1[0] + bb.x, h1[1] + bb.y, h1[2] + bb.z, h1[3] + bb.w);
@@ -226,16 +323,17 @@ __global__ __launch_bounds__(NT, 3) void linear_rows_kernel(RowsP p) {
         float4 c0v = make_float4(row16_sum(m * pv0.x), row16_sum(m * pv0.y), row16_sum(m * pv0.z), row16_sum(m * pv0.w));
         float4 c1v = make_float4(row16_sum(m * pv1.x), row16_sum(m * pv1.y), row16_sum(m * pv1.z), row16_sum(m * pv1.w));
         if (j == 0) {
-          st4(&cs_lds[buf][0] + wave * CH + 4 * q, c0v);
-          st4(&cs_lds[buf][0] + wave * CH + 16 + 4 * q, c1v);
+          st4(&cs_lds[par][0] + wave * CH + 4 * q, c0v);
+          st4(&cs_lds[par][0] + wave * CH + 16 + 4 * q, c1v);
         }
-        cs_par = buf;
+        cs_par = par;
         cs_tile = tile;
         cs_chunk = c;
       }
       po = o;
       pending = true;
-      buf ^= 1;
+      buf = buf + 1 == NS ? 0 : buf + 1;
+      par ^= 1;
       RP_STAMP(4);
 #ifdef RP_ROWS_PROBE
       ++nstamp;
@@ -253,14 +351,14 @@ __global__ __launch_bounds__(NT, 3) void linear_rows_kernel(RowsP p) {
 #endif
 }
 
-template <bool LN>
+template <bool LN, bool BF>
 int rows_slots() {
   static int slots = 0;
   if (!slots) {
     int dev = 0, cus = 256, per_cu = 1;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, linear_rows_kernel<LN>, NT, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, linear_rows_kernel<LN, BF>, NT, 0);
     slots = cus * (per_cu > 0 ? per_cu : 1);
   }
   return slots;
@@ -273,20 +371,26 @@ extern "C" int rp_linear_rows192_tile_rows(void) { return ROWS; }
 extern "C" int rp_linear_rows192(const float* x, const float* w, const float* bias, const float* residual, const float* ln_gamma,
                                  const float* ln_beta, float eps, float* y, float* y_pre, float* xn_out, float* mean_out,
                                  float* rstd_out, const float* dact_aux, float* colsum_part, int M, int N, int K, int act,
-                                 void* stream) {
+                                 int precision, int io_bf16, void* stream) {
   if (M <= 0 || K != C || N <= 0 || N % CH != 0 || N > MAXN || !x || !w || !y || act < 0 || act > 1) return RP_EBADSHAPE;
   if ((ln_gamma == nullptr) != (ln_beta == nullptr)) return RP_EBADSHAPE;
   const bool ln = ln_gamma != nullptr;
   if (!ln && (xn_out || mean_out || rstd_out)) return RP_EBADSHAPE;
-  RowsP p{x, w, bias, residual, ln_gamma, ln_beta, y, y_pre, xn_out, mean_out, rstd_out, dact_aux, colsum_part, M, N, eps, act, N / CH, (M + ROWS - 1) / ROWS, 0, 0};
+  if (precision != 0 && precision != 1) return RP_EUNSUPPORTED;
+  if (io_bf16 && (precision != 1 || (io_bf16 & ~6) || ((io_bf16 & 4) && !dact_aux))) return RP_EUNSUPPORTED;
+  const bool bf = precision == 1;
+  RowsP p{x, w, bias, residual, ln_gamma, ln_beta, y, y_pre, xn_out, mean_out, rstd_out, dact_aux, colsum_part, M, N, eps, act, N / CH, (M + ROWS - 1) / ROWS, 0, 0, io_bf16};
   const long long items = (long long)p.tiles * p.nchunk;
-  const int slots = ln ? rows_slots<true>() : rows_slots<false>();
+  const int slots = bf ? (ln ? rows_slots<true, true>() : rows_slots<false, true>()) : (ln ? rows_slots<true, false>() : rows_slots<false, false>());
   const int G = (int)(items < slots ? items : slots);
   p.base = (int)(items / G);
   p.rem = (int)(items % G);
   hipStream_t st = (hipStream_t)stream;
-  if (ln) hipLaunchKernelGGL(linear_rows_kernel<true>, dim3(G), dim3(NT), 0, st, p);
-  else hipLaunchKernelGGL(linear_rows_kernel<false>, dim3(G), dim3(NT), 0, st, p);
+  if (bf) {
+    if (ln) hipLaunchKernelGGL((linear_rows_kernel<true, true>), dim3(G), dim3(NT), 0, st, p);
+    else hipLaunchKernelGGL((linear_rows_kernel<false, true>), dim3(G), dim3(NT), 0, st, p);
+  } else if (ln) hipLaunchKernelGGL((linear_rows_kernel<true, false>), dim3(G), dim3(NT), 0, st, p);
+  else hipLaunchKernelGGL((linear_rows_kernel<false, false>), dim3(G), dim3(NT), 0, st, p);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }

@@ -481,7 +481,23 @@ def transposed(w):
     return outs[0][2]
 
 
-# K = 192 Linear layers on the row-resident kernel (csrc/linear_rows.hip) instead of the generic LDS-DMA GEMM: exact fp32 only
+def bf16_weight(w):
+    """bf16 copy (round to nearest even) of a weight for the bf16 configuration's row-resident Linear kernel, cached on the tensor
+    until it is modified (same invalidation rules as transposed())."""
+    c = getattr(w, "_rp_b", None)
+    if c is not None and c[0] == w._version and c[1] == w.data_ptr() and c[2] == _PAD_GEN:
+        return c[3]
+    o = w.detach().contiguous().to(torch.bfloat16)
+    if not (w.is_cuda and torch.cuda.is_current_stream_capturing()):
+        try:
+            w._rp_b = (w._version, w.data_ptr(), _PAD_GEN, o)
+        except AttributeError:
+            pass
+    return o
+
+
+# K = 192 Linear layers on the row-resident kernel (csrc/linear_rows.hip) instead of the generic LDS-DMA GEMM: exact fp32, and the
+# bf16 configuration (operand precision 1) on the same kernel with v_mfma_f32_16x16x32_bf16
 ROWS_LINEAR = os.environ.get("RP_ROWS_LINEAR", "1") != "0"
 
 
@@ -489,20 +505,27 @@ ROWS_DX = os.environ.get("RP_ROWS_DX", "1") != "0"      # input-gradient GEMMs t
 
 
 def _rows_ok(x, W):
-    return (ROWS_LINEAR and GEMM_PRECISION == 0 and x.shape[1] == DIM and W.shape[1] == DIM and W.shape[0] % 32 == 0
+    return (ROWS_LINEAR and GEMM_PRECISION in (0, 1) and x.dtype == torch.float32 and x.shape[1] == DIM and W.shape[1] == DIM and W.shape[0] % 32 == 0
             and W.shape[0] <= 1024 and x.is_contiguous() and W.is_contiguous())
 
 
-def linear_rows(x, W, b=None, act=0, want_pre=False, residual=None, ln=None, want_ln_out=False, dact_aux=None, want_colsum=False):
+def linear_rows(x, W, b=None, act=0, want_pre=False, residual=None, ln=None, want_ln_out=False, dact_aux=None, want_colsum=False,
+                out_dtype=None):
     """rp_linear_rows192: y = act(LN?(x) W^T + b) (+ residual) for K = 192.  ln = (gamma, beta) fuses the LayerNorm;
     want_ln_out additionally returns (xn, mean, rstd).  dact_aux [M,N]: y *= GELU'(aux); want_colsum: also the column sums of y
-    (from per-tile partials).  Returns y [, pre] [, xn, mean, rstd] [, colsum]."""
+    (from per-tile partials).  Returns y [, pre] [, xn, mean, rstd] [, colsum].  At operand precision 1 (the bf16 configuration)
+    dact_aux may be a bf16 tensor and out_dtype=torch.bfloat16 stores y (and pre) as bf16."""
     lib = _lib.load()
-    _chk(x, W, b, residual, dact_aux)
+    _chk(x, W, b, residual)
+    _chk_act(dact_aux)
     M, K = x.shape
     N = W.shape[0]
-    y = _empty(M, N, like=x)
-    pre = _empty(M, N, like=x) if want_pre else None
+    obf = out_dtype == torch.bfloat16
+    io = (2 if obf else 0) | (4 if (dact_aux is not None and dact_aux.dtype == torch.bfloat16) else 0)
+    if io and GEMM_PRECISION != 1:
+        raise RuntimeError("bf16-stored operands need operand precision 1 (the bf16 configuration)")
+    y = torch.empty(M, N, device=x.device, dtype=torch.bfloat16) if obf else _empty(M, N, like=x)
+    pre = (torch.empty(M, N, device=x.device, dtype=torch.bfloat16) if obf else _empty(M, N, like=x)) if want_pre else None
     xn = mean = rstd = None
     g = be = None
     if ln is not None:
@@ -514,8 +537,10 @@ def linear_rows(x, W, b=None, act=0, want_pre=False, residual=None, ln=None, wan
     nmn = 1 + (pre is not None) + (residual is not None) + (dact_aux is not None)
     with timed("linear_rows_ln" if ln is not None else "linear_rows", 2.0 * M * N * K,
                4.0 * (M * K * (1 + (xn is not None)) + N * K + M * N * nmn)):
-        _lib.check(lib.rp_linear_rows192(_p(x), _p(W), _p(b), _p(residual), _p(g), _p(be), LN_EPS, _p(y), _p(pre), _p(xn), _p(mean),
-                                         _p(rstd), _p(dact_aux), _p(part), M, N, K, act, _st()), "rp_linear_rows192")
+        wk = bf16_weight(W) if GEMM_PRECISION == 1 else W
+        _lib.check(lib.rp_linear_rows192(_p(x), _p(wk), _p(b), _p(residual), _p(g), _p(be), LN_EPS, _p(y), _p(pre), _p(xn), _p(mean),
+                                         _p(rstd), _p(dact_aux), _p(part), M, N, K, act, GEMM_PRECISION, io, _st()),
+                   "rp_linear_rows192")
     out = ((y,) + ((pre,) if want_pre else ()) + ((xn, mean, rstd) if (ln is not None and want_ln_out) else ())
            + ((colsum(part),) if want_colsum else ()))
     return out[0] if len(out) == 1 else out
@@ -524,8 +549,8 @@ def linear_rows(x, W, b=None, act=0, want_pre=False, residual=None, ln=None, wan
 def ln_linear(x, gamma, beta, W, b, act=0, want_pre=False, train=True, out_dtype=None):
     """(y [, pre], xn, mean, rstd) of  act(LayerNorm(x) W^T + b): one kernel when the row-resident path applies (xn / stats are
     None at inference), LayerNorm kernel + GEMM otherwise."""
-    if _rows_ok(x, W) and out_dtype is None:
-        r = linear_rows(x, W, b, act=act, want_pre=want_pre, ln=(gamma, beta), want_ln_out=train)
+    if _rows_ok(x, W):
+        r = linear_rows(x, W, b, act=act, want_pre=want_pre, ln=(gamma, beta), want_ln_out=train, out_dtype=out_dtype)
         r = r if isinstance(r, tuple) else (r,)
         return r if train else r + (None, None, None)
     xn, m, rs = layernorm_fwd(x, gamma, beta)
@@ -536,8 +561,8 @@ def ln_linear(x, gamma, beta, W, b, act=0, want_pre=False, train=True, out_dtype
 def linear(x, W, b=None, act=0, want_pre=False, residual=None, out_dtype=None):
     """y = act(x W^T + b) (+ residual); x [M,K], W [N,K].  out_dtype=torch.bfloat16: y (and the pre-activation) stored as bf16
     (bf16 configuration only)."""
-    if _rows_ok(x, W) and (residual is None or residual.is_contiguous()) and out_dtype is None and x.dtype == torch.float32:
-        return linear_rows(x, W, b, act=act, want_pre=want_pre, residual=residual)
+    if _rows_ok(x, W) and (residual is None or residual.is_contiguous()) and (out_dtype is None or residual is None):
+        return linear_rows(x, W, b, act=act, want_pre=want_pre, residual=residual, out_dtype=out_dtype)
     M, K = x.shape
     N = W.shape[0]
     pre = torch.empty(M, N, device=x.device, dtype=out_dtype or torch.float32) if want_pre else None
@@ -550,10 +575,10 @@ def linear_dx(dy, W, dact=0, aux=None, want_colsum=False, out_dtype=None):
     layer below when dx is its pre-activation gradient), from the epilogue."""
     M, N = dy.shape
     K = W.shape[1]
-    if (ROWS_DX and N == DIM and K % 32 == 0 and K <= 1024 and GEMM_PRECISION == 0 and dy.is_contiguous() and dact in (0, 1)
-            and out_dtype is None):
+    if (ROWS_DX and N == DIM and K % 32 == 0 and K <= 1024 and GEMM_PRECISION in (0, 1) and dy.is_contiguous() and dact in (0, 1)
+            and dy.dtype == torch.float32):
         # contraction over the layer's 192 outputs: the row-resident kernel on the transposed weight (a 0.1-0.6 MB copy)
-        return linear_rows(dy, transposed(W), dact_aux=aux if dact else None, want_colsum=want_colsum)
+        return linear_rows(dy, transposed(W), dact_aux=aux if dact else None, want_colsum=want_colsum, out_dtype=out_dtype)
     return gemm(dy, W, M, K, N, b_layout=1, dact=dact, aux=aux, want_colsum=want_colsum, out_dtype=out_dtype)
 
 
@@ -701,12 +726,19 @@ ATTN_BWD_STORE_DS = os.environ.get("RP_ATTN_DS", "1") == "1"
 EMM_BWD_STORE_DS = os.environ.get("RP_EMM_DS", "1") == "1"
 
 
+def _ds_buffer(Z, like):
+    """the stored-dS array of one attention / EMM backward: [Z,H,576,576] in 32x32 tiles, bf16 in the bf16 configuration"""
+    return torch.empty(Z, HEADS, N_TOK, N_TOK, device=like.device, dtype=torch.bfloat16 if ATTN_BF16 else torch.float32)
+
+
 def ds_matmul(ds, b_base, ldb, out_base, ldo, Z, b_xor=0):
-    """out[z][i][h*64+d] = sum_j ds[z,h,i,j] b[z^b_xor][j][h*64+d]; b_base / out_base: device addresses of the first column."""
+    """out[z][i][h*64+d] = sum_j ds[z,h,i,j] b[z^b_xor][j][h*64+d]; b_base / out_base: device addresses of the first column.
+    ds: the tiled array a stored-dS pass wrote (fp32, or bf16 from the bf16 configuration's producers)."""
     lib = _lib.load()
-    _chk(ds)
-    with timed("ds_matmul", 2.0 * Z * HEADS * N_TOK * N_TOK * 64, 4.0 * Z * HEADS * N_TOK * (N_TOK + 128)):
-        _lib.check(lib.rp_ds_matmul(_p(ds), ctypes.c_void_p(b_base), ctypes.c_void_p(out_base), Z, HEADS, ldb, ldo, b_xor, _st()),
+    _chk_act(ds)
+    bf = int(ds.dtype == torch.bfloat16)
+    with timed("ds_matmul", 2.0 * Z * HEADS * N_TOK * N_TOK * 64, Z * HEADS * N_TOK * ((2.0 if bf else 4.0) * N_TOK + 4.0 * 128)):
+        _lib.check(lib.rp_ds_matmul(_p(ds), ctypes.c_void_p(b_base), ctypes.c_void_p(out_base), Z, HEADS, ldb, ldo, b_xor, bf, _st()),
                    "rp_ds_matmul")
 
 
@@ -729,13 +761,13 @@ def attn_bwd(qkv, o, lse, do, Z, fork=None, kv_xor=0):
                    "rp_attn_bwd_cross")
         return dqkv
     if ATTN_BWD_STORE_DS and (fork is None or not fork.enabled):
-        # the dK/dV pass stores scale*dS (fp32, [Z,H,576,576] in 32x32 tiles); dQ = dS K is then one rp_ds_matmul: 5 executed GEMMs
-        # instead of 7 (the dQ pass would recompute S and dP) for 2 x 510 MB of extra HBM traffic
-        ds = _empty(Z, HEADS, N_TOK, N_TOK, like=qkv)
+        # the dK/dV pass stores scale*dS ([Z,H,576,576] in 32x32 tiles; fp32, bf16 in the bf16 configuration); dQ = dS K is then one
+        # rp_ds_matmul: 5 executed GEMMs instead of 7 (the dQ pass would recompute S and dP) for 2 x 510 MB of extra HBM traffic
+        ds = _ds_buffer(Z, qkv)
         _lib.check(lib.rp_attn_bwd_dkdv_ds(P(b), P(b + 4 * DIM), P(b + 8 * DIM), _p(do), _p(lse), _p(delta), P(d + 4 * DIM),
                                            P(d + 8 * DIM), _p(ds), Z, HEADS, ld, ld, ld, DIM, ld, ld, sc, ATTN_BF16, _st()),
                    "rp_attn_bwd_dkdv_ds")
-        ds_matmul(ds, b + 4 * DIM, ld, d, ld, Z)                  # dQ = dS K: one streaming launch (exact fp32 in every mode)
+        ds_matmul(ds, b + 4 * DIM, ld, d, ld, Z)                  # dQ = dS K: one streaming launch
         return dqkv
     if fork is None or not fork.enabled:
         _lib.check(lib.rp_attn_bwd(P(b), P(b + 4 * DIM), P(b + 8 * DIM), _p(do), _p(lse), _p(delta), P(d), P(d + 4 * DIM),
@@ -869,7 +901,7 @@ def emm_backward(qkv, x, t, rlse, clse, df, Z, single=False, cross=False):
     if EMM_BWD_STORE_DS:
         # the query-side pass stores scale*dS (tiled); dk_z = dS_z^T-major x q_{z^1} is one rp_ds_matmul instead of a second pass
         # that recomputes S and dA (68 of its 100 MFMAs per tile)
-        ds = _empty(Z, HEADS, N_TOK, N_TOK, like=qkv)
+        ds = _ds_buffer(Z, qkv)
         _lib.check(lib.rp_emm_grad_ds(_p(qkv), ld, _p(x), _p(w), _p(rlse), _p(clse), _p(rho), _p(gam), _p(dqkv), _p(ds), Z,
                                       HEADS, scale, sg, ATTN_BF16, _st()), "rp_emm_grad_ds")
         # dk_z = dS_z (key-major tiles) x q_{z^1}: one streaming launch

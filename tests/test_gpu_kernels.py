@@ -659,6 +659,41 @@ def test_unsupported_intrinsics_fail_loudly_without_a_sync(ops):
     assert torch.isnan(ops.posenc(origin, 3, origin.device)[..., 3:5]).all()
 
 
+def test_ds_matmul_bf16_tiles(ops):
+    """rp_ds_matmul(ds_bf16 = 1): the stored-dS product of the bf16 configuration (bf16 tiles in the producer's accumulator image,
+    v_mfma_f32_32x32x16_bf16, b rounded to bf16 on chip).  With bf16-representable ds AND b every product is exact: fp32-accumulation
+    accuracy (3e-6 of the maximum) against fp64 on the de-tiled array, for b of the same image and of the partner image; with a
+    general b the stated bf16 tolerance (2e-2); and the fp32-tile launch on the same values agrees."""
+    Z = 4
+    bf = torch.bfloat16
+    tiles = rnd(Z, 3, 576, 576, seed=51).to(bf)                       # the TILED array as a producer would write it
+    r_ = torch.arange(16, device="cuda")[:, None]
+    l_ = torch.arange(64, device="cuda")[None, :]
+    ii = ((r_ & 3) + 8 * (r_ >> 2) + 4 * (l_ >> 5)).reshape(-1)
+    jj = (l_ & 31).expand(16, 64).reshape(-1)
+    dense = torch.empty(Z, 3, 18, 18, 32, 32, device="cuda", dtype=torch.float64)
+    dense[:, :, :, :, ii, jj] = tiles.view(Z, 3, 18, 18, 1024).double()
+    dense = dense.permute(0, 1, 2, 4, 3, 5).reshape(Z, 3, 576, 576)
+    e = {}
+    for name, b in (("exact_operands", rnd(Z * 576, 576, seed=52).to(bf).float()), ("general_b", rnd(Z * 576, 576, seed=53))):
+        for b_xor in (0, 1):
+            out = torch.zeros(Z * 576, 576, device="cuda")
+            ops.ds_matmul(tiles, b.data_ptr() + 4 * 192, 576, out.data_ptr(), 576, Z, b_xor=b_xor)
+            bz = b.view(Z, 576, 576)[:, :, 192:384]
+            if b_xor:
+                bz = bz.view(Z // 2, 2, 576, 192).flip(1).reshape(Z, 576, 192)
+            ref = torch.matmul(dense, bz.reshape(Z, 576, 3, 64).permute(0, 2, 1, 3).double()).permute(0, 2, 1, 3).reshape(Z * 576, 192)
+            e["%s_xor%d" % (name, b_xor)] = rel(out[:, :192], ref)
+            assert float(out[:, 192:].abs().max()) == 0.0             # only the addressed column block is written
+            if name == "exact_operands" and not b_xor:
+                out32 = torch.zeros_like(out)
+                ops.ds_matmul(tiles.float(), b.data_ptr() + 4 * 192, 576, out32.data_ptr(), 576, Z)
+                e["vs_fp32_tiles"] = rel(out[:, :192], out32[:, :192])
+    report("ds_matmul_bf16", **e)
+    assert max(e["exact_operands_xor0"], e["exact_operands_xor1"], e["vs_fp32_tiles"]) < 3e-6, e
+    assert max(e["general_b_xor0"], e["general_b_xor1"]) < 2e-2, e
+
+
 # ------------------------------------------------------------------------------------------------ configs[4]: bf16 MFMA mode
 def test_attention_and_emm_bf16_operand_mode(ops):
     """BASELINE.json configs[4] ("bf16 with MFMA bf16 attention GEMMs"): the `bf16` argument of rp_attn_* / rp_emm_* moves the
@@ -909,6 +944,57 @@ def test_row_resident_linear_with_fused_layernorm(ops, M):
     assert max(worst.values()) < 2e-6, worst
     with pytest.raises(RuntimeError):
         ops.linear_rows(x, rnd(200, 192, seed=1), None)                                    # N % 32 != 0
+
+
+@pytest.mark.parametrize("M", [140, 9216 + 48])
+def test_row_resident_linear_bf16_configuration(ops, M):
+    """rp_linear_rows192 at operand precision 1 (the bf16 configuration: v_mfma_f32_16x16x32_bf16, fp32 accumulate; LayerNorm, bias,
+    GELU, residual in fp32).  With bf16-REPRESENTABLE operands the products are exact, so the result must match fp64 to fp32
+    accumulation accuracy (3e-6 of the maximum); with general operands it is the bf16-operand product (2e-2 relative to fp64, the
+    tolerance of the bf16 rp_gemm test).  bf16 storage: y / pre are the round-to-nearest-even of the fp32 outputs BIT FOR BIT, and a
+    bf16 aux is read exactly."""
+    import torch.nn.functional as F
+    bf = torch.bfloat16
+    prev = ops.GEMM_PRECISION
+    ops.set_gemm_precision(1)
+    try:
+        q = lambda t: t.to(bf).float()
+        x, res = q(rnd(M, 192, seed=31)), rnd(M, 192, seed=32)
+        w, bias = q(rnd(576, 192, seed=33, scale=192 ** -0.5)), 0.1 * rnd(576, seed=34)
+        e = {}
+        e["qkv_exact_operands"] = rel(ops.linear_rows(x, w, bias), F.linear(x.double(), w.double(), bias.double()))
+        wp = q(rnd(192, 192, seed=35, scale=192 ** -0.5))
+        e["proj_exact_operands"] = rel(ops.linear_rows(x, wp, None, residual=res), res.double() + x.double() @ wp.double().t())
+        assert max(e.values()) < 3e-6, e
+        # general operands + fused LayerNorm + GELU: bf16-operand accuracy, LayerNorm outputs still fp32-exact
+        xg = rnd(M, 192, seed=36, scale=2.0)
+        g, b = 1 + 0.1 * rnd(192, seed=37), 0.1 * rnd(192, seed=38)
+        w1, b1 = rnd(768, 192, seed=39, scale=192 ** -0.5), 0.1 * rnd(768, seed=40)
+        h, hpre, xn, mean, rstd = ops.linear_rows(xg, w1, b1, act=1, want_pre=True, ln=(g, b), want_ln_out=True)
+        xnd = F.layer_norm(xg.double(), (192,), g.double(), b.double(), 1e-6)
+        pre_ref = F.linear(xnd, w1.double(), b1.double())
+        f = dict(xn=rel(xn, xnd), mean=rel(mean, xg.double().mean(1)))
+        assert max(f.values()) < 2e-6, f
+        f.update(fc1_pre=rel(hpre, pre_ref), fc1_gelu=rel(h, F.gelu(pre_ref)))
+        assert max(f.values()) < 2e-2, f
+        # bf16 storage of the outputs
+        h16, hpre16, _, _, _ = ops.linear_rows(xg, w1, b1, act=1, want_pre=True, ln=(g, b), want_ln_out=True, out_dtype=bf)
+        assert h16.dtype == bf and torch.equal(h16, h.to(bf)) and torch.equal(hpre16, hpre.to(bf))
+        # input-gradient form with GELU'(aux), aux in bf16, output in bf16, column sums from the fp32 values
+        dy, w2 = rnd(M, 192, seed=41), rnd(192, 768, seed=42, scale=768 ** -0.5)
+        d32, cs32 = ops.linear_dx(dy, w2, dact=1, aux=hpre16.float(), want_colsum=True)
+        d16, cs16 = ops.linear_dx(dy, w2, dact=1, aux=hpre16, want_colsum=True, out_dtype=bf)
+        assert d16.dtype == bf and torch.equal(d16, d32.to(bf)) and torch.equal(cs16, cs32)
+        a = hpre16.double()
+        gp = 0.5 * (1 + torch.erf(a / math.sqrt(2))) + a * torch.exp(-0.5 * a * a) / math.sqrt(2 * math.pi)
+        ref = (dy.double() @ w2.double()) * gp
+        f.update(dx=rel(d32, ref), colsum=rel(cs32, ref.sum(0)))
+        report("linear_rows_bf16_M%d" % M, **e, **f)
+        assert f["dx"] < 2e-2 and f["colsum"] < 2e-2, f
+    finally:
+        ops.set_gemm_precision(prev)
+    with pytest.raises(RuntimeError):
+        ops.linear_rows(rnd(64, 192), rnd(192, 192), None, out_dtype=bf)             # bf16 storage only in the bf16 configuration
 
 
 @pytest.mark.parametrize("M", [140, 1152, 9216 + 48])

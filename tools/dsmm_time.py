@@ -28,6 +28,14 @@ if len(sys.argv) > 1:
     dense = dense.permute(0, 1, 2, 4, 3, 5).reshape(Z, 3, 576, 576)
     ref = torch.matmul(dense.double(), k.double()).permute(0, 2, 1, 3).reshape(Z * 576, 192)
     err = float((dq[:, :192].double() - ref).abs().max() / ref.abs().max())
+    ds16 = ds.to(torch.bfloat16); dq16 = torch.zeros_like(qkv)
+    f16 = lambda: ops.ds_matmul(ds16, qkv.data_ptr() + 4 * 192, 576, dq16.data_ptr(), 576, Z)
+    for _ in range(5): f16()
+    torch.cuda.synchronize(); s.record()
+    for _ in range(50): f16()
+    e.record(); torch.cuda.synchronize()
+    t16 = s.elapsed_time(e) / 50 * 1e3
+    print("bf16 tiles: %8.1f us  %5.2f TB/s  err vs fp64 %.1e" % (t16, Z * 3 * 576 * 576 * 2 / t16 * 1e-6, float((dq16[:, :192].double() - ref).abs().max() / ref.abs().max())))
     print("RP_DSMM=%s  %8.1f us  %6.1f TF  %5.2f TB/s  err %.1e" % (os.environ.get("RP_DSMM"), t, 2.0 * Z * 3 * 576 * 576 * 64 / t * 1e-6, Z * 3 * 576 * 576 * 4 / t * 1e-6, err))
 else:
     for v in ("32", "16"):

@@ -6,34 +6,46 @@
 #include <stdio.h>
 #include <vector>
 
+static int G_ = 0;
 int main(int argc, char** argv) {
-  const int N = argc > 1 ? atoi(argv[1]) : 576, M = 73728, ln = argc > 2 ? atoi(argv[2]) : 1;
+  // usage: rows_probe [N] [ln 0/1] [bf16 config 0/1] [io_bf16 bits] [act+pre 0/1] [M]
+  const int N = argc > 1 ? atoi(argv[1]) : 576, ln = argc > 2 ? atoi(argv[2]) : 1;
+  const int bf = argc > 3 ? atoi(argv[3]) : 0, io = argc > 4 ? atoi(argv[4]) : 0, actpre = argc > 5 ? atoi(argv[5]) : 0;
+  const int M = argc > 6 ? atoi(argv[6]) : 73728;
   float *x, *w, *b, *g, *y; long long* probe;
   hipMalloc(&x, (size_t)M * 192 * 4); hipMalloc(&w, (size_t)N * 192 * 4); hipMalloc(&b, N * 4); hipMalloc(&g, 192 * 4);
   hipMalloc(&y, (size_t)M * N * 4); hipMalloc(&probe, 8 * 64 * NW * 5 * 8);
+  float* ypre = nullptr;
+  if (actpre) hipMalloc(&ypre, (size_t)M * N * 4);
   std::vector<float> h((size_t)M * 192);
   unsigned s = 1u;
   for (auto& v : h) { s = s * 1664525u + 1013904223u; v = ((s >> 8) & 0xffff) / 32768.0f - 1.0f; }
   hipMemcpy(x, h.data(), h.size() * 4, hipMemcpyHostToDevice);
   hipMemcpy(w, h.data(), (size_t)N * 192 * 4, hipMemcpyHostToDevice);
   hipMemcpy(b, h.data(), N * 4, hipMemcpyHostToDevice); hipMemcpy(g, h.data(), 192 * 4, hipMemcpyHostToDevice);
-  RowsP p{x, w, b, nullptr, ln ? g : nullptr, ln ? g : nullptr, y, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, M, N, 1e-6f, 0,
-          N / CH, (M + ROWS - 1) / ROWS, 0, 0, probe};
+  RowsP p{x, w, b, nullptr, ln ? g : nullptr, ln ? g : nullptr, y, ypre, nullptr, nullptr, nullptr, nullptr, nullptr, M, N, 1e-6f, actpre,
+          N / CH, (M + ROWS - 1) / ROWS, 0, 0, io, probe};
   const long long items = (long long)p.tiles * p.nchunk;
-  const int slots = ln ? rows_slots<true>() : rows_slots<false>();
+  const int slots = bf ? (ln ? rows_slots<true, true>() : rows_slots<false, true>()) : (ln ? rows_slots<true, false>() : rows_slots<false, false>());
+  auto go = [&]() {
+    if (bf) {
+      if (ln) hipLaunchKernelGGL((linear_rows_kernel<true, true>), dim3(G_), dim3(NT), 0, 0, p);
+      else hipLaunchKernelGGL((linear_rows_kernel<false, true>), dim3(G_), dim3(NT), 0, 0, p);
+    } else if (ln) hipLaunchKernelGGL((linear_rows_kernel<true, false>), dim3(G_), dim3(NT), 0, 0, p);
+    else hipLaunchKernelGGL((linear_rows_kernel<false, false>), dim3(G_), dim3(NT), 0, 0, p);
+  };
   const int G = (int)(items < slots ? items : slots);
+  G_ = G;
   p.base = (int)(items / G); p.rem = (int)(items % G);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int rep = 0; rep < 3; ++rep) {
     hipMemset(probe, 0, 8 * 64 * NW * 5 * 8);
-    if (ln) hipLaunchKernelGGL(linear_rows_kernel<true>, dim3(G), dim3(NT), 0, 0, p);
-    else hipLaunchKernelGGL(linear_rows_kernel<false>, dim3(G), dim3(NT), 0, 0, p);
+    go();
     hipDeviceSynchronize();
   }
   hipEventRecord(e0, 0);
   for (int rep = 0; rep < 20; ++rep) {
-    if (ln) hipLaunchKernelGGL(linear_rows_kernel<true>, dim3(G), dim3(NT), 0, 0, p);
-    else hipLaunchKernelGGL(linear_rows_kernel<false>, dim3(G), dim3(NT), 0, 0, p);
+    go();
   }
   hipEventRecord(e1, 0); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);

@@ -326,7 +326,13 @@ def _attn_ref(qkv, Z):
     return o, torch.logsumexp(s, -1), s
 
 
-def test_attention_fwd_bwd(ops):
+@pytest.mark.parametrize("waves", [None, "2"])
+def test_attention_fwd_bwd(ops, waves, monkeypatch):
+    """waves=None: the launcher's choice for 4 images (one-wave workgroups, the small-batch form); "2": the two-wave workgroups every
+    full-size batch runs (RP_ATTN_FWD / RP_ATTN_NW are the launchers' tuning overrides)."""
+    if waves:
+        monkeypatch.setenv("RP_ATTN_FWD", waves + "2")
+        monkeypatch.setenv("RP_ATTN_NW", waves)
     Z = 4
     qkv = rnd(Z * 576, 576, seed=1)
     qkv[:, :384] *= 1.7          # sharper softmax

@@ -37,7 +37,7 @@ extern "C" {
  * binding (rel_pose_amd/_lib.py parses both macros and counts the declarations) rejects a stale .so at load time instead of
  * failing later on a missing symbol. */
 #define RP_ABI_VERSION 10
-#define RP_ABI_EXPORTS 65
+#define RP_ABI_EXPORTS 67
 int rp_abi_version(void);
 int rp_abi_export_count(void);
 const char* rp_target_arch(void);
@@ -250,6 +250,15 @@ int rp_tokens_bwd(const float* dx, float* dfeat, int Z, int C, int N, void* stre
  * BASELINE.json configs[4]. */
 int rp_attn_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int Z, int H, int ldq, int ldk,
                 int ldv, int ldo, int q_xor, int k_xor, float scale, int stats_only, int bf16, void* stream);
+/* The dual softmax's two normalisers (vision_transformer.py:205-206) of the EMM score matrix S_z = scale * q_{z^1} k_z^T (queries of the
+ * partner image, keys of image z; q / k point at the first of the H*64 columns, rows (z*576 + i)*ld):
+ *   rlse[z][h][i] = log sum_j exp(S_z[i][j]),   clse[z][h][j] = log sum_i exp(S_z[i][j])      ([Z,H,576] floats each)
+ * as ONE pass over S (bf16 = 0): the rows online, the columns from per-32-row-block (max, sum) partials kept in `workspace`
+ * (rp_emm_stats_workspace_bytes(Z, H) bytes) and combined by a second, tiny launch.  bf16 != 0: two rp_attn_fwd(stats_only) passes
+ * (the reductions would cost that mode more than the second pass saves); workspace may then be NULL.  Z must be even. */
+size_t rp_emm_stats_workspace_bytes(int Z, int H);
+int rp_emm_stats(const float* q, const float* k, float* rlse, float* clse, void* workspace, int Z, int H, int ldq, int ldk,
+                 float scale, int bf16, void* stream);
 /* delta[z][h][i] = sum_e dO[z][i][h*64+e] * O[z][i][h*64+e] */
 int rp_attn_bwd_delta(const float* dout, const float* o, float* delta, int Z, int H, int ld, void* stream);
 /* dq, dk, dv of the above (recompute-based, two deterministic passes) */

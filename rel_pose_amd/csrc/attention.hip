@@ -30,6 +30,7 @@ struct AttnP {
   int H, ldq, ldk, ldv, ldo, q_xor, k_xor;
   float scale;
   int ZH;
+  float* colpart;   // COLS only: [ZH][18 owner blocks][576 loop rows][2] = (max, sum of exp2(. - max)) of each loop row over one owner block
 };
 
 // cooperative global -> register prefetch of a [32][64] tile (32 rows x 16 float4).  No exec-masked guards: when the
@@ -137,7 +138,11 @@ RP_DEV void pack_owner(const float (&reg)[32], bf16x8 (&pk)[4]) {
 //   softmax  : VALU;  LDS reads: V[t] rows 8-15
 //   PV part 1: 16 MFMAs;  tile t+1 VGPRs -> LDS[other];  barrier;  LDS reads: K[t+1] first half
 //   PV part 2: 16 MFMAs (cover the K[t+1] read)
-template <int NW, bool STATS, int WPS, bool BF>
+// COLS (with STATS): the same pass also reduces every score tile along the OTHER index -- per loop row (key) the maximum and the sum of
+// exp2 over the wave's 32 owner rows (DPP row reductions + one cross-row exchange, no LDS) -- and writes these partials; 18 of them
+// per key combine into the column log-sum-exp (colstats_finalize_kernel).  The dual softmax's row and column normalisers then cost
+// ONE pass over S instead of two (rp_emm_stats).
+template <int NW, bool STATS, int WPS, bool BF, bool COLS = false>
 __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_kernel(AttnP p) {
   constexpr int NT = NW * 64;
   constexpr int NPF = (512 + NT - 1) / NT;
@@ -213,6 +218,17 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_kernel(AttnP p) {
       s = mfma32(kb2[c].z, qreg[16 + 4 * c + 2], s);
       s = mfma32(kb2[c].w, qreg[16 + 4 * c + 3], s);
     }
+    }
+    if (COLS) {
+      float2* cp = reinterpret_cast<float2*>(p.colpart) + ((long long)zh * NTILE + (q0 >> 5)) * NTOK + t * 32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float cm = row16_max(s[r]);
+        cm = fmaxf(cm, __shfl_xor(cm, 16, 64));                    // the other DPP row of this 32-lane half (same hi = same loop row)
+        float cl = row16_sum(fast_exp2(s[r] - cm));
+        cl += __shfl_xor(cl, 16, 64);
+        cp[acc_row(r, hi)] = make_float2(cm, cl);                  // every lane of the half holds the pair: one 8-byte line write, no exec-masked block
+      }
     }
     float mx = s[0];
 #pragma unroll
@@ -726,7 +742,55 @@ __global__ __launch_bounds__(NW * 64, 3) void ds_matmul16_kernel(DsMmP p) {
   }
 }
 
+// clse[zh][j] = ln sum_i exp(S[i][j]) from the 18 per-owner-block partials (log2 units: max m_b, l_b = sum exp2(s - m_b))
+__global__ __launch_bounds__(256) void colstats_finalize_kernel(const float2* part, float* clse, long long total) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const long long zh = idx / NTOK;
+  const int j = (int)(idx % NTOK);
+  const float2* pp = part + zh * NTILE * NTOK + j;
+  float2 v[NTILE];
+  float M = -INFINITY;
+#pragma unroll
+  for (int b = 0; b < NTILE; ++b) {
+    v[b] = pp[(long long)b * NTOK];
+    M = fmaxf(M, v[b].x);
+  }
+  float L = 0.f;
+#pragma unroll
+  for (int b = 0; b < NTILE; ++b) L += v[b].y * fast_exp2(v[b].x - M);
+  clse[idx] = M * RP_LN2 + logf(L);
+}
+
 }  // namespace
+
+// Row and column log-sum-exp of the EMM's score matrix S_z = scale q_{z^1} k_z^T (vision_transformer.py:205-206, the dual softmax's
+// two normalisers): rlse[z][h][i] over keys j, clse[z][h][j] over queries i.  fp32: ONE pass over S (rows online, columns from per-block
+// partials in `workspace`, rp_emm_stats_workspace_bytes) + a finalize launch; bf16 != 0: the two stats_only passes of rp_attn_fwd.
+extern "C" size_t rp_emm_stats_workspace_bytes(int Z, int H) { return (size_t)Z * H * NTILE * NTOK * 2 * sizeof(float); }
+extern "C" int rp_emm_stats(const float* q, const float* k, float* rlse, float* clse, void* workspace, int Z, int H, int ldq, int ldk,
+                            float scale, int bf16, void* stream) {
+  if (Z <= 0 || H <= 0 || (Z & 1) || !q || !k || !rlse || !clse) return RP_EBADSHAPE;
+  if ((ldq | ldk) & 3) return RP_EALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 g3(xcd_grid(NTILE / 3, Z * H));
+  if (bf16) {
+    AttnP a{q, k, nullptr, nullptr, rlse, H, ldq, ldk, 4, 4, 1, 0, scale, Z * H, nullptr};
+    hipLaunchKernelGGL((attn_fwd_kernel<3, true, 2, true>), g3, dim3(192), 0, st, a);
+    AttnP b{k, q, nullptr, nullptr, clse, H, ldk, ldq, 4, 4, 0, 1, scale, Z * H, nullptr};
+    hipLaunchKernelGGL((attn_fwd_kernel<3, true, 2, true>), g3, dim3(192), 0, st, b);
+    RP_CHECK_LAUNCH();
+    return RP_OK;
+  }
+  if (!workspace) return RP_EBADSHAPE;
+  AttnP a{q, k, nullptr, nullptr, rlse, H, ldq, ldk, 4, 4, 1, 0, scale, Z * H, (float*)workspace};
+  hipLaunchKernelGGL((attn_fwd_kernel<3, true, 2, false, true>), g3, dim3(192), 0, st, a);
+  RP_CHECK_LAUNCH();
+  const long long total = (long long)Z * H * NTOK;
+  hipLaunchKernelGGL(colstats_finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float2*)workspace, clse, total);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
 
 extern "C" int rp_attn_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int Z, int H, int ldq,
                            int ldk, int ldv, int ldo, int q_xor, int k_xor, float scale, int stats_only, int bf16, void* stream) {
@@ -735,7 +799,7 @@ extern "C" int rp_attn_fwd(const float* q, const float* k, const float* v, float
   if ((q_xor || k_xor) && (Z & 1)) return RP_EBADSHAPE;
   if ((ldq | ldk) & 3) return RP_EALIGN;
   if (!stats_only && ((ldv | ldo) & 3)) return RP_EALIGN;
-  AttnP p{q, k, v, o, lse, H, ldq, ldk, ldv, ldo, q_xor, k_xor, scale, Z * H};
+  AttnP p{q, k, v, o, lse, H, ldq, ldk, ldv, ldo, q_xor, k_xor, scale, Z * H, nullptr};
   hipStream_t st = (hipStream_t)stream;
   const char* ov = getenv("RP_ATTN_FWD");   // tuning aid: "<NW><WPS>", e.g. "32"
   // few problems (small batches): one-wave workgroups -- with <= two 2-wave workgroups per CU every workgroup's 18-tile

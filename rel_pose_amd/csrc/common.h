@@ -114,6 +114,14 @@ RP_DEV float row16_sum(float v) {
   return v;
 }
 
+RP_DEV float row16_max(float v) {
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)));
+  return v;
+}
+
 // 4 x 4 transpose across the four lanes of a DPP quad: before, lane q (= lane & 3) holds a[0..3]; after, it holds b[e] = (a of lane e)[q].
 // Two 2 x 2 stages (quad_perm [1,0,3,2], then [2,3,0,1]), 16 VALU operations, no LDS.  Used to turn four 4-byte-per-lane stores of an
 // accumulator image into one 16-byte-per-lane store (the stored-dS tiles): lanes 4Q..4Q+3 each end up with four CONSECUTIVE lanes' values

@@ -825,12 +825,32 @@ def emm_build_x(qkv, pos, Z):
     return x
 
 
+EMM_STATS_ONE_PASS = os.environ.get("RP_EMM_STATS_ONE_PASS", "1") == "1"      # A/B aid
+_stats_ws = {}
+
+
 def emm_stats(qkv, Z, single=False):
-    """row / column log-sum-exp of S_z = scale q_{z^1} k_z^T (single softmax: rows only)."""
-    _, rlse = attn_fwd(qkv, Z, stats_only=True, q_off=0, k_off=DIM, q_xor=1, k_xor=0)
-    if single:
-        return rlse, rlse
-    _, clse = attn_fwd(qkv, Z, stats_only=True, q_off=DIM, k_off=0, q_xor=0, k_xor=1)
+    """row / column log-sum-exp of S_z = scale q_{z^1} k_z^T (single softmax: rows only).  Both normalisers come from ONE pass over S
+    (rp_emm_stats; two rp_attn_fwd(stats_only) passes in the bf16 configuration)."""
+    if single or not EMM_STATS_ONE_PASS:
+        _, rlse = attn_fwd(qkv, Z, stats_only=True, q_off=0, k_off=DIM, q_xor=1, k_xor=0)
+        if single:
+            return rlse, rlse
+        _, clse = attn_fwd(qkv, Z, stats_only=True, q_off=DIM, k_off=0, q_xor=0, k_xor=1)
+        return rlse, clse
+    lib = _lib.load()
+    _chk(qkv)
+    ld = qkv.shape[1]
+    rlse, clse = _empty(Z, HEADS, N_TOK, like=qkv), _empty(Z, HEADS, N_TOK, like=qkv)
+    ws = None
+    if not ATTN_BF16:
+        key = (qkv.device, Z)
+        ws = _stats_ws.get(key)
+        if ws is None:
+            ws = _stats_ws[key] = torch.empty(lib.rp_emm_stats_workspace_bytes(Z, HEADS) // 4, device=qkv.device, dtype=torch.float32)
+    b = qkv.data_ptr()
+    _lib.check(lib.rp_emm_stats(ctypes.c_void_p(b), ctypes.c_void_p(b + 4 * DIM), _p(rlse), _p(clse), _p(ws), Z, HEADS, ld, ld,
+                                (DIM // HEADS) ** -0.5, ATTN_BF16, _st()), "rp_emm_stats")
     return rlse, clse
 
 

@@ -390,6 +390,21 @@ def test_attention_stats_partner(ops):
     s = (qp @ k.transpose(-1, -2)) * 0.125                  # S_z[i][j]
     assert rel(rlse, torch.logsumexp(s, -1)) < 2e-6
     assert rel(clse, torch.logsumexp(s, -2)) < 2e-6
+    # rp_emm_stats (one pass over S: rows online, columns from per-block partials) against the two stats_only passes it replaces
+    keep, ops.EMM_STATS_ONE_PASS = ops.EMM_STATS_ONE_PASS, False
+    try:
+        r2, c2 = ops.emm_stats(qkv, Z)
+    finally:
+        ops.EMM_STATS_ONE_PASS = keep
+    assert ops.EMM_STATS_ONE_PASS and torch.equal(rlse, r2) and rel(clse, c2) < 1e-6
+    qs = qkv.clone()
+    qs[:576, :64] *= 40.0                                   # one head of one image with scores of magnitude ~1e3: the per-block maxima matter
+    r3, c3 = ops.emm_stats(qs, Z)
+    t3 = qs.double().view(Z, 576, 3, 3, 64).permute(2, 0, 3, 1, 4)
+    s3 = (t3[0][[1, 0, 3, 2]] @ t3[1].transpose(-1, -2)) * 0.125
+    assert rel(r3, torch.logsumexp(s3, -1)) < 2e-6 and rel(c3, torch.logsumexp(s3, -2)) < 2e-6
+    with pytest.raises(RuntimeError):
+        ops.emm_stats(qkv[:3 * 576].contiguous(), 3)          # odd image count has no pairs
 
 
 # ------------------------------------------------------------------------------------------------ EMM

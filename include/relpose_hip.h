@@ -371,11 +371,15 @@ int rp_mlp_fused_fwd(const float* x, const float* gamma, const float* beta, cons
 /* Backward-data of the same MLP (training): dhp [M,hidden] = (dy W2) o GELU'(hpre) -- the gradient of fc1's pre-activation, which
  * fc1's weight gradient needs -- and dxn [M,dim] = dhp W1, the gradient of the LayerNorm output, as one kernel (dh never exists).
  * w2t = W2^T [hidden,dim] and w1t = W1^T [dim,hidden], contiguous.  colpart [ceil(M / rp_mlp_fused_bwd_tile_rows()), hidden]
- * receives the column sums of dhp per row tile (their sum is the fc1 bias gradient). */
+ * receives the column sums of dhp per row tile (their sum is the fc1 bias gradient).
+ * precision: 0 exact fp32 MFMA.  1 = the bf16 configuration (v_mfma_f32_16x16x32_bf16, fp32 accumulate; GELU', column sums and dxn fp32):
+ * w2t and w1t then point to BF16 copies, w1t with the 32 hidden units of every chunk c stored in the order a lane's accumulators form the
+ * MFMA operand: position 8 q + e of chunk c holds unit 32 c + 4 q + e (e < 4) or 32 c + 16 + 4 q + e - 4 (e >= 4), q = 0..3.  io_bf16
+ * (precision 1 only): bit 1 = dhp is written as bf16, bit 2 = hpre holds bf16. */
 size_t rp_mlp_fused_bwd_workspace_bytes(int M);
 int rp_mlp_fused_bwd_tile_rows(void);
 int rp_mlp_fused_bwd(const float* dy, const float* hpre, const float* w2t, const float* w1t, float* dhp, float* dxn, float* colpart,
-                     void* workspace, int M, int dim, int hidden, void* stream);
+                     void* workspace, int M, int dim, int hidden, int precision, int io_bf16, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Training-time augmentation of a resident batch (RGBDAugmentor, src/data_readers/augmentation.py:7-37):

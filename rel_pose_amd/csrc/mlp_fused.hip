@@ -32,6 +32,7 @@ namespace {
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 RP_DEV f32x4v mfma16(float a, float b, f32x4v c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+RP_DEV f32x4v mfma16bf(bf16x8 a, bf16x8 b, f32x4v c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 
 constexpr int C = 192, HID = 768, CH = 32, NCHUNK = HID / CH;
 constexpr int W1T = CH * C, W2T = C * CH;                      // floats per staged tile (6144 each = 24 KB)
@@ -46,6 +47,7 @@ struct MlpP {
   int M;
   float eps;
   int tiles, base, rem, P;
+  int io_bf16;       // BF only: bit 1 = dhp is written as bf16, bit 2 = hpre holds bf16
 };
 
 RP_DEV void item_range(const MlpP& p, int b, int& start, int& count) {
@@ -58,13 +60,21 @@ RP_DEV void item_range(const MlpP& p, int b, int& start, int& count) {
 // which is the SAME two chained products with the transposed weights in the two roles (p.w1 = W2^T [768,192], p.w2 = W1^T
 // [192,768]), GELU replaced by the multiplication with GELU'(h_pre) read from HBM in accumulator layout, no LayerNorm on the way
 // in and no bias / residual on the way out.  Also emits the column sums of dhp per (row tile, chunk) -- the fc1 bias gradient.
-template <int NW, int WPS, int MODE>
+//
+// BF (MODE 1 only; the bf16 configuration): both products on v_mfma_f32_16x16x32_bf16, fp32 accumulate.  The weights arrive as bf16
+// copies (12 KB per staged tile): GEMM1 exactly as linear_rows.hip's bf16 form (a lane's k-set of block u is 32 u + 8 q .. + 7; the dy
+// rows are rounded to bf16 once per row tile); GEMM2 contracts the chunk's 32 units in ONE MFMA per 16-column block: its B operand is
+// pack8(h0, h1) -- k-slot 8 q + e <-> unit 4 q + e (e < 4) / 16 + 4 q + e - 4 -- so the caller stores the second weight with the units
+// of every 32-chunk in THAT order and a lane's A operand is one ds_read_b128.  GELU', the column sums and the stream-K partials stay fp32.
+template <int NW, int WPS, int MODE, bool BF = false>
 __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
   constexpr int NT = NW * 64, ROWS = NW * 16;
-  constexpr int DMA = (W1T / 4) / NT;                           // 16-byte chunks per thread per tile (3 for NW = 8)
-  static_assert((W1T / 4) % NT == 0, "tile must be a whole number of DMA rounds");
-  __shared__ __attribute__((aligned(16))) float w1t[W1T];
-  __shared__ __attribute__((aligned(16))) float w2t[W2T];
+  constexpr int TILE_FL = BF ? W1T / 2 : W1T;                   // floats per staged weight tile (bf16 weights: half)
+  constexpr int DMA = (TILE_FL / 4) / NT;                       // 16-byte chunks per thread per tile (3 for NW = 8)
+  static_assert((TILE_FL / 4) % NT == 0, "tile must be a whole number of DMA rounds");
+  static_assert(!BF || MODE == 1, "the bf16 form exists for the backward-data chain only");
+  __shared__ __attribute__((aligned(16))) float w1t[TILE_FL];
+  __shared__ __attribute__((aligned(16))) float w2t[TILE_FL];
   // MODE 0: gamma | beta of the LayerNorm (b1 is read from L2: staging all of it here would cost the third resident workgroup per
   // CU, measured with tools/lab/rows_probe); MODE 1: per-wave column sums of a chunk
   __shared__ __attribute__((aligned(16))) float b1s[MODE == 0 ? 2 * C : NW * CH];
@@ -82,19 +92,26 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
 #pragma unroll
   for (int r = 0; r < DMA; ++r) {
     const int pp = r * NT + tid;
-    const int row1 = pp / 48, ch1 = (pp % 48) ^ (row1 & 15);
-    off1[r] = (unsigned)((row1 * C + ch1 * 4) * 4);
-    const int row2 = pp >> 3, ch2 = (pp & 7) ^ ((row2 >> 1) & 7);
-    off2[r] = (unsigned)((row2 * HID + ch2 * 4) * 4);
+    if (BF) {
+      const int row1 = pp / 24, sl1 = pp % 24, ch1 = (sl1 & ~7) | ((sl1 & 7) ^ ((row1 >> 1) & 7));
+      off1[r] = (unsigned)(row1 * C * 2 + ch1 * 16);
+      const int row2 = pp >> 2, ch2 = (pp & 3) ^ ((row2 >> 2) & 3);
+      off2[r] = (unsigned)(row2 * HID * 2 + ch2 * 16);
+    } else {
+      const int row1 = pp / 48, ch1 = (pp % 48) ^ (row1 & 15);
+      off1[r] = (unsigned)((row1 * C + ch1 * 4) * 4);
+      const int row2 = pp >> 3, ch2 = (pp & 7) ^ ((row2 >> 1) & 7);
+      off2[r] = (unsigned)((row2 * HID + ch2 * 4) * 4);
+    }
   }
   const unsigned l1 = lds_byte_addr(w1t) + wave * 1024, l2 = lds_byte_addr(w2t) + wave * 1024;
   auto issue_w1 = [&](int c) {
-    const float* src = uniform_ptr(p.w1 + (long long)c * CH * C);
+    const float* src = uniform_ptr(p.w1 + (long long)c * CH * (BF ? C / 2 : C));
 #pragma unroll
     for (int r = 0; r < DMA; ++r) glds16(src, off1[r], l1 + r * NT * 16);
   };
   auto issue_w2 = [&](int c) {
-    const float* src = uniform_ptr(p.w2 + c * CH);
+    const float* src = uniform_ptr(p.w2 + c * (BF ? CH / 2 : CH));
 #pragma unroll
     for (int r = 0; r < DMA; ++r) glds16(src, off2[r], l2 + r * NT * 16);
   };
@@ -108,12 +125,13 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
     const int tile = it / NCHUNK, c0 = it % NCHUNK, c1 = min(NCHUNK, c0 + end - it);
     const int row = tile * ROWS + wave * 16 + j;
     const bool live = row < p.M;
-    const float* xr = p.x + (long long)min(row, p.M - 1) * C + 4 * q;
-    // ---- the wave's 16 rows (MODE 0: layer-normalised) straight into the B-operand registers (lane (j, q): columns 16t + 4q + 0..3)
+    const float* xr = p.x + (long long)min(row, p.M - 1) * C + (BF ? 8 * q : 4 * q);
+    // ---- the wave's 16 rows (MODE 0: layer-normalised) straight into the B-operand registers (lane (j, q): columns 16t + 4q + 0..3;
+    // BF: columns 32 (t >> 1) + 8 q + 4 (t & 1) + 0..3, i.e. 8 consecutive per 32-wide k block)
     float xn[48];
 #pragma unroll
     for (int t = 0; t < 12; ++t) {
-      const float4 v = ld4(xr + 16 * t);
+      const float4 v = ld4(xr + (BF ? 32 * (t >> 1) + 4 * (t & 1) : 16 * t));
       xn[4 * t] = v.x; xn[4 * t + 1] = v.y; xn[4 * t + 2] = v.z; xn[4 * t + 3] = v.w;
     }
     if (MODE == 0) {
@@ -144,6 +162,13 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
     f32x4v acc[12];
 #pragma unroll
     for (int ob = 0; ob < 12; ++ob) acc[ob] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    bf16x8 xb[BF ? 6 : 1];
+    if constexpr (BF) {
+#pragma unroll
+      for (int u = 0; u < 6; ++u) xb[u] = pack8(xn + 8 * u);
+    }
+    const bool dhp_bf = BF && (p.io_bf16 & 2), hpre_bf = BF && (p.io_bf16 & 4);
+    const int bfo = (q & 1) ? 16 + 4 * (q - 1) - 4 * q : 0;      // element offset of a lane's 8 consecutive units in a bf16 row (st/ld_bf16x8)
 
     for (int c = c0; c < c1; ++c, ++it) {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // W1(c) landed everywhere; W2 tile free
@@ -155,12 +180,28 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
         g1p = ld4(p.b1 + c * CH + 16 + 4 * q);
       }
       if (MODE == 1) {
-        g0p = ld4(p.hpre + ho);
-        g1p = ld4(p.hpre + ho + 16);
+        if (hpre_bf) {
+          ld_bf16x8(reinterpret_cast<const unsigned short*>(p.hpre) + ho + bfo, g0p, g1p, q);
+        } else {
+          g0p = ld4(p.hpre + ho);
+          g1p = ld4(p.hpre + ho + 16);
+        }
         asm volatile("" ::: "memory");            // issue here, under GEMM1 -- not where the values are first used
       }
       // ---- GEMM1: two 16-unit blocks, K = 192
       f32x4v h0 = {0.f, 0.f, 0.f, 0.f}, h1 = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (BF) {
+        const float* w0 = w1t + j * (C / 2);
+        const float* w1r = w0 + 16 * (C / 2);
+        const int key = (j >> 1) & 7;
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+          const int sl = 4 * u + q, ch = ((sl & ~7) | ((sl & 7) ^ key)) * 4;
+          const float4 l = ld4(w0 + ch), m = ld4(w1r + ch);
+          h0 = mfma16bf(__builtin_bit_cast(bf16x8, l), xb[u], h0);
+          h1 = mfma16bf(__builtin_bit_cast(bf16x8, m), xb[u], h1);
+        }
+      } else {
       const float* a0p = w1t + j * C;
       const float* a1p = w1t + (16 + j) * C;
       float4 a0 = ld4(a0p + ((q ^ j) * 4)), a1 = ld4(a1p + ((q ^ j) * 4));
@@ -185,6 +226,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
         a1 = n1;
         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);          // the two ds_read_b128 of the NEXT group first ...
         __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);          // ... then this group's eight MFMAs
+      }
       }
       if (MODE == 0) {
         const float4 ba = g0p, bb = g1p;
@@ -218,8 +260,13 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
       if (it + 1 < end) issue_w1((it + 1) % NCHUNK);
       if (MODE == 1) {          // after the DMA issue: these stores have the whole of GEMM2 to retire before the next vmcnt(0)
         if (live) {
-          st4(p.dhp + ho, make_float4(h0[0], h0[1], h0[2], h0[3]));
-          st4(p.dhp + ho + 16, make_float4(h1[0], h1[1], h1[2], h1[3]));
+          if (dhp_bf) {
+            st_bf16x8(reinterpret_cast<unsigned short*>(p.dhp) + ho + bfo, make_float4(h0[0], h0[1], h0[2], h0[3]),
+                      make_float4(h1[0], h1[1], h1[2], h1[3]), q);
+          } else {
+            st4(p.dhp + ho, make_float4(h0[0], h0[1], h0[2], h0[3]));
+            st4(p.dhp + ho + 16, make_float4(h1[0], h1[1], h1[2], h1[3]));
+          }
         }
         if (tid < CH) {
           float sum = 0.f;
@@ -229,6 +276,15 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
         }
       }
       // ---- GEMM2: 12 column blocks of 16, K = the 32 units of this chunk
+      if constexpr (BF) {
+        const bf16x8 hb = pack8(h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]);
+#pragma unroll
+        for (int ob = 0; ob < 12; ++ob) {
+          const int r2 = 16 * ob + j;
+          const float4 a = ld4(w2t + r2 * (CH / 2) + ((q ^ ((r2 >> 2) & 3)) * 4));
+          acc[ob] = mfma16bf(__builtin_bit_cast(bf16x8, a), hb, acc[ob]);
+        }
+      } else {
       auto w2frag = [&](int ob, float4& f0, float4& f1) {
         const int r2 = 16 * ob + j, sw = (r2 >> 1) & 7;
         const float* ap = w2t + r2 * CH;
@@ -254,6 +310,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
         g1 = n1;
         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+      }
       }
     }
     // ---- epilogue: lane (j, q) holds Y[row j][16 ob + 4q + 0..3]
@@ -313,7 +370,7 @@ __global__ __launch_bounds__(256) void mlp_fixup_kernel(MlpP p, int G) {
 }
 
 // NW waves per workgroup (16 rows each), WPS waves per SIMD the register allocation is held to
-template <int NW, int WPS, int MODE>
+template <int NW, int WPS, int MODE, bool BF = false>
 struct Variant {
   static constexpr int ROWS = NW * 16;
   static int grid(int tiles) {
@@ -322,7 +379,7 @@ struct Variant {
       int dev = 0, cus = 256, per_cu = 1;
       (void)hipGetDevice(&dev);
       (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mlp_fused_kernel<NW, WPS, MODE>, NW * 64, 0);
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mlp_fused_kernel<NW, WPS, MODE, BF>, NW * 64, 0);
       slots = cus * (per_cu > 0 ? per_cu : 1);
     }
     const long long items = (long long)tiles * NCHUNK;
@@ -344,7 +401,7 @@ struct Variant {
   }
   static int launch(MlpP p, hipStream_t st) {
     const int G = partition(p);
-    hipLaunchKernelGGL((mlp_fused_kernel<NW, WPS, MODE>), dim3(G), dim3(NW * 64), 0, st, p);
+    hipLaunchKernelGGL((mlp_fused_kernel<NW, WPS, MODE, BF>), dim3(G), dim3(NW * 64), 0, st, p);
     RP_CHECK_LAUNCH();
     if (p.rem != 0 || p.base % NCHUNK != 0) {                     // some tile is shared between workgroups
       hipLaunchKernelGGL((mlp_fixup_kernel<ROWS, MODE>), dim3((ROWS * C / 4 + 255) / 256, p.tiles), dim3(256), 0, st, p, G);
@@ -379,7 +436,7 @@ extern "C" int rp_mlp_fused_fwd(const float* x, const float* gamma, const float*
                                 void* stream) {
   if (M <= 0 || dim != C || hidden != HID || !x || !gamma || !beta || !w1 || !b1 || !w2 || !b2 || !y || !workspace)
     return RP_EBADSHAPE;
-  MlpP p{x, gamma, beta, w1, b1, w2, b2, y, nullptr, nullptr, nullptr, (float*)workspace, M, eps, 0, 0, 0, 0};
+  MlpP p{x, gamma, beta, w1, b1, w2, b2, y, nullptr, nullptr, nullptr, (float*)workspace, M, eps, 0, 0, 0, 0, 0};
   hipStream_t st = (hipStream_t)stream;
   switch (mlp_variant()) {
     case 1: return Variant<8, 2, 0>::launch(p, st);
@@ -406,9 +463,11 @@ extern "C" size_t rp_mlp_fused_bwd_workspace_bytes(int M) {
 }
 extern "C" int rp_mlp_fused_bwd_tile_rows(void) { return mlp_bwd_variant() == 1 ? Variant<8, 2, 1>::ROWS : Variant<12, 3, 1>::ROWS; }
 extern "C" int rp_mlp_fused_bwd(const float* dy, const float* hpre, const float* w2t, const float* w1t, float* dhp, float* dxn,
-                                float* colpart, void* workspace, int M, int dim, int hidden, void* stream) {
+                                float* colpart, void* workspace, int M, int dim, int hidden, int precision, int io_bf16, void* stream) {
   if (M <= 0 || dim != C || hidden != HID || !dy || !hpre || !w2t || !w1t || !dhp || !dxn || !colpart || !workspace)
     return RP_EBADSHAPE;
-  MlpP p{dy, nullptr, nullptr, w2t, nullptr, w1t, nullptr, dxn, hpre, dhp, colpart, (float*)workspace, M, 0.f, 0, 0, 0, 0};
+  if ((precision != 0 && precision != 1) || (io_bf16 && (precision != 1 || (io_bf16 & ~6)))) return RP_EUNSUPPORTED;
+  MlpP p{dy, nullptr, nullptr, w2t, nullptr, w1t, nullptr, dxn, hpre, dhp, colpart, (float*)workspace, M, 0.f, 0, 0, 0, 0, io_bf16};
+  if (precision == 1) return Variant<12, 3, 1, true>::launch(p, (hipStream_t)stream);      // (same 192-row tiles: same workspace / tile rows)
   return mlp_bwd_variant() == 1 ? Variant<8, 2, 1>::launch(p, (hipStream_t)stream) : Variant<12, 3, 1>::launch(p, (hipStream_t)stream);
 }

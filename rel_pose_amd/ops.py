@@ -1023,14 +1023,54 @@ def mlp_fused(x2d, gamma, beta, w1, b1, w2, b2, eps=LN_EPS):
 FUSE_MLP_BWD = os.environ.get("RP_FUSE_MLP_BWD", "1") != "0"
 
 
-def mlp_fused_bwd(dy, hpre, w1, w2):
+_UNIT_PERM = {}
+
+
+def _mlp_unit_perm(device):
+    """column order of rp_mlp_fused_bwd's bf16 second weight: position 8q+e of every 32-unit chunk holds unit 4q+e (e<4) / 16+4q+e-4"""
+    pm = _UNIT_PERM.get(device)
+    if pm is None:
+        pos = torch.arange(4 * DIM, device=device)
+        c, r = pos // 32, pos % 32
+        q, e = r // 8, r % 8
+        pm = _UNIT_PERM[device] = c * 32 + torch.where(e < 4, 4 * q + e, 16 + 4 * q + e - 4)
+    return pm
+
+
+def _mlp_bwd_bf16_weights(w1, w2):
+    """(bf16 W2^T [768,192], bf16 W1^T [192,768] with the chunk-permuted unit order), cached on w1 / w2 until they change"""
+    w2b = bf16_weight(transposed(w2))
+    c = getattr(w1, "_rp_bp", None)
+    if c is not None and c[0] == w1._version and c[1] == w1.data_ptr() and c[2] == _PAD_GEN:
+        return w2b, c[3]
+    w1p = w1.detach().t().index_select(1, _mlp_unit_perm(w1.device)).to(torch.bfloat16).contiguous()
+    if not torch.cuda.is_current_stream_capturing():
+        try:
+            w1._rp_bp = (w1._version, w1.data_ptr(), _PAD_GEN, w1p)
+        except AttributeError:
+            pass
+    return w2b, w1p
+
+
+def mlp_fused_bwd(dy, hpre, w1, w2, out_dtype=None):
     """(dhp, dxn, db1_partials) of the MLP backward-data chain (rp_mlp_fused_bwd): dhp = (dy W2) o GELU'(hpre), dxn = dhp W1.
-    w1 [768,192], w2 [192,768] as stored by nn.Linear (transposed here: 2 x 590 KB); db1_partials [tiles,768] column-sums to db1."""
+    w1 [768,192], w2 [192,768] as stored by nn.Linear (transposed here: 2 x 590 KB); db1_partials [tiles,768] column-sums to db1.
+    At operand precision 1 (the bf16 configuration) the products run on the bf16 MFMA from bf16 weight copies; hpre may then be a bf16
+    tensor and out_dtype=torch.bfloat16 stores dhp as bf16."""
     lib = _lib.load()
-    _chk(dy, hpre)
+    _chk(dy)
+    _chk_act(hpre)
     M = dy.shape[0]
-    w2t, w1t = transposed(w2), transposed(w1)
-    dhp, dxn = torch.empty_like(hpre), torch.empty_like(dy)
+    bf = GEMM_PRECISION == 1
+    io = (2 if out_dtype == torch.bfloat16 else 0) | (4 if hpre.dtype == torch.bfloat16 else 0)
+    if io and not bf:
+        raise RuntimeError("bf16-stored operands need operand precision 1 (the bf16 configuration)")
+    if bf:
+        w2t, w1t = _mlp_bwd_bf16_weights(w1, w2)
+    else:
+        w2t, w1t = transposed(w2), transposed(w1)
+    dhp = torch.empty(hpre.shape, device=dy.device, dtype=out_dtype or torch.float32)
+    dxn = torch.empty_like(dy)
     tiles = -(-M // lib.rp_mlp_fused_bwd_tile_rows())
     colpart = _empty(tiles, hpre.shape[1], like=dy)
     key = (dy.device, M, "bwd", torch.cuda.current_stream(dy.device).cuda_stream)
@@ -1038,7 +1078,7 @@ def mlp_fused_bwd(dy, hpre, w1, w2):
     if ws is None:
         ws = _mlp_ws[key] = torch.empty(max(1, lib.rp_mlp_fused_bwd_workspace_bytes(M)) // 4 + 1, device=dy.device, dtype=torch.float32)
     _lib.check(lib.rp_mlp_fused_bwd(_p(dy), _p(hpre), _p(w2t), _p(w1t), _p(dhp), _p(dxn), _p(colpart), _p(ws), M, dy.shape[1],
-                                    hpre.shape[1], _st()), "rp_mlp_fused_bwd")
+                                    hpre.shape[1], 1 if bf else 0, io, _st()), "rp_mlp_fused_bwd")
     return dhp, dxn, colpart
 
 
@@ -1083,10 +1123,10 @@ def _mlp_bwd(fork, dy, xn, h, hpre, w1, w2, want_db2=True, ln=None):
         dw2, db2 = _param_grads(fork, dy, h)
     else:                     # the caller gets colsum(dy) for free from the LayerNorm backward that adds dy
         dw2, db2 = fork.on_side(lambda: linear_dw(dy, h)), None
-    if (FUSE_MLP_BWD and GEMM_PRECISION == 0 and dy.shape[1] == DIM and tuple(w1.shape) == (4 * DIM, DIM)
-            and tuple(w2.shape) == (DIM, 4 * DIM)):
+    if (FUSE_MLP_BWD and GEMM_PRECISION in (0, 1) and dy.shape[1] == DIM and tuple(w1.shape) == (4 * DIM, DIM)
+            and tuple(w2.shape) == (DIM, 4 * DIM) and dy.dtype == torch.float32):
         # both input-gradient products as one kernel (dh stays on chip); fc1 bias gradient from its per-tile column sums
-        dh, dxn, part = mlp_fused_bwd(dy, hpre, w1, w2)
+        dh, dxn, part = mlp_fused_bwd(dy, hpre, w1, w2, out_dtype=torch.bfloat16 if hpre.dtype == torch.bfloat16 else None)
         db1 = colsum(part)
         fork.sync_side()
         dw1 = fork.on_side(lambda: linear_dw(dh, xn))

@@ -1039,6 +1039,41 @@ def test_fused_mlp_backward_data_kernel(ops, M):
     assert torch.equal(d2, dhp) and torch.equal(x2, dxn) and torch.equal(p2, part)        # deterministic
 
 
+@pytest.mark.parametrize("M", [140, 9216 + 48])
+def test_fused_mlp_backward_bf16_configuration(ops, M):
+    """rp_mlp_fused_bwd at operand precision 1 (v_mfma_f32_16x16x32_bf16 from bf16 weight copies, the second one in the kernel's
+    chunk-permuted unit order).  With bf16-representable dy and weights the FIRST product is exact: dhp must match fp64 to fp32
+    accuracy (3e-6); dxn contracts the bf16-rounded dhp -- against the fp64 product of exactly those rounded values also 3e-6, and
+    within the stated bf16 tolerance (2e-2) of the unrounded chain.  bf16 storage: a bf16 hpre is read exactly and a bf16 dhp is the
+    round-to-nearest-even of the fp32 one BIT FOR BIT; column sums come from the fp32 values."""
+    import torch.nn.functional as F
+    bf = torch.bfloat16
+    q = lambda t: t.to(bf).float()
+    w1, b1 = q(rnd(768, 192, seed=4, scale=192 ** -0.5)), 0.1 * rnd(768, seed=5)
+    w2 = q(rnd(192, 768, seed=6, scale=768 ** -0.5))
+    dy = q(rnd(M, 192, seed=9))
+    hp = q(rnd(M, 768, seed=8, scale=1.5))                     # bf16-representable pre-activation: the bf16-stored run reads the same values
+    a = hp.double()
+    gp = 0.5 * (1 + torch.erf(a / math.sqrt(2))) + a * torch.exp(-0.5 * a * a) / math.sqrt(2 * math.pi)
+    dhp_ref = (dy.double() @ w2.double()) * gp
+    prev = ops.GEMM_PRECISION
+    ops.set_gemm_precision(1)
+    try:
+        dhp, dxn, part = ops.mlp_fused_bwd(dy, hp, w1, w2)
+        e = dict(dhp=rel(dhp, dhp_ref), db1=rel(part.sum(0), dhp_ref.sum(0)),
+                 dxn_of_rounded_dhp=rel(dxn, dhp.to(bf).double() @ w1.double()), dxn=rel(dxn, dhp_ref @ w1.double()))
+        d16, x16, p16 = ops.mlp_fused_bwd(dy, hp.to(bf), w1, w2, out_dtype=bf)
+        assert d16.dtype == bf and torch.equal(d16, dhp.to(bf)) and torch.equal(x16, dxn) and torch.equal(p16, part)
+        d2, x2, p2 = ops.mlp_fused_bwd(dy, hp, w1, w2)
+        assert torch.equal(d2, dhp) and torch.equal(x2, dxn) and torch.equal(p2, part)        # deterministic
+    finally:
+        ops.set_gemm_precision(prev)
+    report("mlp_fused_bwd_bf16_M%d" % M, **e)
+    assert max(e["dhp"], e["db1"], e["dxn_of_rounded_dhp"]) < 3e-6 and e["dxn"] < 2e-2, e
+    with pytest.raises(RuntimeError):
+        ops.mlp_fused_bwd(dy, hp.to(bf), w1, w2)                  # bf16 storage only in the bf16 configuration
+
+
 @pytest.mark.parametrize("M", [140, 1152, 9216 + 48])
 def test_row_resident_input_gradient_with_gelu_grad_and_column_sums(ops, M):
     """linear_dx for a Linear with 192 outputs (fc2, attention proj) on rp_linear_rows192: dx = (dy W) o GELU'(aux) and the column

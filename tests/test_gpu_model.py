@@ -588,8 +588,11 @@ def test_bf16_configuration_at_128_pairs_per_gpu(model, states):
     attention / EMM kernels -- at that configuration's per-GPU batch (1024 global / 8 = 128 pairs), forward and backward.
     128 pairs = 4 distinct pairs x 32 copies.  Stated tolerance vs the fp64 oracle: R,t within 5e-2, token gradients within
     2e-1 of max|ref| in the max norm (bf16 has 8 significant bits; forward + backward cross 12 block passes -- measured
-    1.4e-2 / 1.8e-2 / 1.1e-1); copies of a pair stay bit-identical
-    (the kernels are deterministic in this mode too)."""
+    1.4e-2 / 1.8e-2 / 1.1e-1).  The kernels are deterministic in this mode too: a second run is bit-identical, and the 32 copies of a
+    pair have bit-identical poses.  Their token GRADIENTS agree to bf16 resolution only (2e-2 of the maximum): the CrossBlock's MLP
+    backward (rp_mlp_fused_bwd on 256 x 70 rows) cuts its row tiles' chunk ranges at workgroup boundaries that depend on the tile index,
+    so the fixed fp32 summation order of a tile's partial sums differs from tile to tile by an ulp, and the bf16 roundings behind it
+    turn an ulp into a bf16 step for a few elements."""
     from rel_pose_amd import ops
     _, sd64 = states
     B = 128
@@ -610,15 +613,21 @@ def test_bf16_configuration_at_128_pairs_per_gpu(model, states):
             p.grad = None
         out = model.forward_tokens(fmap, Gs4[src].cuda(), intr4[src].contiguous().cuda())
         (out * cot4[src].float().cuda()).sum().backward()
+        g_first, fmap.grad = fmap.grad.clone(), None
+        out2 = model.forward_tokens(fmap, Gs4[src].cuda(), intr4[src].contiguous().cuda())
+        (out2 * cot4[src].float().cuda()).sum().backward()
     finally:
         ops.set_gemm_precision(prev)
         ops.set_attention_precision(0)
         model.eval()
     assert torch.isfinite(out).all() and torch.isfinite(fmap.grad).all()
+    assert torch.equal(out, out2) and torch.equal(fmap.grad, g_first)                     # run-to-run deterministic
     t_err, q_err, _ = O.pose_errors(out[:4].detach().cpu(), ref.detach())
     g = fmap.grad.view(B, 2, 192, 576)
+    gmax = float(g.abs().max())
     for b in range(4, B):
-        assert torch.equal(out[b], out[b % 4]) and torch.equal(g[b], g[b % 4])
+        assert torch.equal(out[b], out[b % 4])
+        assert float((g[b] - g[b % 4]).abs().max()) < 2e-2 * gmax
     e_tok = rel(g[:4].reshape(8, 192, 576).permute(0, 2, 1), gtok)
     report("config5_bf16_128pairs", t=t_err, q=q_err, grad_tokens=e_tok)
     assert 1e-5 < max(t_err, q_err) < 5e-2 and e_tok < 2e-1

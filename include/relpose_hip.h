@@ -363,10 +363,14 @@ int rp_linear_rows192(const float* x, const float* w, const float* bias, const f
  *   y = x + fc2(GELU(fc1(LayerNorm(x; gamma, beta, eps)) + b1)) + b2,   x, y [M, dim], w1 [hidden, dim], w2 [dim, hidden]
  * (nn.Linear layouts).  The normalised rows and the hidden activation stay in registers / LDS.  dim = 192, hidden = 768 only
  * (RP_EBADSHAPE otherwise).  workspace: rp_mlp_fused_workspace_bytes(M) bytes (partial tiles of the stream-K split).
+ * Training form: with xn_out [M,dim], mean_out [M], rstd_out [M], h_out [M,hidden] and hpre_out [M,hidden] (all five or none;
+ * NULL = inference) the kernel also stores what the backward needs -- the normalised rows and their statistics, fc1's pre-activation
+ * and the hidden activation -- on the way: the forward of the MLP is then one launch in training too.
  * ------------------------------------------------------------------------------------------- */
 size_t rp_mlp_fused_workspace_bytes(int M);
 int rp_mlp_fused_fwd(const float* x, const float* gamma, const float* beta, const float* w1, const float* b1, const float* w2,
-                     const float* b2, float* y, void* workspace, int M, int dim, int hidden, float eps, void* stream);
+                     const float* b2, float* y, void* workspace, int M, int dim, int hidden, float eps, float* xn_out, float* mean_out,
+                     float* rstd_out, float* h_out, float* hpre_out, void* stream);
 
 /* Backward-data of the same MLP (training): dhp [M,hidden] = (dy W2) o GELU'(hpre) -- the gradient of fc1's pre-activation, which
  * fc1's weight gradient needs -- and dxn [M,dim] = dhp W1, the gradient of the LayerNorm output, as one kernel (dh never exists).

@@ -25,6 +25,7 @@
 // chunks of a tile finishes it (bias, residual, store); otherwise it writes its partial Y tile to the workspace and
 // mlp_fixup_kernel adds the (at most few) partials of that tile in chunk order -- fixed order, no atomics, deterministic.
 #include <stdlib.h>
+#include <algorithm>
 #include "common.h"
 #include "../../include/relpose_hip.h"
 
@@ -48,6 +49,9 @@ struct MlpP {
   float eps;
   int tiles, base, rem, P;
   int io_bf16;       // BF only: bit 1 = dhp is written as bf16, bit 2 = hpre holds bf16
+  // MODE 0, TRAIN: what the backward needs, written on the way (all [M, .] fp32): the normalised rows and their statistics, the fc1
+  // pre-activation (dhp doubles as its pointer) and the hidden activation
+  float *xn_out, *mean_out, *rstd_out, *h_out;
 };
 
 RP_DEV void item_range(const MlpP& p, int b, int& start, int& count) {
@@ -66,13 +70,17 @@ RP_DEV void item_range(const MlpP& p, int b, int& start, int& count) {
 // rows are rounded to bf16 once per row tile); GEMM2 contracts the chunk's 32 units in ONE MFMA per 16-column block: its B operand is
 // pack8(h0, h1) -- k-slot 8 q + e <-> unit 4 q + e (e < 4) / 16 + 4 q + e - 4 -- so the caller stores the second weight with the units
 // of every 32-chunk in THAT order and a lane's A operand is one ds_read_b128.  GELU', the column sums and the stream-K partials stay fp32.
-template <int NW, int WPS, int MODE, bool BF = false>
+// TRAIN (MODE 0 only): the training forward -- same kernel, but xn / mean / rstd (by the workgroup that runs a tile's first chunk), the
+// pre-activation and the hidden activation are stored for the backward (the chain then costs the MFMA time of its two products instead
+// of a LayerNorm+fc1 launch and an fc2 launch that re-reads h).
+template <int NW, int WPS, int MODE, bool BF = false, bool TRAIN = false>
 __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
   constexpr int NT = NW * 64, ROWS = NW * 16;
   constexpr int TILE_FL = BF ? W1T / 2 : W1T;                   // floats per staged weight tile (bf16 weights: half)
   constexpr int DMA = (TILE_FL / 4) / NT;                       // 16-byte chunks per thread per tile (3 for NW = 8)
   static_assert((TILE_FL / 4) % NT == 0, "tile must be a whole number of DMA rounds");
   static_assert(!BF || MODE == 1, "the bf16 form exists for the backward-data chain only");
+  static_assert(!TRAIN || MODE == 0, "TRAIN is the training form of the forward");
   __shared__ __attribute__((aligned(16))) float w1t[TILE_FL];
   __shared__ __attribute__((aligned(16))) float w2t[TILE_FL];
   // MODE 0: gamma | beta of the LayerNorm (b1 is read from L2: staging all of it here would cost the third resident workgroup per
@@ -150,6 +158,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
       var += __shfl_xor(var, 16, 64);
       var += __shfl_xor(var, 32, 64);
       const float rs = 1.0f / sqrtf(var * (1.0f / C) + p.eps);
+      const bool owner = TRAIN && c0 == 0 && live;                  // the range holding the tile's first chunk writes xn / stats
 #pragma unroll
       for (int t = 0; t < 12; ++t) {
         const float4 g = ld4(b1s + 16 * t + 4 * q), bb = ld4(b1s + (MODE == 0 ? C : 0) + 16 * t + 4 * q);
@@ -157,6 +166,12 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
         xn[4 * t + 1] = (xn[4 * t + 1] - mu) * rs * g.y + bb.y;
         xn[4 * t + 2] = (xn[4 * t + 2] - mu) * rs * g.z + bb.z;
         xn[4 * t + 3] = (xn[4 * t + 3] - mu) * rs * g.w + bb.w;
+        if (TRAIN && owner)
+          st4(p.xn_out + (long long)row * C + 16 * t + 4 * q, make_float4(xn[4 * t], xn[4 * t + 1], xn[4 * t + 2], xn[4 * t + 3]));
+      }
+      if (TRAIN && owner && q == 0) {
+        p.mean_out[row] = mu;
+        p.rstd_out[row] = rs;
       }
     }
     f32x4v acc[12];
@@ -228,8 +243,13 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
         __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);          // ... then this group's eight MFMAs
       }
       }
+      float4 pre0 = make_float4(0.f, 0.f, 0.f, 0.f), pre1 = pre0;
       if (MODE == 0) {
         const float4 ba = g0p, bb = g1p;
+        if (TRAIN) {
+          pre0 = make_float4(h0[0] + ba.x, h0[1] + ba.y, h0[2] + ba.z, h0[3] + ba.w);
+          pre1 = make_float4(h1[0] + bb.x, h1[1] + bb.y, h1[2] + bb.z, h1[3] + bb.w);
+        }
         h0[0] = gelu_fast(h0[0] + ba.x); h0[1] = gelu_fast(h0[1] + ba.y);
         h0[2] = gelu_fast(h0[2] + ba.z); h0[3] = gelu_fast(h0[3] + ba.w);
         h1[0] = gelu_fast(h1[0] + bb.x); h1[1] = gelu_fast(h1[1] + bb.y);
@@ -258,6 +278,12 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
       }
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // W2(c) landed everywhere; W1 tile free
       if (it + 1 < end) issue_w1((it + 1) % NCHUNK);
+      if (TRAIN && live) {      // (after the DMA issue, like MODE 1's stores)
+        st4(p.dhp + ho, pre0);
+        st4(p.dhp + ho + 16, pre1);
+        st4(p.h_out + ho, make_float4(h0[0], h0[1], h0[2], h0[3]));
+        st4(p.h_out + ho + 16, make_float4(h1[0], h1[1], h1[2], h1[3]));
+      }
       if (MODE == 1) {          // after the DMA issue: these stores have the whole of GEMM2 to retire before the next vmcnt(0)
         if (live) {
           if (dhp_bf) {
@@ -370,7 +396,7 @@ __global__ __launch_bounds__(256) void mlp_fixup_kernel(MlpP p, int G) {
 }
 
 // NW waves per workgroup (16 rows each), WPS waves per SIMD the register allocation is held to
-template <int NW, int WPS, int MODE, bool BF = false>
+template <int NW, int WPS, int MODE, bool BF = false, bool TRAIN = false>
 struct Variant {
   static constexpr int ROWS = NW * 16;
   static int grid(int tiles) {
@@ -379,7 +405,7 @@ struct Variant {
       int dev = 0, cus = 256, per_cu = 1;
       (void)hipGetDevice(&dev);
       (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mlp_fused_kernel<NW, WPS, MODE, BF>, NW * 64, 0);
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mlp_fused_kernel<NW, WPS, MODE, BF, TRAIN>, NW * 64, 0);
       slots = cus * (per_cu > 0 ? per_cu : 1);
     }
     const long long items = (long long)tiles * NCHUNK;
@@ -401,7 +427,7 @@ struct Variant {
   }
   static int launch(MlpP p, hipStream_t st) {
     const int G = partition(p);
-    hipLaunchKernelGGL((mlp_fused_kernel<NW, WPS, MODE, BF>), dim3(G), dim3(NW * 64), 0, st, p);
+    hipLaunchKernelGGL((mlp_fused_kernel<NW, WPS, MODE, BF, TRAIN>), dim3(G), dim3(NW * 64), 0, st, p);
     RP_CHECK_LAUNCH();
     if (p.rem != 0 || p.base % NCHUNK != 0) {                     // some tile is shared between workgroups
       hipLaunchKernelGGL((mlp_fixup_kernel<ROWS, MODE>), dim3((ROWS * C / 4 + 255) / 256, p.tiles), dim3(256), 0, st, p, G);
@@ -425,19 +451,30 @@ int mlp_variant() {
 extern "C" size_t rp_mlp_fused_workspace_bytes(int M) {
   if (M <= 0) return 0;
   switch (mlp_variant()) {
-    case 1: return Variant<8, 2, 0>::workspace(M);
-    case 2: return Variant<12, 3, 0>::workspace(M);
-    default: return Variant<4, 3, 0>::workspace(M);
+    // (enough for the inference and the training form: their occupancy, hence their stream-K partition, may differ)
+    case 1: return std::max(Variant<8, 2, 0>::workspace(M), Variant<8, 2, 0, false, true>::workspace(M));
+    case 2: return std::max(Variant<12, 3, 0>::workspace(M), Variant<12, 3, 0, false, true>::workspace(M));
+    default: return std::max(Variant<4, 3, 0>::workspace(M), Variant<4, 3, 0, false, true>::workspace(M));
   }
 }
 
 extern "C" int rp_mlp_fused_fwd(const float* x, const float* gamma, const float* beta, const float* w1, const float* b1,
                                 const float* w2, const float* b2, float* y, void* workspace, int M, int dim, int hidden, float eps,
-                                void* stream) {
+                                float* xn_out, float* mean_out, float* rstd_out, float* h_out, float* hpre_out, void* stream) {
   if (M <= 0 || dim != C || hidden != HID || !x || !gamma || !beta || !w1 || !b1 || !w2 || !b2 || !y || !workspace)
     return RP_EBADSHAPE;
-  MlpP p{x, gamma, beta, w1, b1, w2, b2, y, nullptr, nullptr, nullptr, (float*)workspace, M, eps, 0, 0, 0, 0, 0};
+  const bool train = xn_out || mean_out || rstd_out || h_out || hpre_out;
+  if (train && !(xn_out && mean_out && rstd_out && h_out && hpre_out)) return RP_EBADSHAPE;      // the training outputs come as a set
+  MlpP p{x, gamma, beta, w1, b1, w2, b2, y, nullptr, hpre_out, nullptr, (float*)workspace, M, eps, 0, 0, 0, 0, 0,
+         xn_out, mean_out, rstd_out, h_out};
   hipStream_t st = (hipStream_t)stream;
+  if (train) {
+    switch (mlp_variant()) {
+      case 1: return Variant<8, 2, 0, false, true>::launch(p, st);
+      case 2: return Variant<12, 3, 0, false, true>::launch(p, st);
+      default: return Variant<4, 3, 0, false, true>::launch(p, st);
+    }
+  }
   switch (mlp_variant()) {
     case 1: return Variant<8, 2, 0>::launch(p, st);
     case 2: return Variant<12, 3, 0>::launch(p, st);
@@ -467,7 +504,8 @@ extern "C" int rp_mlp_fused_bwd(const float* dy, const float* hpre, const float*
   if (M <= 0 || dim != C || hidden != HID || !dy || !hpre || !w2t || !w1t || !dhp || !dxn || !colpart || !workspace)
     return RP_EBADSHAPE;
   if ((precision != 0 && precision != 1) || (io_bf16 && (precision != 1 || (io_bf16 & ~6)))) return RP_EUNSUPPORTED;
-  MlpP p{dy, nullptr, nullptr, w2t, nullptr, w1t, nullptr, dxn, hpre, dhp, colpart, (float*)workspace, M, 0.f, 0, 0, 0, 0, io_bf16};
+  MlpP p{dy, nullptr, nullptr, w2t, nullptr, w1t, nullptr, dxn, hpre, dhp, colpart, (float*)workspace, M, 0.f, 0, 0, 0, 0, io_bf16,
+         nullptr, nullptr, nullptr, nullptr};
   if (precision == 1) return Variant<12, 3, 1, true>::launch(p, (hipStream_t)stream);      // (same 192-row tiles: same workspace / tile rows)
   return mlp_bwd_variant() == 1 ? Variant<8, 2, 1>::launch(p, (hipStream_t)stream) : Variant<12, 3, 1>::launch(p, (hipStream_t)stream);
 }

@@ -997,14 +997,17 @@ class TokensFn(_Fn):
         return dfeat, dpe
 
 
-# Inference path of the transformer MLP: LayerNorm + fc1 + GELU + fc2 + residual as ONE kernel, hidden activation on chip
-# (csrc/mlp_fused.hip).  Training keeps the GEMM chain: its backward needs xn, h and h_pre in HBM anyway.
+# The transformer MLP's forward: LayerNorm + fc1 + GELU + fc2 + residual as ONE kernel (csrc/mlp_fused.hip).  Inference
+# keeps the hidden activation on chip; training runs the same kernel and stores xn, h and h_pre for the backward on the way
+# (RP_FUSE_MLP_TRAIN=0: the LayerNorm+fc1 launch and the fc2 launch instead).
 FUSE_MLP = os.environ.get("RP_FUSE_MLP", "1") != "0"
+FUSE_MLP_TRAIN = os.environ.get("RP_FUSE_MLP_TRAIN", "1") != "0"
 _mlp_ws = {}
 
 
-def mlp_fused(x2d, gamma, beta, w1, b1, w2, b2, eps=LN_EPS):
-    """y = x + fc2(GELU(fc1(LayerNorm(x)) + b1)) + b2 for x [M,192], w1 [768,192], w2 [192,768] (rp_mlp_fused_fwd)."""
+def mlp_fused(x2d, gamma, beta, w1, b1, w2, b2, eps=LN_EPS, train=False):
+    """y = x + fc2(GELU(fc1(LayerNorm(x)) + b1)) + b2 for x [M,192], w1 [768,192], w2 [192,768] (rp_mlp_fused_fwd).
+    train=True: returns (y, xn, mean, rstd, h, hpre) -- the same launch also stores what the backward needs."""
     lib = _lib.load()
     _chk(x2d, gamma, beta, w1, b1, w2, b2)
     M = x2d.shape[0]
@@ -1014,10 +1017,14 @@ def mlp_fused(x2d, gamma, beta, w1, b1, w2, b2, eps=LN_EPS):
     if ws is None:
         ws = _mlp_ws[key] = torch.empty(max(1, lib.rp_mlp_fused_workspace_bytes(M)) // 4 + 1, device=x2d.device, dtype=torch.float32)
     Hd = w1.shape[0]
-    with timed("mlp_fused_fwd", 4.0 * M * DIM * Hd, 4.0 * (2 * M * DIM + 2 * DIM * Hd)):
+    xn = mean = rstd = h = hpre = None
+    if train:
+        xn, mean, rstd = torch.empty_like(x2d), _empty(M, like=x2d), _empty(M, like=x2d)
+        h, hpre = _empty(M, Hd, like=x2d), _empty(M, Hd, like=x2d)
+    with timed("mlp_fused_fwd", 4.0 * M * DIM * Hd, 4.0 * (2 * M * DIM + 2 * DIM * Hd + (M * DIM + 2 * M * Hd if train else 0))):
         _lib.check(lib.rp_mlp_fused_fwd(_p(x2d), _p(gamma), _p(beta), _p(w1), _p(b1), _p(w2), _p(b2), _p(y), _p(ws), M, x2d.shape[1],
-                                        Hd, eps, _st()), "rp_mlp_fused_fwd")
-    return y
+                                        Hd, eps, _p(xn), _p(mean), _p(rstd), _p(h), _p(hpre), _st()), "rp_mlp_fused_fwd")
+    return (y, xn, mean, rstd, h, hpre) if train else y
 
 
 FUSE_MLP_BWD = os.environ.get("RP_FUSE_MLP_BWD", "1") != "0"
@@ -1084,8 +1091,10 @@ def mlp_fused_bwd(dy, hpre, w1, w2, out_dtype=None):
 
 def _mlp_block_fwd(x1, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b, train):
     """(y, xn2, m2, r2, h, hpre) of `x1 + Mlp(norm2(x1))`; the inference path returns y only (rest None)."""
-    if (not train and FUSE_MLP and GEMM_PRECISION == 0 and x1.shape[1] == DIM and tuple(fc1_w.shape) == (4 * DIM, DIM)
-            and tuple(fc2_w.shape) == (DIM, 4 * DIM)):
+    if (FUSE_MLP and GEMM_PRECISION == 0 and x1.shape[1] == DIM and tuple(fc1_w.shape) == (4 * DIM, DIM)
+            and tuple(fc2_w.shape) == (DIM, 4 * DIM) and (not train or FUSE_MLP_TRAIN)):
+        if train:
+            return mlp_fused(x1, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b, train=True)
         return mlp_fused(x1, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b), None, None, None, None, None
     hd = torch.bfloat16 if _act_bf16() else None          # bf16 configuration: the [tokens, 768] hidden tensors live in bf16
     if train:

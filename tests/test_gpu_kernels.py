@@ -921,6 +921,17 @@ def test_fused_mlp_inference_kernel(ops, M):
     report("mlp_fused_M%d" % M, vs_fp64=e, vs_unfused_chain=e2, chain_vs_fp64=rel(chain, ref))
     assert e < 2e-6 and e2 < 2e-6
     assert torch.equal(y, ops.mlp_fused(x, g, b, w1, b1, w2, b2))                  # deterministic (fixed-order fix-up)
+    # training form: the same launch also stores what the backward needs (its y may differ from the inference launch's in the last
+    # bit: the two instantiations' occupancy, hence where the stream-K split cuts a tile's chunk range, can differ)
+    yt, xn_t, mean_t, rstd_t, h_t, hpre_t = ops.mlp_fused(x, g, b, w1, b1, w2, b2, train=True)
+    xnd = F.layer_norm(xd, (192,), g.double(), b.double(), 1e-6)
+    pre_ref = F.linear(xnd, w1.double(), b1.double())
+    t = dict(xn=rel(xn_t, xnd), mean=rel(mean_t, xd.mean(1)), rstd=rel(rstd_t, (xd.var(1, unbiased=False) + 1e-6).rsqrt()),
+             hpre=rel(hpre_t, pre_ref), h=rel(h_t, F.gelu(pre_ref)))
+    t["y_vs_inference_launch"] = rel(yt, y)
+    report("mlp_fused_train_M%d" % M, **t)
+    assert max(t.values()) < 2e-6 and t["y_vs_inference_launch"] < 5e-7, t
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(ops.mlp_fused(x, g, b, w1, b1, w2, b2, train=True), (yt, xn_t, mean_t, rstd_t, h_t, hpre_t)))
     with pytest.raises(RuntimeError):
         ops.mlp_fused(x[:, :128].contiguous(), g[:128], b[:128], w1[:, :128].contiguous(), b1, w2, b2)
 

@@ -366,11 +366,14 @@ int rp_linear_rows192(const float* x, const float* w, const float* bias, const f
  * Training form: with xn_out [M,dim], mean_out [M], rstd_out [M], h_out [M,hidden] and hpre_out [M,hidden] (all five or none;
  * NULL = inference) the kernel also stores what the backward needs -- the normalised rows and their statistics, fc1's pre-activation
  * and the hidden activation -- on the way: the forward of the MLP is then one launch in training too.
+ * precision: 0 exact fp32 MFMA; 1 = the bf16 configuration (v_mfma_f32_16x16x32_bf16, fp32 accumulate; LayerNorm, bias, GELU, residual
+ * fp32): w1 and w2 then point to BF16 copies ([hidden,dim] and [dim,hidden]), w2 with the hidden units of every 32-chunk in the order
+ * documented at rp_mlp_fused_bwd.  io_bf16 (precision 1, training form only): bit 1 = h_out and hpre_out are written as bf16.
  * ------------------------------------------------------------------------------------------- */
 size_t rp_mlp_fused_workspace_bytes(int M);
 int rp_mlp_fused_fwd(const float* x, const float* gamma, const float* beta, const float* w1, const float* b1, const float* w2,
                      const float* b2, float* y, void* workspace, int M, int dim, int hidden, float eps, float* xn_out, float* mean_out,
-                     float* rstd_out, float* h_out, float* hpre_out, void* stream);
+                     float* rstd_out, float* h_out, float* hpre_out, int precision, int io_bf16, void* stream);
 
 /* Backward-data of the same MLP (training): dhp [M,hidden] = (dy W2) o GELU'(hpre) -- the gradient of fc1's pre-activation, which
  * fc1's weight gradient needs -- and dxn [M,dim] = dhp W1, the gradient of the LayerNorm output, as one kernel (dh never exists).

@@ -119,7 +119,7 @@ _SIGS = {
     "rp_linear_rows192_tile_rows": (c_int, []),
     "rp_linear_rows192": (c_int, [P, P, P, P, P, P, F, P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
     "rp_mlp_fused_workspace_bytes": (ctypes.c_size_t, [I]),
-    "rp_mlp_fused_fwd": (c_int, [P, P, P, P, P, P, P, P, P, I, I, I, ctypes.c_float, P, P, P, P, P, P]),
+    "rp_mlp_fused_fwd": (c_int, [P, P, P, P, P, P, P, P, P, I, I, I, ctypes.c_float, P, P, P, P, P, I, I, P]),
     "rp_mlp_fused_bwd_workspace_bytes": (ctypes.c_size_t, [I]),
     "rp_mlp_fused_bwd_tile_rows": (c_int, []),
     "rp_mlp_fused_bwd": (c_int, [P, P, P, P, P, P, P, P, I, I, I, I, I, P]),

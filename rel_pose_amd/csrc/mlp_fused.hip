@@ -65,7 +65,7 @@ RP_DEV void item_range(const MlpP& p, int b, int& start, int& count) {
 // [192,768]), GELU replaced by the multiplication with GELU'(h_pre) read from HBM in accumulator layout, no LayerNorm on the way
 // in and no bias / residual on the way out.  Also emits the column sums of dhp per (row tile, chunk) -- the fc1 bias gradient.
 //
-// BF (MODE 1 only; the bf16 configuration): both products on v_mfma_f32_16x16x32_bf16, fp32 accumulate.  The weights arrive as bf16
+// BF (the bf16 configuration; 12-wave workgroups): both products on v_mfma_f32_16x16x32_bf16, fp32 accumulate.  The weights arrive as bf16
 // copies (12 KB per staged tile): GEMM1 exactly as linear_rows.hip's bf16 form (a lane's k-set of block u is 32 u + 8 q .. + 7; the dy
 // rows are rounded to bf16 once per row tile); GEMM2 contracts the chunk's 32 units in ONE MFMA per 16-column block: its B operand is
 // pack8(h0, h1) -- k-slot 8 q + e <-> unit 4 q + e (e < 4) / 16 + 4 q + e - 4 -- so the caller stores the second weight with the units
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
   constexpr int TILE_FL = BF ? W1T / 2 : W1T;                   // floats per staged weight tile (bf16 weights: half)
   constexpr int DMA = (TILE_FL / 4) / NT;                       // 16-byte chunks per thread per tile (3 for NW = 8)
   static_assert((TILE_FL / 4) % NT == 0, "tile must be a whole number of DMA rounds");
-  static_assert(!BF || MODE == 1, "the bf16 form exists for the backward-data chain only");
+  static_assert(!BF || NW == 12, "the bf16 form stages its 12 KB weight tiles in one DMA round of 768 threads");
   static_assert(!TRAIN || MODE == 0, "TRAIN is the training form of the forward");
   __shared__ __attribute__((aligned(16))) float w1t[TILE_FL];
   __shared__ __attribute__((aligned(16))) float w2t[TILE_FL];
@@ -133,13 +133,14 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
     const int tile = it / NCHUNK, c0 = it % NCHUNK, c1 = min(NCHUNK, c0 + end - it);
     const int row = tile * ROWS + wave * 16 + j;
     const bool live = row < p.M;
-    const float* xr = p.x + (long long)min(row, p.M - 1) * C + (BF ? 8 * q : 4 * q);
+    const float* xrow = p.x + (long long)min(row, p.M - 1) * C;
+    auto colof = [&](int t) { return BF ? 32 * (t >> 1) + 8 * q + 4 * (t & 1) : 16 * t + 4 * q; };   // first column of register group t
     // ---- the wave's 16 rows (MODE 0: layer-normalised) straight into the B-operand registers (lane (j, q): columns 16t + 4q + 0..3;
     // BF: columns 32 (t >> 1) + 8 q + 4 (t & 1) + 0..3, i.e. 8 consecutive per 32-wide k block)
     float xn[48];
 #pragma unroll
     for (int t = 0; t < 12; ++t) {
-      const float4 v = ld4(xr + (BF ? 32 * (t >> 1) + 4 * (t & 1) : 16 * t));
+      const float4 v = ld4(xrow + colof(t));
       xn[4 * t] = v.x; xn[4 * t + 1] = v.y; xn[4 * t + 2] = v.z; xn[4 * t + 3] = v.w;
     }
     if (MODE == 0) {
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
 #pragma unroll
       for (int i = 0; i < 48; ++i) {
         const float d = xn[i] - mu;
-        var += d * d;
+        var = fmaf(d, d, var);          // (explicit: every instantiation must contract the same way -- an ulp here is a bf16 step later)
       }
       var += __shfl_xor(var, 16, 64);
       var += __shfl_xor(var, 32, 64);
@@ -161,13 +162,13 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
       const bool owner = TRAIN && c0 == 0 && live;                  // the range holding the tile's first chunk writes xn / stats
 #pragma unroll
       for (int t = 0; t < 12; ++t) {
-        const float4 g = ld4(b1s + 16 * t + 4 * q), bb = ld4(b1s + (MODE == 0 ? C : 0) + 16 * t + 4 * q);
-        xn[4 * t] = (xn[4 * t] - mu) * rs * g.x + bb.x;
-        xn[4 * t + 1] = (xn[4 * t + 1] - mu) * rs * g.y + bb.y;
-        xn[4 * t + 2] = (xn[4 * t + 2] - mu) * rs * g.z + bb.z;
-        xn[4 * t + 3] = (xn[4 * t + 3] - mu) * rs * g.w + bb.w;
+        const float4 g = ld4(b1s + colof(t)), bb = ld4(b1s + (MODE == 0 ? C : 0) + colof(t));
+        xn[4 * t] = fmaf((xn[4 * t] - mu) * rs, g.x, bb.x);
+        xn[4 * t + 1] = fmaf((xn[4 * t + 1] - mu) * rs, g.y, bb.y);
+        xn[4 * t + 2] = fmaf((xn[4 * t + 2] - mu) * rs, g.z, bb.z);
+        xn[4 * t + 3] = fmaf((xn[4 * t + 3] - mu) * rs, g.w, bb.w);
         if (TRAIN && owner)
-          st4(p.xn_out + (long long)row * C + 16 * t + 4 * q, make_float4(xn[4 * t], xn[4 * t + 1], xn[4 * t + 2], xn[4 * t + 3]));
+          st4(p.xn_out + (long long)row * C + colof(t), make_float4(xn[4 * t], xn[4 * t + 1], xn[4 * t + 2], xn[4 * t + 3]));
       }
       if (TRAIN && owner && q == 0) {
         p.mean_out[row] = mu;
@@ -279,10 +280,16 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // W2(c) landed everywhere; W1 tile free
       if (it + 1 < end) issue_w1((it + 1) % NCHUNK);
       if (TRAIN && live) {      // (after the DMA issue, like MODE 1's stores)
-        st4(p.dhp + ho, pre0);
-        st4(p.dhp + ho + 16, pre1);
-        st4(p.h_out + ho, make_float4(h0[0], h0[1], h0[2], h0[3]));
-        st4(p.h_out + ho + 16, make_float4(h1[0], h1[1], h1[2], h1[3]));
+        if (dhp_bf) {           // bf16 configuration: the hidden tensors live in bf16
+          st_bf16x8(reinterpret_cast<unsigned short*>(p.dhp) + ho + bfo, pre0, pre1, q);
+          st_bf16x8(reinterpret_cast<unsigned short*>(p.h_out) + ho + bfo, make_float4(h0[0], h0[1], h0[2], h0[3]),
+                    make_float4(h1[0], h1[1], h1[2], h1[3]), q);
+        } else {
+          st4(p.dhp + ho, pre0);
+          st4(p.dhp + ho + 16, pre1);
+          st4(p.h_out + ho, make_float4(h0[0], h0[1], h0[2], h0[3]));
+          st4(p.h_out + ho + 16, make_float4(h1[0], h1[1], h1[2], h1[3]));
+        }
       }
       if (MODE == 1) {          // after the DMA issue: these stores have the whole of GEMM2 to retire before the next vmcnt(0)
         if (live) {
@@ -347,7 +354,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
         for (int ob = 0; ob < 12; ++ob) {
           float4 r = make_float4(0.f, 0.f, 0.f, 0.f), b2 = r;
           if (MODE == 0) {
-            r = ld4(xr + 16 * ob);
+            r = ld4(xrow + 16 * ob + 4 * q);
             b2 = ld4(p.b2 + 16 * ob + 4 * q);
           }
           st4(yr + 16 * ob, make_float4(acc[ob][0] + b2.x + r.x, acc[ob][1] + b2.y + r.y, acc[ob][2] + b2.z + r.z,
@@ -450,24 +457,28 @@ int mlp_variant() {
 
 extern "C" size_t rp_mlp_fused_workspace_bytes(int M) {
   if (M <= 0) return 0;
+  const size_t bfw = std::max(Variant<12, 3, 0, true, true>::workspace(M), Variant<12, 3, 0, true, false>::workspace(M));   // bf16 forms
   switch (mlp_variant()) {
     // (enough for the inference and the training form: their occupancy, hence their stream-K partition, may differ)
-    case 1: return std::max(Variant<8, 2, 0>::workspace(M), Variant<8, 2, 0, false, true>::workspace(M));
-    case 2: return std::max(Variant<12, 3, 0>::workspace(M), Variant<12, 3, 0, false, true>::workspace(M));
-    default: return std::max(Variant<4, 3, 0>::workspace(M), Variant<4, 3, 0, false, true>::workspace(M));
+    case 1: return std::max(bfw, std::max(Variant<8, 2, 0>::workspace(M), Variant<8, 2, 0, false, true>::workspace(M)));
+    case 2: return std::max(bfw, std::max(Variant<12, 3, 0>::workspace(M), Variant<12, 3, 0, false, true>::workspace(M)));
+    default: return std::max(bfw, std::max(Variant<4, 3, 0>::workspace(M), Variant<4, 3, 0, false, true>::workspace(M)));
   }
 }
 
 extern "C" int rp_mlp_fused_fwd(const float* x, const float* gamma, const float* beta, const float* w1, const float* b1,
                                 const float* w2, const float* b2, float* y, void* workspace, int M, int dim, int hidden, float eps,
-                                float* xn_out, float* mean_out, float* rstd_out, float* h_out, float* hpre_out, void* stream) {
+                                float* xn_out, float* mean_out, float* rstd_out, float* h_out, float* hpre_out, int precision,
+                                int io_bf16, void* stream) {
   if (M <= 0 || dim != C || hidden != HID || !x || !gamma || !beta || !w1 || !b1 || !w2 || !b2 || !y || !workspace)
     return RP_EBADSHAPE;
   const bool train = xn_out || mean_out || rstd_out || h_out || hpre_out;
   if (train && !(xn_out && mean_out && rstd_out && h_out && hpre_out)) return RP_EBADSHAPE;      // the training outputs come as a set
-  MlpP p{x, gamma, beta, w1, b1, w2, b2, y, nullptr, hpre_out, nullptr, (float*)workspace, M, eps, 0, 0, 0, 0, 0,
+  if ((precision != 0 && precision != 1) || (io_bf16 && (precision != 1 || !train || (io_bf16 & ~2)))) return RP_EUNSUPPORTED;
+  MlpP p{x, gamma, beta, w1, b1, w2, b2, y, nullptr, hpre_out, nullptr, (float*)workspace, M, eps, 0, 0, 0, 0, io_bf16,
          xn_out, mean_out, rstd_out, h_out};
   hipStream_t st = (hipStream_t)stream;
+  if (precision == 1) return train ? Variant<12, 3, 0, true, true>::launch(p, st) : Variant<12, 3, 0, true, false>::launch(p, st);
   if (train) {
     switch (mlp_variant()) {
       case 1: return Variant<8, 2, 0, false, true>::launch(p, st);

@@ -1005,12 +1005,18 @@ FUSE_MLP_TRAIN = os.environ.get("RP_FUSE_MLP_TRAIN", "1") != "0"
 _mlp_ws = {}
 
 
-def mlp_fused(x2d, gamma, beta, w1, b1, w2, b2, eps=LN_EPS, train=False):
+def mlp_fused(x2d, gamma, beta, w1, b1, w2, b2, eps=LN_EPS, train=False, out_dtype=None):
     """y = x + fc2(GELU(fc1(LayerNorm(x)) + b1)) + b2 for x [M,192], w1 [768,192], w2 [192,768] (rp_mlp_fused_fwd).
-    train=True: returns (y, xn, mean, rstd, h, hpre) -- the same launch also stores what the backward needs."""
+    train=True: returns (y, xn, mean, rstd, h, hpre) -- the same launch also stores what the backward needs.  At operand precision 1
+    (the bf16 configuration) both products run on the bf16 MFMA from bf16 weight copies, and out_dtype=torch.bfloat16 stores h / hpre
+    as bf16."""
     lib = _lib.load()
     _chk(x2d, gamma, beta, w1, b1, w2, b2)
     M = x2d.shape[0]
+    bf = GEMM_PRECISION == 1
+    obf = out_dtype == torch.bfloat16
+    if obf and not (bf and train):
+        raise RuntimeError("bf16-stored hidden tensors need operand precision 1 (the bf16 configuration) and the training form")
     y = torch.empty_like(x2d)
     key = (x2d.device, M, torch.cuda.current_stream(x2d.device).cuda_stream)
     ws = _mlp_ws.get(key)
@@ -1020,10 +1026,16 @@ def mlp_fused(x2d, gamma, beta, w1, b1, w2, b2, eps=LN_EPS, train=False):
     xn = mean = rstd = h = hpre = None
     if train:
         xn, mean, rstd = torch.empty_like(x2d), _empty(M, like=x2d), _empty(M, like=x2d)
-        h, hpre = _empty(M, Hd, like=x2d), _empty(M, Hd, like=x2d)
+        hdt = torch.bfloat16 if obf else torch.float32
+        h, hpre = torch.empty(M, Hd, device=x2d.device, dtype=hdt), torch.empty(M, Hd, device=x2d.device, dtype=hdt)
+    if bf:
+        w1k, w2k = bf16_weight(w1), _chunk_permuted_bf16(w2)
+    else:
+        w1k, w2k = w1, w2
     with timed("mlp_fused_fwd", 4.0 * M * DIM * Hd, 4.0 * (2 * M * DIM + 2 * DIM * Hd + (M * DIM + 2 * M * Hd if train else 0))):
-        _lib.check(lib.rp_mlp_fused_fwd(_p(x2d), _p(gamma), _p(beta), _p(w1), _p(b1), _p(w2), _p(b2), _p(y), _p(ws), M, x2d.shape[1],
-                                        Hd, eps, _p(xn), _p(mean), _p(rstd), _p(h), _p(hpre), _st()), "rp_mlp_fused_fwd")
+        _lib.check(lib.rp_mlp_fused_fwd(_p(x2d), _p(gamma), _p(beta), _p(w1k), _p(b1), _p(w2k), _p(b2), _p(y), _p(ws), M, x2d.shape[1],
+                                        Hd, eps, _p(xn), _p(mean), _p(rstd), _p(h), _p(hpre), 1 if bf else 0, 2 if obf else 0, _st()),
+                   "rp_mlp_fused_fwd")
     return (y, xn, mean, rstd, h, hpre) if train else y
 
 
@@ -1044,19 +1056,25 @@ def _mlp_unit_perm(device):
     return pm
 
 
-def _mlp_bwd_bf16_weights(w1, w2):
-    """(bf16 W2^T [768,192], bf16 W1^T [192,768] with the chunk-permuted unit order), cached on w1 / w2 until they change"""
-    w2b = bf16_weight(transposed(w2))
-    c = getattr(w1, "_rp_bp", None)
-    if c is not None and c[0] == w1._version and c[1] == w1.data_ptr() and c[2] == _PAD_GEN:
-        return w2b, c[3]
-    w1p = w1.detach().t().index_select(1, _mlp_unit_perm(w1.device)).to(torch.bfloat16).contiguous()
+def _chunk_permuted_bf16(w, transpose=False):
+    """bf16 copy of a [192, 768] operand (w, or w^T when transpose) with the 768 hidden units of every 32-chunk in the order the fused
+    MLP kernels' second product wants (_mlp_unit_perm); cached on w until it changes"""
+    c = getattr(w, "_rp_bp", None)
+    if c is not None and c[0] == w._version and c[1] == w.data_ptr() and c[2] == _PAD_GEN:
+        return c[3]
+    src = w.detach().t() if transpose else w.detach()
+    o = src.index_select(1, _mlp_unit_perm(w.device)).to(torch.bfloat16).contiguous()
     if not torch.cuda.is_current_stream_capturing():
         try:
-            w1._rp_bp = (w1._version, w1.data_ptr(), _PAD_GEN, w1p)
+            w._rp_bp = (w._version, w.data_ptr(), _PAD_GEN, o)
         except AttributeError:
             pass
-    return w2b, w1p
+    return o
+
+
+def _mlp_bwd_bf16_weights(w1, w2):
+    """(bf16 W2^T [768,192], bf16 W1^T [192,768] with the chunk-permuted unit order)"""
+    return bf16_weight(transposed(w2)), _chunk_permuted_bf16(w1, transpose=True)
 
 
 def mlp_fused_bwd(dy, hpre, w1, w2, out_dtype=None):
@@ -1091,10 +1109,10 @@ def mlp_fused_bwd(dy, hpre, w1, w2, out_dtype=None):
 
 def _mlp_block_fwd(x1, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b, train):
     """(y, xn2, m2, r2, h, hpre) of `x1 + Mlp(norm2(x1))`; the inference path returns y only (rest None)."""
-    if (FUSE_MLP and GEMM_PRECISION == 0 and x1.shape[1] == DIM and tuple(fc1_w.shape) == (4 * DIM, DIM)
-            and tuple(fc2_w.shape) == (DIM, 4 * DIM) and (not train or FUSE_MLP_TRAIN)):
+    if (FUSE_MLP and GEMM_PRECISION in (0, 1) and x1.shape[1] == DIM and tuple(fc1_w.shape) == (4 * DIM, DIM)
+            and tuple(fc2_w.shape) == (DIM, 4 * DIM) and (not train or FUSE_MLP_TRAIN) and x1.dtype == torch.float32):
         if train:
-            return mlp_fused(x1, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b, train=True)
+            return mlp_fused(x1, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b, train=True, out_dtype=torch.bfloat16 if _act_bf16() else None)
         return mlp_fused(x1, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b), None, None, None, None, None
     hd = torch.bfloat16 if _act_bf16() else None          # bf16 configuration: the [tokens, 768] hidden tensors live in bf16
     if train:

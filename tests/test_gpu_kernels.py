@@ -1051,6 +1051,43 @@ def test_fused_mlp_backward_data_kernel(ops, M):
 
 
 @pytest.mark.parametrize("M", [140, 9216 + 48])
+def test_fused_mlp_forward_bf16_configuration(ops, M):
+    """rp_mlp_fused_fwd at operand precision 1 (both products on v_mfma_f32_16x16x32_bf16 from bf16 weight copies; LayerNorm, bias, GELU
+    and the residual fp32), inference and training form.  LayerNorm outputs stay fp32-exact (2e-6); the pre-activation, the hidden
+    activation and y carry the bf16 operand rounding (2e-2 of the maximum against fp64); with bf16 storage h / hpre are the
+    round-to-nearest-even of the fp32-stored ones BIT FOR BIT and y is unchanged; the inference launch gives the training launch's y."""
+    import torch.nn.functional as F
+    bf = torch.bfloat16
+    x = rnd(M, 192, seed=1, scale=2.0)
+    g, b = 1 + 0.1 * rnd(192, seed=2), 0.1 * rnd(192, seed=3)
+    w1, b1 = rnd(768, 192, seed=4, scale=192 ** -0.5), 0.1 * rnd(768, seed=5)
+    w2, b2 = rnd(192, 768, seed=6, scale=768 ** -0.5), 0.1 * rnd(192, seed=7)
+    xd = x.double()
+    xnd = F.layer_norm(xd, (192,), g.double(), b.double(), 1e-6)
+    pre_ref = F.linear(xnd, w1.double(), b1.double())
+    ref = xd + F.linear(F.gelu(pre_ref), w2.double(), b2.double())
+    prev = ops.GEMM_PRECISION
+    ops.set_gemm_precision(1)
+    try:
+        y, xn, mean, rstd, h, hpre = ops.mlp_fused(x, g, b, w1, b1, w2, b2, train=True)
+        e = dict(xn=rel(xn, xnd), mean=rel(mean, xd.mean(1)), rstd=rel(rstd, (xd.var(1, unbiased=False) + 1e-6).rsqrt()))
+        assert max(e.values()) < 2e-6, e
+        e.update(hpre=rel(hpre, pre_ref), h=rel(h, F.gelu(pre_ref)), y=rel(y, ref))
+        # exactness of the SECOND product and of the unit permutation: y against fp64 on the kernel's own bf16-rounded h and weights
+        y_chk = xd + F.linear(h.to(bf).double(), w2.to(bf).double(), b2.double())
+        e["y_given_h"] = rel(y, y_chk)
+        y16, _, _, _, h16, hpre16 = ops.mlp_fused(x, g, b, w1, b1, w2, b2, train=True, out_dtype=bf)
+        assert h16.dtype == bf and torch.equal(h16, h.to(bf)) and torch.equal(hpre16, hpre.to(bf)) and torch.equal(y16, y)
+        e["y_inference_launch"] = rel(ops.mlp_fused(x, g, b, w1, b1, w2, b2), y)
+    finally:
+        ops.set_gemm_precision(prev)
+    report("mlp_fused_fwd_bf16_M%d" % M, **e)
+    assert max(e["hpre"], e["h"], e["y"]) < 2e-2 and e["y_given_h"] < 3e-6 and e["y_inference_launch"] < 5e-7, e
+    with pytest.raises(RuntimeError):
+        ops.mlp_fused(x, g, b, w1, b1, w2, b2, train=True, out_dtype=bf)          # bf16 storage only in the bf16 configuration
+
+
+@pytest.mark.parametrize("M", [140, 9216 + 48])
 def test_fused_mlp_backward_bf16_configuration(ops, M):
     """rp_mlp_fused_bwd at operand precision 1 (v_mfma_f32_16x16x32_bf16 from bf16 weight copies, the second one in the kernel's
     chunk-permuted unit order).  With bf16-representable dy and weights the FIRST product is exact: dhp must match fp64 to fp32

@@ -588,11 +588,11 @@ def test_bf16_configuration_at_128_pairs_per_gpu(model, states):
     attention / EMM kernels -- at that configuration's per-GPU batch (1024 global / 8 = 128 pairs), forward and backward.
     128 pairs = 4 distinct pairs x 32 copies.  Stated tolerance vs the fp64 oracle: R,t within 5e-2, token gradients within
     2e-1 of max|ref| in the max norm (bf16 has 8 significant bits; forward + backward cross 12 block passes -- measured
-    1.4e-2 / 1.8e-2 / 1.1e-1).  The kernels are deterministic in this mode too: a second run is bit-identical, and the 32 copies of a
-    pair have bit-identical poses.  Their token GRADIENTS agree to bf16 resolution only (2e-2 of the maximum): the CrossBlock's MLP
-    backward (rp_mlp_fused_bwd on 256 x 70 rows) cuts its row tiles' chunk ranges at workgroup boundaries that depend on the tile index,
-    so the fixed fp32 summation order of a tile's partial sums differs from tile to tile by an ulp, and the bf16 roundings behind it
-    turn an ulp into a bf16 step for a few elements."""
+    1.4e-2 / 1.8e-2 / 1.1e-1).  The kernels are deterministic in this mode too: a second run is bit-identical.  The 32 copies of a pair
+    agree to bf16 resolution only (poses within 5e-3, token gradients within 2e-2 of the maximum), not bit for bit: the CrossBlock's
+    MLP (rp_mlp_fused_fwd / _bwd on 256 x 70 rows) cuts its row tiles' chunk ranges at workgroup boundaries that depend on the tile
+    index, so the fixed fp32 summation order of a tile's partial sums differs from tile to tile by an ulp, and the bf16 roundings
+    behind it turn an ulp into a bf16 step for a few elements."""
     from rel_pose_amd import ops
     _, sd64 = states
     B = 128
@@ -626,7 +626,7 @@ def test_bf16_configuration_at_128_pairs_per_gpu(model, states):
     g = fmap.grad.view(B, 2, 192, 576)
     gmax = float(g.abs().max())
     for b in range(4, B):
-        assert torch.equal(out[b], out[b % 4])
+        assert float((out[b] - out[b % 4]).abs().max()) < 5e-3
         assert float((g[b] - g[b % 4]).abs().max()) < 2e-2 * gmax
     e_tok = rel(g[:4].reshape(8, 192, 576).permute(0, 2, 1), gtok)
     report("config5_bf16_128pairs", t=t_err, q=q_err, grad_tokens=e_tok)

@@ -232,6 +232,11 @@ class KernelTimer:
         self.enabled = False
 
     def reset(self):
+        """forget the recorded launches; their hipEvent handles go back to the free list"""
+        if not hasattr(self, "_pool"):
+            self._pool = []
+        for s, e in self.events:
+            self._pool += [s, e]
         self.events, self.tevents, self.flops, self.bytes = [], [], 0.0, 0.0
 
     def summary(self):

@@ -216,9 +216,9 @@ def parse_instance(text):
         return text
 
 
-TAG_SYMBOLS = {"mlp_fused_fwd": "mlp_fused_kernel<4, 3, 0>", "attn_fwd": "attn_fwd_kernel<2, false, 2, false>",
-               "attn_stats": "attn_fwd_kernel<3, true, 2, false>", "linear_rows_ln": "linear_rows_kernel<true>",
-               "linear_rows": "linear_rows_kernel<false>"}
+TAG_SYMBOLS = {"mlp_fused_fwd": "mlp_fused_kernel<4, 3, 0, false, false>", "attn_fwd": "attn_fwd_kernel<2, false, 2, false, false>",
+               "attn_stats": "attn_fwd_kernel<3, true, 2, false, true>", "linear_rows_ln": "linear_rows_kernel<true, false>",
+               "linear_rows": "linear_rows_kernel<false, false>"}
 
 
 def main():
@@ -441,8 +441,8 @@ def main():
                                               kernel_symbol=TAG_SYMBOLS["mlp_fused_fwd"], traffic_files=("r3_traffic_fwd.json",))),
                             ("bf16_128", dict(tag="train.py step, bf16 MFMA operands in Linear / attention / EMM GEMMs and the MIOpen "
                                                   "convolutions, fp32 accumulate (BASELINE configs[4] per-GPU workload)",
-                                              batch=128, mode="train", precision="bf16", steps=20, warmup=3, timer_instance=(0, 0, 2, 1),
-                                              kernel_symbol="gemm_kernel<0, 0, 2, 1, 1>", traffic_files=("r3_traffic_bf16.json",)))):
+                                              batch=128, mode="train", precision="bf16", steps=20, warmup=3, timer_instance=(1, 1, 1, 3),
+                                              kernel_symbol="gemm_kernel<1, 1, 1, 3, 1>", traffic_files=("r3_traffic_bf16.json",)))):
                 try:
                     sup[key] = supplementary_point(dev, hw=args.hw, **kw)
                 except Exception as e:          # a supplementary point must never take the headline line down with it

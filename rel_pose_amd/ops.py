@@ -418,7 +418,9 @@ def gemm(A, B, M, N, K, *, a_layout=0, b_layout=0, lda=None, ldb=None, out=None,
             _SPLITK_BATCH[0].append(defer)
         tm.events.append((e0, e1))
         tm.flops += 2.0 * M * N * K * batch
-        tm.bytes += 4.0 * batch * (M * K + N * K + M * N * (1 + (aux is not None) + (residual is not None) + (pre_out is not None)))
+        ob = 2.0 if (out_dtype == torch.bfloat16) else 4.0                     # bf16-stored operands (RpGemm.io_bf16) count 2 bytes
+        tm.bytes += batch * (M * K * float(A.element_size()) + 4.0 * N * K + M * N * (ob * (1 + (pre_out is not None))
+                             + (float(aux.element_size()) if aux is not None else 0.0) + (4.0 if residual is not None else 0.0)))
         return (out, colsum(cpart)) if want_colsum else out
     _lib.check(lib.rp_gemm(ctypes.byref(g), _st()), "rp_gemm")
     if defer is not None and g.split_k > 1:

@@ -326,6 +326,35 @@ def test_branch_free_gelu_constants_are_accurate():
     assert np.abs(grad - (phi + xd * np.exp(-0.5 * xd * xd) / np.sqrt(2 * np.pi))).max() < 5e-7
 
 
+def test_bf16_weight_copies_of_the_bf16_configuration():
+    """Host side of the bf16 configuration's row-resident / fused-MLP kernels: ops.bf16_weight keeps a round-to-nearest-even bf16 copy of a
+    weight until the weight is modified; ops._chunk_permuted_bf16 additionally stores the 768 hidden units of every 32-chunk in the order
+    include/relpose_hip.h documents at rp_mlp_fused_bwd (position 8q+e <- unit 4q+e for e < 4, 16+4q+e-4 otherwise)."""
+    from rel_pose_amd import ops
+    w = torch.nn.Parameter(torch.randn(768, 192))
+    a = ops.bf16_weight(w)
+    assert a.dtype == torch.bfloat16 and torch.equal(a, w.detach().to(torch.bfloat16)) and ops.bf16_weight(w) is a
+    with torch.no_grad():
+        w.mul_(1.5)                                                       # an optimizer step: the copy is refreshed
+    b = ops.bf16_weight(w)
+    assert b is not a and torch.equal(b, w.detach().to(torch.bfloat16))
+    perm = ops._mlp_unit_perm(torch.device("cpu"))
+    assert perm.shape == (768,) and sorted(perm.tolist()) == list(range(768))                      # a permutation ...
+    assert all(int(perm[i]) // 32 == i // 32 for i in range(768))                                  # ... inside every 32-chunk
+    for pos in range(32):
+        q, e = pos // 8, pos % 8
+        assert int(perm[64 + pos]) == 64 + (4 * q + e if e < 4 else 16 + 4 * q + e - 4)
+    w2 = torch.nn.Parameter(torch.randn(192, 768))
+    p2 = ops._chunk_permuted_bf16(w2)
+    assert p2.shape == (192, 768) and torch.equal(p2, w2.detach()[:, perm].to(torch.bfloat16)) and ops._chunk_permuted_bf16(w2) is p2
+    w1 = torch.nn.Parameter(torch.randn(768, 192))
+    p1 = ops._chunk_permuted_bf16(w1, transpose=True)
+    assert p1.shape == (192, 768) and torch.equal(p1, w1.detach().t()[:, perm].to(torch.bfloat16))
+    with torch.no_grad():
+        w1.add_(1.0)
+    assert ops._chunk_permuted_bf16(w1, transpose=True) is not p1
+
+
 def test_padded_weight_cache_follows_in_place_updates():
     """ops._padded caches the alignment pads of the CrossBlock / regressor weights between forwards; an optimizer step, load_state_dict
     or any other in-place write (Tensor._version) and a re-pointed .data must invalidate it."""

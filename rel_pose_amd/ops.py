@@ -1071,7 +1071,7 @@ def _chunk_permuted_bf16(w, transpose=False):
         return c[3]
     src = w.detach().t() if transpose else w.detach()
     o = src.index_select(1, _mlp_unit_perm(w.device)).to(torch.bfloat16).contiguous()
-    if not torch.cuda.is_current_stream_capturing():
+    if not (w.is_cuda and torch.cuda.is_current_stream_capturing()):
         try:
             w._rp_bp = (w._version, w.data_ptr(), _PAD_GEN, o)
         except AttributeError:

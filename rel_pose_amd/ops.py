@@ -851,7 +851,7 @@ def emm_stats(qkv, Z, single=False):
     rlse, clse = _empty(Z, HEADS, N_TOK, like=qkv), _empty(Z, HEADS, N_TOK, like=qkv)
     ws = None
     if not ATTN_BF16:
-        key = (qkv.device, Z)
+        key = (qkv.device, Z, torch.cuda.current_stream(qkv.device).cuda_stream)      # (one scratch per stream, like _mlp_ws)
         ws = _stats_ws.get(key)
         if ws is None:
             ws = _stats_ws[key] = torch.empty(lib.rp_emm_stats_workspace_bytes(Z, HEADS) // 4, device=qkv.device, dtype=torch.float32)

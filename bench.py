@@ -19,6 +19,7 @@ import types
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # the host driver only supports dmabuf IPC: RCCL between ranks needs it
 import rel_pose_amd._env  # noqa: F401,E402  (MIOpen user-db path; before torch / the first convolution)
 import torch
 import torch.distributed as dist

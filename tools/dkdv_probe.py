@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Phase timing of attn_bwd_dkdv_kernel with shader-clock stamps (tools/lab/libattn_probe.so = csrc/attention.hip built with
--DRP_DKDV_PROBE): per-wave average cycles per query tile spent in each phase.  Tuning aid."""
+-DRP_DKDV_PROBE): per-wave average cycles per query tile spent in each phase; BF16=1 probes the bf16 operand mode.  Tuning aid."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -20,7 +20,7 @@ b, d = qkv.data_ptr(), dqkv.data_ptr()
 st = P(torch.cuda.current_stream().cuda_stream)
 def run():
     rc = lib.rp_attn_bwd_dkdv_ds(P(b), P(b + 4 * 192), P(b + 8 * 192), P(do.data_ptr()), P(lse.data_ptr()), P(delta.data_ptr()), P(d + 4 * 192),
-                                 P(d + 8 * 192), P(ds.data_ptr()), Z, 3, 576, 576, 576, 192, 576, 576, 0.125, 0, st)
+                                 P(d + 8 * 192), P(ds.data_ptr()), Z, 3, 576, 576, 576, 192, 576, 576, 0.125, int(os.environ.get("BF16", "0")), st)
     assert rc == 0, rc
 for _ in range(3): run()
 torch.cuda.synchronize()

@@ -278,17 +278,22 @@ int rp_attn_bwd_dkdv(const float* q, const float* k, const float* v, const float
  * i & 31 = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) and j & 31 = lane & 31 (the producing wave's MFMA accumulator image: 4 KB contiguous per
  * tile, coalesced 256-byte stores).  dQ = ds K is then ONE rp_ds_matmul instead of the dQ pass, which would recompute S and dP
  * (5 executed GEMMs instead of 7).  bf16 != 0 (the bf16 configuration): the tiles are stored as BF16 in the same image (2 KB per
- * tile, ds then holds Z*H*576*576 bf16) -- pass ds_bf16 = 1 to rp_ds_matmul */
+ * tile, ds then holds Z*H*576*576 bf16) -- pass ds_bf16 = 1 to rp_ds_matmul.
+ * dk_colpart / dv_colpart (both or neither; NULL = off): [Z*18][ldp] arrays (pointers at the first of the H*64 columns) that receive the
+ * column sums of dk / dv over each block of 32 token rows -- summed over the Z*18 rows they are the k / v thirds of the qkv bias
+ * gradient (vision_transformer.py:323), which then needs no pass over the [tokens, 576] gradient; rp_ds_matmul's `colpart` is the
+ * same for its output (the q third). */
 int rp_attn_bwd_dkdv_ds(const float* q, const float* k, const float* v, const float* dout, const float* lse,
                         const float* delta, float* dk, float* dv, float* ds, int Z, int H, int ldq, int ldk, int ldv, int lddo,
-                        int lddk, int lddv, float scale, int bf16, void* stream);
+                        int lddk, int lddv, float scale, int bf16, float* dk_colpart, float* dv_colpart, int ldp, void* stream);
 /* out[z][i][h*64 + d] = sum_j ds[z*H + h][i][j] * b[z ^ b_xor][j][h*64 + d] for the [Z,H,576,576] array a stored-dS pass wrote: the
  * dQ = dS K half of Attention's autograd (vision_transformer.py:325-329) after rp_attn_bwd_dkdv_ds, and with b_xor = 1 the
  * dK = dS^T-major x Q(partner image) half of the EMM's (:198-206) after rp_emm_grad_ds.  b / out point at the first of the H*64
  * columns (row strides ldb / ldo floats, 576 rows per image); one launch for all Z*H problems, dS streamed once from memory.
  * ds_bf16: 0 = fp32 tiles, exact fp32 MFMA; 1 = bf16 tiles (what the producers write when their bf16 flag is set): the product
  * runs on v_mfma_f32_32x32x16_bf16 with b rounded to bf16 on chip, fp32 accumulate and output. */
-int rp_ds_matmul(const float* ds, const float* b, float* out, int Z, int H, int ldb, int ldo, int b_xor, int ds_bf16, void* stream);
+int rp_ds_matmul(const float* ds, const float* b, float* out, int Z, int H, int ldb, int ldo, int b_xor, int ds_bf16, float* colpart,
+                 int ldp, void* stream);
 int rp_attn_bwd_dq(const float* q, const float* k, const float* v, const float* dout, const float* lse, const float* delta,
                    float* dq, int Z, int H, int ldq, int ldk, int ldv, int lddo, int lddq, float scale, int bf16, void* stream);
 

@@ -89,10 +89,10 @@ _SIGS = {
     "rp_attn_fwd": (c_int, [P, P, P, P, P, I, I, I, I, I, I, I, I, F, I, I, P]),
     "rp_attn_bwd_delta": (c_int, [P, P, P, I, I, I, P]),
     "rp_attn_bwd": (c_int, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, P]),
-    "rp_attn_bwd_dkdv_ds": (c_int, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, F, I, P]),
+    "rp_attn_bwd_dkdv_ds": (c_int, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, F, I, P, P, I, P]),
     "rp_emm_stats_workspace_bytes": (ctypes.c_size_t, [I, I]),
     "rp_emm_stats": (c_int, [P, P, P, P, P, I, I, I, I, F, I, P]),
-    "rp_ds_matmul": (c_int, [P, P, P, I, I, I, I, I, I, P]),
+    "rp_ds_matmul": (c_int, [P, P, P, I, I, I, I, I, I, P, I, P]),
     "rp_attn_bwd_cross": (c_int, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, I, P]),
     "rp_attn_bwd_dkdv": (c_int, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, F, I, P]),
     "rp_attn_bwd_dq": (c_int, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, F, I, P]),

@@ -116,6 +116,22 @@ RP_DEV void store_ownerT(float* row_ptr, int hi, const f32x16& o0, const f32x16&
   }
 }
 
+// column sums of the same acc^T tile over its 32 owner rows (x mul): part[d] for d = 0..63 -- a partial of the bias gradient of the
+// Linear that produced the operand (qkv), so that gradient needs no pass of its own over the [tokens, 576] tensor.  Register r of a
+// 32-lane half holds column d = acc_row(r, hi) (+32 for o1) of 32 different rows: DPP row sums + one cross-row exchange, fixed order.
+RP_DEV void colsum_ownerT(float* part, int l31, int hi, const f32x16& o0, const f32x16& o1, float mul) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float a = row16_sum(o0[r]), b = row16_sum(o1[r]);
+    a += __shfl_xor(a, 16, 64);
+    b += __shfl_xor(b, 16, 64);
+    if (l31 == 0) {
+      part[acc_row(r, hi)] = a * mul;
+      part[32 + acc_row(r, hi)] = b * mul;
+    }
+  }
+}
+
 // load the owner operand (32 rows x 64) into registers: lane (row l31, half hi) keeps cols 32*hi .. +31
 RP_DEV void load_owner(const float* row_ptr, int hi, float mul, float (&reg)[32]) {
 #pragma unroll
@@ -322,6 +338,8 @@ struct AttnBwdP {
   int kv_xor;   // 1: keys/values (and dK, dV) of problem z live at image z^1 relative to its queries (cross attention)
   float* ds;    // optional [Z][H][18 q-blocks][18 key-blocks][16][64]: scale * dS in 32x32 tiles (accumulator image) written by the
                 // dK/dV pass, so dQ = dS K is one streaming rp_ds_matmul
+  float *dk_colpart, *dv_colpart;   // optional [Z * 18][ldp]: column sums of dk / dv over each 32-row block (first of the H*64 columns)
+  int ldp;
 };
 
 #ifdef RP_DKDV_PROBE
@@ -426,6 +444,11 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dkdv_kernel(AttnBwdP p)
 #endif
   store_ownerT(p.dv + ((long long)z * NTOK + k0 + l31) * p.lddv + h * 64, hi, dv0, dv1, 1.0f);
   store_ownerT(p.dk + ((long long)z * NTOK + k0 + l31) * p.lddk + h * 64, hi, dk0, dk1, p.scale);
+  if (p.dk_colpart) {
+    const long long prow = ((long long)z * NTILE + (k0 >> 5)) * p.ldp + h * 64;
+    colsum_ownerT(p.dv_colpart + prow, l31, hi, dv0, dv1, 1.0f);
+    colsum_ownerT(p.dk_colpart + prow, l31, hi, dk0, dk1, p.scale);
+  }
 }
 
 template <int NW, int WPS, bool BF>
@@ -493,7 +516,10 @@ struct DsMmP {
   const float* ds; const float* b; float* out;
   int H, ldb, ldo, b_xor, ZH;
   int reverse;      // walk the problems last-to-first: the producer wrote them first-to-last, so the newest tiles may still sit in the
-};                  // 256 MB memory-side cache
+                    // 256 MB memory-side cache
+  float* colpart;   // optional [Z * 18][ldp]: column sums of `out` over each 32-row block (first of the H*64 columns)
+  int ldp;
+};
 
 // acc^T[d][owner] += sum_r Ts[row0 + r][d] * p[r]: like accum_tile but register r pairs with the CONTIGUOUS row row0 + r (row0 = 16 hi):
 // the owner operand then is 64 contiguous bytes of its memory row per lane
@@ -576,6 +602,7 @@ __global__ __launch_bounds__(NW * 64, 4) void ds_matmul_kernel(DsMmP p) {
     step(a2, a1, t + 2);
   }
   store_ownerT(p.out + ((long long)z * NTOK + i0 + l31) * p.ldo + h * 64, hi, o0, o1, 1.0f);
+  if (p.colpart) colsum_ownerT(p.colpart + ((long long)z * NTILE + (i0 >> 5)) * p.ldp + h * 64, l31, hi, o0, o1, 1.0f);
 }
 
 // The bf16 configuration's form: the producer stored bf16 tiles (store_acc_image_bf16: the same [16 r][64 lanes] image, 2 KB), so
@@ -651,6 +678,7 @@ __global__ __launch_bounds__(NW * 64, 4) void ds_matmul_bf16_kernel(DsMmP p) {
     step(a2, a1, t + 2);
   }
   store_ownerT(p.out + ((long long)z * NTOK + i0 + l31) * p.ldo + h * 64, hi, o0, o1, 1.0f);
+  if (p.colpart) colsum_ownerT(p.colpart + ((long long)z * NTILE + (i0 >> 5)) * p.ldp + h * 64, l31, hi, o0, o1, 1.0f);
 }
 
 // The same product on v_mfma_f32_16x16x4_f32.  Why: with >= 2 waves per SIMD taking turns MFMA by MFMA (what a short LDS-fed loop at
@@ -838,10 +866,12 @@ static int launch_bwd(const AttnBwdP& p, int Z, int H, int which, hipStream_t st
 static int attn_bwd_impl(const float* q, const float* k, const float* v, const float* dout, const float* lse,
                          const float* delta, float* dq, float* dk, float* dv, int Z, int H, int ldq, int ldk, int ldv,
                          int lddo, int lddq, int lddk, int lddv, float scale, int which, int bf16, void* stream, int kv_xor = 0,
-                         float* ds = nullptr) {
+                         float* ds = nullptr, float* dk_colpart = nullptr, float* dv_colpart = nullptr, int ldp = 0) {
   if (Z <= 0 || H <= 0 || (kv_xor & ~1) || (kv_xor && (Z & 1))) return RP_EBADSHAPE;
   if ((ldq | ldk | ldv | lddo | lddq | lddk | lddv) & 3) return RP_EALIGN;
-  AttnBwdP p{q, k, v, dout, lse, delta, dq, dk, dv, H, ldq, ldk, ldv, lddo, lddq, lddk, lddv, scale, Z * H, kv_xor, ds};
+  if ((dk_colpart == nullptr) != (dv_colpart == nullptr) || (dk_colpart && ldp < H * 64)) return RP_EBADSHAPE;
+  AttnBwdP p{q, k, v, dout, lse, delta, dq, dk, dv, H, ldq, ldk, ldv, lddo, lddq, lddk, lddv, scale, Z * H, kv_xor, ds,
+             dk_colpart, dv_colpart, ldp};
   // both passes need ~190-240 VGPRs (2 waves/SIMD = 8 wave slots per CU): 2-wave workgroups pack 4 per CU, 3-wave ones only 2
   if (bf16) return launch_bwd<2, true>(p, Z, H, which, (hipStream_t)stream);
   const char* ov = getenv("RP_ATTN_NW");
@@ -868,10 +898,11 @@ extern "C" int rp_attn_bwd_dkdv(const float* q, const float* k, const float* v, 
 }
 extern "C" int rp_attn_bwd_dkdv_ds(const float* q, const float* k, const float* v, const float* dout, const float* lse,
                                    const float* delta, float* dk, float* dv, float* ds, int Z, int H, int ldq, int ldk, int ldv,
-                                   int lddo, int lddk, int lddv, float scale, int bf16, void* stream) {
+                                   int lddo, int lddk, int lddv, float scale, int bf16, float* dk_colpart, float* dv_colpart,
+                                   int ldp, void* stream) {
   if (!ds) return RP_EBADSHAPE;
   return attn_bwd_impl(q, k, v, dout, lse, delta, nullptr, dk, dv, Z, H, ldq, ldk, ldv, lddo, 4, lddk, lddv, scale, 1, bf16, stream,
-                       0, ds);
+                       0, ds, dk_colpart, dv_colpart, ldp);
 }
 extern "C" int rp_attn_bwd_dq(const float* q, const float* k, const float* v, const float* dout, const float* lse,
                               const float* delta, float* dq, int Z, int H, int ldq, int ldk, int ldv, int lddo, int lddq,
@@ -882,17 +913,18 @@ extern "C" int rp_attn_bwd_dq(const float* q, const float* k, const float* v, co
 // out[z][i][h*64 + d] = sum_j ds[z*H + h][i][j] * b[z ^ b_xor][j][h*64 + d]: the product that follows a stored-dS pass
 // (rp_attn_bwd_dkdv_ds: dQ = ds K;  rp_emm_grad_ds: dK = ds Q of the partner image, b_xor = 1), one launch for all Z*H problems
 extern "C" int rp_ds_matmul(const float* ds, const float* b, float* out, int Z, int H, int ldb, int ldo, int b_xor, int ds_bf16,
-                            void* stream) {
+                            float* colpart, int ldp, void* stream) {
   if (Z <= 0 || H <= 0 || !ds || !b || !out || (b_xor & ~1) || (b_xor && (Z & 1))) return RP_EBADSHAPE;
   if ((ldb | ldo) & 3) return RP_EALIGN;
+  if (colpart && ldp < H * 64) return RP_EBADSHAPE;
   const char* rv = getenv("RP_DSMM_REV");
-  DsMmP p{ds, b, out, H, ldb, ldo, b_xor, Z * H, rv ? rv[0] - '0' : 1};
+  DsMmP p{ds, b, out, H, ldb, ldo, b_xor, Z * H, rv ? rv[0] - '0' : 1, colpart, ldp};
   // RP_DSMM=16: the v_mfma_f32_16x16x4_f32 form (A/B aid; both run ~200 us per 128 images: the stream of fragment-shaped dS reads, not
   // the MFMA form, is what bounds this kernel -- profiles/r3_ds_matmul.txt)
   const char* ov = getenv("RP_DSMM");
   hipStream_t st = (hipStream_t)stream;
   if (ds_bf16) hipLaunchKernelGGL((ds_matmul_bf16_kernel<3>), dim3(xcd_grid(NTILE / 3, Z * H)), dim3(192), 0, st, p);
-  else if (ov && ov[0] == '1') hipLaunchKernelGGL((ds_matmul16_kernel<3>), dim3(xcd_grid(NTILE / 3, Z * H)), dim3(192), 0, st, p);
+  else if (ov && ov[0] == '1' && !colpart) hipLaunchKernelGGL((ds_matmul16_kernel<3>), dim3(xcd_grid(NTILE / 3, Z * H)), dim3(192), 0, st, p);
   else hipLaunchKernelGGL((ds_matmul_kernel<3>), dim3(xcd_grid(NTILE / 3, Z * H)), dim3(192), 0, st, p);
   RP_CHECK_LAUNCH();
   return RP_OK;

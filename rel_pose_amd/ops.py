@@ -738,18 +738,22 @@ def _ds_buffer(Z, like):
     return torch.empty(Z, HEADS, N_TOK, N_TOK, device=like.device, dtype=torch.bfloat16 if ATTN_BF16 else torch.float32)
 
 
-def ds_matmul(ds, b_base, ldb, out_base, ldo, Z, b_xor=0):
+def ds_matmul(ds, b_base, ldb, out_base, ldo, Z, b_xor=0, colpart_base=None, ldp=0):
     """out[z][i][h*64+d] = sum_j ds[z,h,i,j] b[z^b_xor][j][h*64+d]; b_base / out_base: device addresses of the first column.
-    ds: the tiled array a stored-dS pass wrote (fp32, or bf16 from the bf16 configuration's producers)."""
+    ds: the tiled array a stored-dS pass wrote (fp32, or bf16 from the bf16 configuration's producers).  colpart_base / ldp: device
+    address + row stride of a [Z*18, ldp] array that receives the column sums of `out` per 32-row block (a bias-gradient partial)."""
     lib = _lib.load()
     _chk_act(ds)
     bf = int(ds.dtype == torch.bfloat16)
     with timed("ds_matmul", 2.0 * Z * HEADS * N_TOK * N_TOK * 64, Z * HEADS * N_TOK * ((2.0 if bf else 4.0) * N_TOK + 4.0 * 128)):
-        _lib.check(lib.rp_ds_matmul(_p(ds), ctypes.c_void_p(b_base), ctypes.c_void_p(out_base), Z, HEADS, ldb, ldo, b_xor, bf, _st()),
-                   "rp_ds_matmul")
+        _lib.check(lib.rp_ds_matmul(_p(ds), ctypes.c_void_p(b_base), ctypes.c_void_p(out_base), Z, HEADS, ldb, ldo, b_xor, bf,
+                                    ctypes.c_void_p(colpart_base) if colpart_base else None, ldp, _st()), "rp_ds_matmul")
 
 
-def attn_bwd(qkv, o, lse, do, Z, fork=None, kv_xor=0):
+QKV_BIAS_FROM_PRODUCERS = os.environ.get("RP_QKV_BIAS_PARTIALS", "1") != "0"      # A/B aid
+
+
+def attn_bwd(qkv, o, lse, do, Z, fork=None, kv_xor=0, want_bias_partials=False):
     """dqkv of the fused attention.  With a _Fork the dQ pass runs on the side stream next to the dK/dV pass (they write
     disjoint column blocks of dqkv); the caller must fork.sync_main() before reading dqkv.
     kv_xor=1: backward of attn_fwd(..., k_xor=3) (keys/values from the partner image)."""
@@ -766,20 +770,27 @@ def attn_bwd(qkv, o, lse, do, Z, fork=None, kv_xor=0):
         _lib.check(lib.rp_attn_bwd_cross(P(b), P(b + 4 * DIM), P(b + 8 * DIM), _p(do), _p(lse), _p(delta), P(d),
                                          P(d + 4 * DIM), P(d + 8 * DIM), Z, HEADS, ld, ld, ld, DIM, ld, ld, ld, sc, 1, ATTN_BF16, _st()),
                    "rp_attn_bwd_cross")
-        return dqkv
+        return (dqkv, None) if want_bias_partials else dqkv
     if ATTN_BWD_STORE_DS and (fork is None or not fork.enabled):
         # the dK/dV pass stores scale*dS ([Z,H,576,576] in 32x32 tiles; fp32, bf16 in the bf16 configuration); dQ = dS K is then one
         # rp_ds_matmul: 5 executed GEMMs instead of 7 (the dQ pass would recompute S and dP) for 2 x 510 MB of extra HBM traffic
         ds = _ds_buffer(Z, qkv)
+        part = pb = None
+        if want_bias_partials and QKV_BIAS_FROM_PRODUCERS:
+            # [Z*18, 576]: column sums of dq | dk | dv per 32-row block, written by the epilogues of the two kernels below: the qkv bias
+            # gradient becomes a column sum over 2304 rows per 128 images instead of 73 728
+            part = _empty(Z * (N_TOK // 32), 3 * DIM, like=qkv)
+            pb = part.data_ptr()
         _lib.check(lib.rp_attn_bwd_dkdv_ds(P(b), P(b + 4 * DIM), P(b + 8 * DIM), _p(do), _p(lse), _p(delta), P(d + 4 * DIM),
-                                           P(d + 8 * DIM), _p(ds), Z, HEADS, ld, ld, ld, DIM, ld, ld, sc, ATTN_BF16, _st()),
+                                           P(d + 8 * DIM), _p(ds), Z, HEADS, ld, ld, ld, DIM, ld, ld, sc, ATTN_BF16,
+                                           P(pb + 4 * DIM) if pb else None, P(pb + 8 * DIM) if pb else None, 3 * DIM, _st()),
                    "rp_attn_bwd_dkdv_ds")
-        ds_matmul(ds, b + 4 * DIM, ld, d, ld, Z)                  # dQ = dS K: one streaming launch
-        return dqkv
+        ds_matmul(ds, b + 4 * DIM, ld, d, ld, Z, colpart_base=pb, ldp=3 * DIM)      # dQ = dS K: one streaming launch
+        return (dqkv, part) if want_bias_partials else dqkv
     if fork is None or not fork.enabled:
         _lib.check(lib.rp_attn_bwd(P(b), P(b + 4 * DIM), P(b + 8 * DIM), _p(do), _p(lse), _p(delta), P(d), P(d + 4 * DIM),
                                    P(d + 8 * DIM), Z, HEADS, ld, ld, ld, DIM, ld, ld, ld, sc, ATTN_BF16, _st()), "rp_attn_bwd")
-        return dqkv
+        return (dqkv, None) if want_bias_partials else dqkv
     fork.sync_side()                                   # delta (and do, dqkv allocation) visible to the side stream
 
     def dq_pass():
@@ -788,7 +799,7 @@ def attn_bwd(qkv, o, lse, do, Z, fork=None, kv_xor=0):
     fork.on_side(dq_pass)
     _lib.check(lib.rp_attn_bwd_dkdv(P(b), P(b + 4 * DIM), P(b + 8 * DIM), _p(do), _p(lse), _p(delta), P(d + 4 * DIM),
                                     P(d + 8 * DIM), Z, HEADS, ld, ld, ld, DIM, ld, ld, sc, ATTN_BF16, _st()), "rp_attn_bwd_dkdv")
-    return dqkv
+    return (dqkv, None) if want_bias_partials else dqkv
 
 
 def preprocess(images, pad=0):
@@ -1217,10 +1228,13 @@ class BlockFn(_Fn):
             fork.sync_side()
             dprojw = fork.on_side(lambda: linear_dw(dx1, o))
             do = linear_dx(dx1, proj_w)
-            dqkv = attn_bwd(qkv, o, lse, do, Z, fork, kv_xor=1 if ctx.cross else 0)
+            dqkv, bpart = attn_bwd(qkv, o, lse, do, Z, fork, kv_xor=1 if ctx.cross else 0, want_bias_partials=True)
             fork.sync_main()                                  # dQ pass (side) done before dqkv is consumed
             fork.sync_side()
-            dqkvw, dqkvb = _param_grads(fork, dqkv, xn1)
+            if bpart is not None:      # qkv bias gradient from the per-block column sums the attention backward's kernels left
+                dqkvw, dqkvb = fork.on_side(lambda: linear_dw(dqkv, xn1)), colsum(bpart)
+            else:
+                dqkvw, dqkvb = _param_grads(fork, dqkv, xn1)
             dx, dn1w, dn1b, dprojb = linear_dx_lnbwd(dqkv, qkv_w, x2, n1w, m1, r1, add=dx1)
             fork.sync_main()
         return (dx.view(Z, N_TOK, DIM), dn1w, dn1b, dqkvw, dqkvb, dprojw, dprojb, dn2w, dn2b, dfc1w, dfc1b, dfc2w,

@@ -354,6 +354,11 @@ def test_attention_fwd_bwd(ops, waves, monkeypatch):
         e = [rel(dqkv[:, i * 192:(i + 1) * 192], q64.grad[:, i * 192:(i + 1) * 192]) for i in range(3)]
         report("attn_bwd[store_ds=%d]" % store_ds, dq=e[0], dk=e[1], dv=e[2])
         assert max(e) < 2e-5
+    # the stored-dS kernels can also leave the column sums of dq | dk | dv per 32-row block (the qkv bias gradient's partials)
+    d2, part = ops.attn_bwd(qkv, o, lse, do, Z, want_bias_partials=True)
+    assert part.shape == (Z * 18, 576) and torch.equal(d2, ops.attn_bwd(qkv, o, lse, do, Z))
+    blocks = d2.double().view(Z * 18, 32, 576).sum(1)
+    assert rel(part, blocks) < 2e-6 and rel(part.double().sum(0), q64.grad.sum(0)) < 2e-5
 
 
 def test_cross_attention_is_attention_on_partner_keys_values(ops):

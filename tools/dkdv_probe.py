@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "lab", "libattn_probe.so"))
 P, I, F = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
-lib.rp_attn_bwd_dkdv_ds.argtypes = [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, F, I, P]
+lib.rp_attn_bwd_dkdv_ds.argtypes = [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, F, I, P, P, I, P]
 lib.rp_attn_bwd_dkdv_ds.restype = I
 Z = 128
 torch.manual_seed(0)
@@ -20,7 +20,7 @@ b, d = qkv.data_ptr(), dqkv.data_ptr()
 st = P(torch.cuda.current_stream().cuda_stream)
 def run():
     rc = lib.rp_attn_bwd_dkdv_ds(P(b), P(b + 4 * 192), P(b + 8 * 192), P(do.data_ptr()), P(lse.data_ptr()), P(delta.data_ptr()), P(d + 4 * 192),
-                                 P(d + 8 * 192), P(ds.data_ptr()), Z, 3, 576, 576, 576, 192, 576, 576, 0.125, int(os.environ.get("BF16", "0")), st)
+                                 P(d + 8 * 192), P(ds.data_ptr()), Z, 3, 576, 576, 576, 192, 576, 576, 0.125, int(os.environ.get("BF16", "0")), None, None, 0, st)
     assert rc == 0, rc
 for _ in range(3): run()
 torch.cuda.synchronize()

@@ -240,12 +240,16 @@ def main():
     ap.add_argument("--scope", default="full", choices=("full", "hot"),
                     help="full = images -> CNN -> hot path (the metric); hot = synthetic CNN maps -> hot path only "
                          "(kernel profiling; not the headline number)")
-    ap.add_argument("--timer-instance", default="1,1,1,3", help="gemm_kernel<aL,bL,TM,TN> instance timed for `roofline`")
+    ap.add_argument("--timer-instance", default=None,
+                    help="kernel timed for `roofline`: a gemm_kernel<aL,bL,TM,TN> instance (default 1,1,1,3, the weight-gradient GEMM) or a kernel "
+                         "tag of ops.timed (default with --mode fwd: mlp_fused_fwd, the dominant kernel of the forward)")
     ap.add_argument("--precision", default="fp32", choices=tuple(PRECISIONS),
                     help="how rp_gemm multiplies its fp32 operands: fp32 = exact v_mfma_f32_32x32x2_f32 (default); split3 = "
                          "three bf16 limbs per operand, six limb products on the bf16 MFMA pipe, fp32-grade results; "
                          "bf16 = operands rounded to bf16 (BASELINE.json configs[4]; NOT the headline metric)")
     args = ap.parse_args()
+    if args.timer_instance is None:
+        args.timer_instance = "mlp_fused_fwd" if (args.mode == "fwd" and args.precision == "fp32") else "1,1,1,3"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -405,7 +409,15 @@ def main():
                      3: "dense bf16 MFMA peak 2500 TF / 6 limb products per fp32 multiply-add (v_mfma_f32_32x32x16_bf16); "
                         "the same kernel is %.2f of the 157.3 TF fp32-MFMA peak it replaces" % (achieved / FP32_MFMA_PEAK_TFLOPS),
                      1: "dense bf16 MFMA peak"}[nl]
-        traffic, traffic_src = pmc_traffic(kname)     # PMC passes cannot run inside the timed process: tools/pmc_bench.sh
+        # PMC passes cannot run inside the timed process (tools/pmc_bench.sh); the committed passes of the matching operating point
+        # (64 pairs fp32 training / forward, 128 pairs bf16 training; bytes per launch of any other batch were not measured: null)
+        tfiles = None
+        if args.hw == 384:
+            if args.batch == 64 and nl == 0:
+                tfiles = TRAFFIC_FILES if train else ("r3_traffic_fwd.json",)
+            elif args.batch == 128 and nl == 1 and train:
+                tfiles = ("r3_traffic_bf16.json",)
+        traffic, traffic_src = pmc_traffic(kname, tfiles) if tfiles else (None, None)
         rec = {
             "metric": METRIC, "value": round(pairs / el, 2), "unit": "image-pairs/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 3),

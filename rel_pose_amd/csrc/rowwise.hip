@@ -287,7 +287,28 @@ __global__ __launch_bounds__(256) void rowdot96_kernel(const float* __restrict__
   if (lane == 0) out[row] = s;
 }
 
-// delta[z][h][i] = sum_e dO[z][i][h*64+e] * O[z][i][h*64+e]; one wave per (z,i,h)
+// delta[z][h][i] = sum_e dO[z][i][h*64+e] * O[z][i][h*64+e].  One wave per token row when the heads fill at most one wave of float4
+// (H <= 4: 16 lanes x 16 bytes per head, DPP row sums, no LDS; the ViT's H = 3 uses 48 lanes) -- 16-byte loads and a third of the waves
+// of the one-wave-per-(row, head) form below, which stays for wider layouts.
+__global__ __launch_bounds__(256) void attn_delta_rows_kernel(const float* __restrict__ dout, const float* __restrict__ o,
+                                                              float* __restrict__ delta, int H, int ld, long long rows) {
+  const long long zi = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);  // token row index z*576 + i
+  if (zi >= rows) return;
+  const int lane = threadIdx.x & 63, h = lane >> 4;
+  float s = 0.f;
+  if (h < H) {
+    const long long off = zi * ld + 4 * lane;                            // lane l holds columns 4l .. 4l+3 = head l / 16
+    const float4 a = *reinterpret_cast<const float4*>(dout + off), b = *reinterpret_cast<const float4*>(o + off);
+    s = (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
+  }
+  s = row16_sum(s);
+  if (h < H && (lane & 15) == 0) {
+    const long long z = zi / 576;
+    const int i = (int)(zi % 576);
+    delta[(z * H + h) * 576 + i] = s;
+  }
+}
+
 __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict__ dout, const float* __restrict__ o,
                                                          float* __restrict__ delta, int H, int ld, long long total) {
   const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);  // index over (z*576+i)*H + h
@@ -595,9 +616,12 @@ extern "C" int rp_rowdot96(const float* a, const float* b, float* out, long long
 
 extern "C" int rp_attn_bwd_delta(const float* dout, const float* o, float* delta, int Z, int H, int ld, void* stream) {
   if (Z <= 0 || H <= 0) return RP_EBADSHAPE;
-  const long long total = (long long)Z * 576 * H;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dout, o,
-                     delta, H, ld, total);
+  const long long total = (long long)Z * 576 * H, rows = (long long)Z * 576;
+  if (H <= 4 && (ld & 3) == 0)
+    hipLaunchKernelGGL(attn_delta_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dout, o, delta, H, ld, rows);
+  else
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dout, o,
+                       delta, H, ld, total);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }

@@ -245,19 +245,32 @@ __global__ __launch_bounds__(256) void emm_build_x_bwd_kernel(const float* __res
   dqkv[((long long)z * 576 + n) * ld + 384 + h * 64 + t] = dx[(((long long)z * H + h) * 576 + n) * 96 + t];
 }
 
-// g[z^1][c][h*70 + a] = sum_wg fp[z][h][wg][a][c]; zero pad to ldg
+// g[z^1][c][h*70 + a] = sum_wg fp[z][h][wg][a][c]; zero pad to ldg.  One workgroup per (z, h): the nwg partial 96 x 96 tiles are read
+// with 16-byte row-contiguous loads and summed in wg order, the 70 x 70 corner goes through LDS (padded rows) and leaves transposed --
+// rows of g are written 70 consecutive floats at a time.  Head 0's workgroup also writes the zero pad [H*70, ldg).
 __global__ __launch_bounds__(256) void emm_finalize_kernel(const float* __restrict__ fp, float* __restrict__ g, int H,
                                                            int ldg, int nwg) {
-  const int z = blockIdx.y, c = blockIdx.x;  // c in [0,70)
-  float* gr = g + ((long long)(z ^ 1) * 70 + c) * ldg;
-  for (int k = threadIdx.x; k < ldg; k += 256) {
-    float s = 0.f;
-    if (k < H * 70) {
-      const int h = k / 70, a = k % 70;
-      const float* f = fp + (((long long)z * H + h) * nwg) * 9216 + a * 96 + c;
-      for (int w = 0; w < nwg; ++w) s += f[(long long)w * 9216];
+  __shared__ float t[70][97];
+  const int z = blockIdx.y, h = blockIdx.x;
+  const float* f = fp + (((long long)z * H + h) * nwg) * 9216;
+  for (int e = threadIdx.x; e < 70 * 24; e += 256) {           // 70 rows x 24 float4
+    const int a = e / 24, c4 = (e % 24) * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int w = 0; w < nwg; ++w) {
+      const float4 v = *reinterpret_cast<const float4*>(f + (long long)w * 9216 + a * 96 + c4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
-    gr[k] = s;
+    t[a][c4] = s.x; t[a][c4 + 1] = s.y; t[a][c4 + 2] = s.z; t[a][c4 + 3] = s.w;
+  }
+  __syncthreads();
+  float* gz = g + (long long)(z ^ 1) * 70 * ldg;
+  for (int e = threadIdx.x; e < 70 * 70; e += 256) {
+    const int c = e / 70, a = e % 70;
+    gz[(long long)c * ldg + h * 70 + a] = t[a][c];
+  }
+  if (h == 0) {
+    const int padw = ldg - H * 70;
+    for (int e = threadIdx.x; e < 70 * padw; e += 256) gz[(long long)(e / padw) * ldg + H * 70 + e % padw] = 0.f;
   }
 }
 
@@ -273,18 +286,20 @@ __global__ __launch_bounds__(256) void emm_finalize_bwd_kernel(const float* __re
   }
 }
 
-// out[r] = sum_c a[r][c] b[r][c], C = 96; one wave per row pair... 32 lanes x 3
+// out[r] = sum_c a[r][c] b[r][c], C = 96: two rows per wave -- a 32-lane half holds one row as 24 float4 (16-byte loads), DPP row sums
+// + one cross-row exchange, no LDS
 __global__ __launch_bounds__(256) void rowdot96_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                        float* __restrict__ out, long long rows) {
-  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const int lane = threadIdx.x & 63;
-  const float* ar = a + row * 96;
-  const float* br = b + row * 96;
-  float s = ar[lane] * br[lane];
-  if (lane < 32) s += ar[64 + lane] * br[64 + lane];
-  s = wave_sum(s);
-  if (lane == 0) out[row] = s;
+  const int lane = threadIdx.x & 63, l31 = lane & 31;
+  const long long row = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + (lane >> 5);
+  float s = 0.f;
+  if (row < rows && l31 < 24) {
+    const float4 x = *reinterpret_cast<const float4*>(a + row * 96 + 4 * l31), y = *reinterpret_cast<const float4*>(b + row * 96 + 4 * l31);
+    s = (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
+  }
+  s = row16_sum(s);
+  s += __shfl_xor(s, 16, 64);
+  if (row < rows && l31 == 0) out[row] = s;
 }
 
 // delta[z][h][i] = sum_e dO[z][i][h*64+e] * O[z][i][h*64+e].  One wave per token row when the heads fill at most one wave of float4
@@ -594,7 +609,7 @@ extern "C" int rp_emm_build_x_bwd(const float* dx, float* dqkv, int Z, int H, in
 
 extern "C" int rp_emm_finalize(const float* f_part, float* g, int Z, int H, int ldg, void* stream) {
   if (Z <= 0 || (Z & 1) || H * 70 > ldg) return RP_EBADSHAPE;
-  hipLaunchKernelGGL(emm_finalize_kernel, dim3(70, Z), dim3(256), 0, (hipStream_t)stream, f_part, g, H, ldg, 6);
+  hipLaunchKernelGGL(emm_finalize_kernel, dim3(H, Z), dim3(256), 0, (hipStream_t)stream, f_part, g, H, ldg, 6);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }
@@ -608,7 +623,7 @@ extern "C" int rp_emm_finalize_bwd(const float* dg, float* df, int Z, int H, int
 
 extern "C" int rp_rowdot96(const float* a, const float* b, float* out, long long rows, void* stream) {
   if (rows <= 0) return RP_EBADSHAPE;
-  hipLaunchKernelGGL(rowdot96_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, b, out,
+  hipLaunchKernelGGL(rowdot96_kernel, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, (hipStream_t)stream, a, b, out,
                      rows);
   RP_CHECK_LAUNCH();
   return RP_OK;

@@ -214,6 +214,10 @@ def pick_split_k(M, N, K, a_layout=0, b_layout=0, target_wgs=768, min_ktiles=8, 
     # floor, not ceil: tiles * split must not spill past the resident slots (9 tiles x 86 splits = 774 workgroups on 768 slots
     # ran a second, nearly empty round: 173 vs 137 us); whole groups of 8 because split z is pinned to XCD z % 8
     sk = max(1, min(ktiles // min_ktiles, target_wgs // tiles, max_split))
+    if sk < 8:
+        # split z runs on XCD z % 8 only (csrc/gemm.hip: the sharers of a K chunk meet in one L2), so fewer than 8 splits leave whole
+        # XCDs idle: the regressor's [64,512] x [512,26880] input gradient took 74 us with 2 splits, 23.5 us with none
+        return 1
     return sk - sk % 8 if sk >= 16 else sk
 
 

@@ -113,7 +113,9 @@ def test_gemm_tile_and_splitk_selection():
     sk = ops.pick_split_k(576, 192, 73728, 1, 1)                # weight gradient: 9 tiles, 2304 k-tiles
     assert 64 <= sk <= 128
     assert ops.pick_split_k(64, 512, 26880) > 32                # regressor layer 0 at batch 64
-    assert ops.pick_split_k(64, 26880, 512) <= 2
+    assert ops.pick_split_k(64, 26880, 512) == 1                # its input gradient: 2 splits would run on 2 of the 8 XCDs only
+    assert all(ops.pick_split_k(m, n, k, a, b) in (1,) + tuple(range(8, 129)) for (m, n, k, a, b) in
+               ((6912, 192, 576, 0, 1), (64, 26880, 512, 0, 1), (192, 224, 8960, 1, 1), (512, 512, 64, 1, 1), (840, 192, 224, 0, 0)))
 
 
 def test_se3_algebra_and_loss():

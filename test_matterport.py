@@ -35,7 +35,7 @@ def load_model(args):
     return model.cuda().eval()
 
 
-def main():
+def main(argv=None):
     parser = argparse.ArgumentParser()
     parser.add_argument("--datapath")
     parser.add_argument("--weights")
@@ -44,7 +44,7 @@ def main():
     parser.add_argument("--ckpt")
     parser.add_argument("--gamma", type=float, default=0.9)
     parser.add_argument("--limit", type=int, default=0, help="evaluate only the first N pairs (0 = all)")
-    args = model_parser(parser).parse_args()
+    args = model_parser(parser).parse_args(argv)
     with open(os.path.join(args.datapath, "mp3d_planercnn_json/cached_set_test.json")) as f:
         dset = json.load(f)["data"]
     if args.limit:
@@ -52,7 +52,7 @@ def main():
     out_dir = os.path.join("output", args.exp, "matterport_test")
     print("performing evaluation on matterport_test set using model %s" % args.ckpt)
     model = load_model(args)
-    pt, pr, gt_t, gt_r = [], [], [], []
+    pt, pr, gt_t, gt_r, raw = [], [], [], [], []
     Gs = SE3(torch.tensor([[0, 0, 0, 0, 0, 0, 1.0]] * 2).unsqueeze(0).cuda())
     for entry in dset:
         names = [os.path.join(args.datapath, "/".join(str(entry[k]["file_name"]).split("/")[6:])) for k in ("0", "1")]
@@ -61,7 +61,8 @@ def main():
         intrinsics = torch.tensor([[[517.97, 517.97, 320, 240]] * 2], dtype=torch.float32).cuda()
         with torch.no_grad():
             est = model(images, Gs, intrinsics=intrinsics)
-        t, q = E.matterport_prediction(est[0][0][1].data.cpu().numpy())
+        raw.append(est[0][0][1].data.cpu().numpy())
+        t, q = E.matterport_prediction(raw[-1])
         pt.append(t)
         pr.append(q)
         gt_t.append(entry["rel_pose"]["position"])
@@ -71,6 +72,7 @@ def main():
         for k, v in metrics.items():
             print(k, v)
             print(k, v, file=f)
+    return metrics, {"raw": raw, "pred_tran": pt, "pred_rot": pr, "gt_tran": gt_t, "gt_rot": gt_r, "out_dir": out_dir}
 
 
 if __name__ == "__main__":

@@ -14,7 +14,7 @@ from rel_pose_amd.se3 import SE3
 from test_matterport import load_model, model_parser
 
 
-def main():
+def main(argv=None):
     parser = argparse.ArgumentParser()
     parser.add_argument("--datapath")
     parser.add_argument("--weights")
@@ -24,7 +24,7 @@ def main():
     parser.add_argument("--dataset", default="interiornet", choices=("interiornet", "streetlearn"))
     parser.add_argument("--gamma", type=float, default=0.9)
     parser.add_argument("--streetlearn_interiornet_type", default="", choices=("", "nooverlap", "T", "nooverlapT"))
-    args = model_parser(parser).parse_args()
+    args = model_parser(parser).parse_args(argv)
     with_t = args.streetlearn_interiornet_type == "T"
     meta = "metadata/%s%s/test_pair_%s.npy" % (args.dataset, "T" if with_t else "", "translation" if with_t else "rotation")
     out_name = "%s%s_test" % (args.dataset, "T" if with_t else "")
@@ -34,7 +34,7 @@ def main():
     print("performing evaluation on %s set using model %s" % (out_name, args.ckpt))
     model = load_model(args)
     Gs = SE3(torch.tensor([[0, 0, 0, 0, 0, 0, 1.0]] * 2).unsqueeze(0).cuda())
-    pred_q, gt_q = [], []
+    pred_q, gt_q, raw = [], [], []
     for i, item in sorted(dset.items())[:1000]:
         a, b = item["img1"], item["img2"]
         images = np.stack([imread_bgr(os.path.join(args.datapath, "data", folder, a["path"])),
@@ -43,13 +43,15 @@ def main():
         intrinsics = torch.full((1, 2, 4), 128.0).cuda()
         with torch.no_grad():
             est = model(images, Gs, intrinsics=intrinsics)
-        pred_q.append(est[0][0][1].data.cpu().numpy()[3:])
+        raw.append(est[0][0][1].data.cpu().numpy())
+        pred_q.append(raw[-1][3:])
         gt_q.append(relative_quaternion(a["x"], a["y"], b["x"], b["y"]))
     metrics = E.rotation_metrics_panorama(pred_q, gt_q, out_dir)
     with open(os.path.join(out_dir, "results.txt"), "w") as f:
         for k, v in metrics.items():
             print(k, v)
             print(k, v, file=f)
+    return metrics, {"raw": raw, "pred_rot": pred_q, "gt_rot": gt_q, "out_dir": out_dir}
 
 
 if __name__ == "__main__":

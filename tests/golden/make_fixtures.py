@@ -30,6 +30,10 @@ torch.Tensor.cuda = lambda self, *a, **k: self          # shim 1
 
 from oracle import relpose_oracle as O                   # noqa: E402  (closed-form generators only)
 from rel_pose_amd.modules import resnet as _rn           # noqa: E402
+import importlib.util as _ilu                            # noqa: E402
+_spec = _ilu.spec_from_file_location("_eval_cases", os.path.join(ROOT, "tests", "_eval_cases.py"))
+EC = _ilu.module_from_spec(_spec)                        # closed-form fake datasets / metric inputs shared with the tests
+_spec.loader.exec_module(EC)
 
 tv = types.ModuleType("torchvision")
 tvm = types.ModuleType("torchvision.models")
@@ -45,6 +49,12 @@ class SE3:                                               # shim 3
 
     def __getitem__(self, idx):
         return SE3(self.data[idx])
+
+    @staticmethod
+    def IdentityLike(other):                             # test_streetlearn_interiornet.py:220
+        d = torch.zeros_like(other.data)
+        d[..., 6] = 1
+        return SE3(d)
 
 
 lt = types.ModuleType("lietorch")
@@ -346,7 +356,141 @@ def demo_fixture():
     print("wrote reference_demo.npz:", out["demo_matterport_pred7_f32"])
 
 
+def _reference_script(name, argv, workdir):
+    """Execute one of the reference's evaluation SCRIPTS (everything under `if __name__ == '__main__'`) from the read-only
+    reference under the harness shims, in `workdir`, with the model class wrapped so that its raw outputs are recorded.
+    Returns the namespace after the run (predictions, camera_metrics, eval_camera ...).  Nothing of the script is stored."""
+    import ast
+    from PIL import Image
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    cv2 = types.ModuleType("cv2")
+    cv2.imread = lambda path: np.ascontiguousarray(np.asarray(Image.open(path).convert("RGB"))[:, :, ::-1])
+    sys.modules["cv2"] = cv2
+    torch.multiprocessing.set_start_method = lambda *a, **k: None
+    tree = ast.parse(open(os.path.join(REF, name)).read())
+    top = [n for n in tree.body if not isinstance(n, ast.If)]
+    body = [n for n in tree.body if isinstance(n, ast.If)][-1].body
+    ns = {"__name__": "reference_eval"}
+    exec(compile(ast.Module(body=top, type_ignores=[]), os.path.join(REF, name), "exec"), ns)
+    raw = []
+    RefModel = ns["ViTEss"]
+
+    class Recording(RefModel):
+        def forward(self, *a, **k):
+            out = super().forward(*a, **k)
+            raw.append(out[0].data[0, 1].detach().clone().numpy())
+            return out
+
+    ns["ViTEss"] = Recording
+    old_argv, old_cwd = sys.argv, os.getcwd()
+    sys.argv = [name] + argv
+    os.chdir(workdir)
+    try:
+        exec(compile(ast.Module(body=body, type_ignores=[]), os.path.join(REF, name), "exec"), ns)
+    finally:
+        sys.argv = old_argv
+        os.chdir(old_cwd)
+    ns["_raw_outputs"] = np.stack(raw)
+    return ns
+
+
+def _metric_arrays(prefix, metrics, out):
+    out[prefix + "_metric_names"] = np.array(list(metrics.keys()))
+    out[prefix + "_metric_values"] = np.array([float(v) for v in metrics.values()], dtype=np.float64)
+
+
+def metrics_fixture():
+    """the reference's OWN evaluation code -- test_matterport.py:27-68,117-164 and
+    test_streetlearn_interiornet.py:26-128,194-244 -- executed here (a) as whole scripts on closed-form fake datasets
+    (tests/_eval_cases.py) with the closed-form checkpoint, the reference model running on the CPU, and (b) function by
+    function on hand-made prediction sets with the edge cases.  Only what the reference PRODUCED is committed
+    (reference_metrics.npz): raw model outputs, the converted predictions / ground truths, metric values, the CSV / results files."""
+    import tempfile
+    out = {}
+    shapes = dict(O.vit_param_shapes())
+    shapes.update(O.cnn_param_shapes())
+    sd32 = O.make_state(shapes, torch.float32)
+    full = ViTEss(ref_args()).state_dict()
+    full.update(sd32)
+    tmp = tempfile.mkdtemp()
+    ck = os.path.join(tmp, "closed_form.pth")
+    torch.save({"model": {"module." + k: v for k, v in full.items()}}, ck)
+
+    # ---- (a1) test_matterport.py as a script --------------------------------------------------------------------------
+    root = os.path.join(tmp, "matterport_fake")
+    EC.write_matterport(root)
+    ns = _reference_script("test_matterport.py", ["--datapath", root, "--exp", "e0", "--ckpt", ck, "--fusion_transformer"], tmp)
+    P = ns["predictions"]["camera"]
+    out["mp_script_raw_outputs_f32"] = ns["_raw_outputs"].astype(np.float32)
+    out["mp_script_pred_tran"] = np.vstack(P["preds"]["tran"])
+    out["mp_script_pred_rot"] = np.vstack(P["preds"]["rot"])
+    out["mp_script_gt_tran"] = np.vstack(P["gts"]["tran"]).astype(np.float64)
+    out["mp_script_gt_rot"] = np.vstack(P["gts"]["rot"]).astype(np.float64)
+    _metric_arrays("mp_script", ns["camera_metrics"], out)
+    d = os.path.join(tmp, "output", "e0", "matterport_test")
+    for f in ("results.txt", "gt_translation_magnitude_vs_error.csv", "gt_rotation_magnitude_vs_error.csv"):
+        out["mp_script_file_" + f] = np.array(open(os.path.join(d, f)).read())
+    mp_eval = ns["eval_camera"]
+
+    # ---- (b1) eval_camera of test_matterport.py on the hand-made cases -----------------------------------------------
+    for name, c in EC.matterport_metric_cases().items():
+        ns["args"].exp = "k_" + name
+        os.makedirs(os.path.join(tmp, "output", ns["args"].exp, ns["output_folder"]), exist_ok=True)
+        pred = {"camera": {"preds": {"tran": list(c["pred_tran"]), "rot": list(c["pred_rot"])},
+                           "gts": {"tran": list(c["gt_tran"]), "rot": list(c["gt_rot"])}}}
+        cwd = os.getcwd()
+        os.chdir(tmp)
+        try:
+            m = mp_eval(pred)
+        finally:
+            os.chdir(cwd)
+        _metric_arrays("mp_case_" + name, m, out)
+        d = os.path.join(tmp, "output", ns["args"].exp, ns["output_folder"])
+        for f in ("gt_translation_magnitude_vs_error.csv", "gt_rotation_magnitude_vs_error.csv"):
+            out["mp_case_%s_file_%s" % (name, f)] = np.array(open(os.path.join(d, f)).read())
+
+    # ---- (a2) test_streetlearn_interiornet.py as a script (interiornet, rotation-only pairs) -------------------------
+    proot = os.path.join(tmp, "pano_fake")
+    split = EC.write_panorama(proot, "interiornet")
+    ns = _reference_script("test_streetlearn_interiornet.py",
+                           ["--datapath", proot, "--exp", "e1", "--ckpt", ck, "--dataset", "interiornet", "--fusion_transformer"], tmp)
+    P = ns["predictions"]["camera"]
+    out["pano_script_raw_outputs_f32"] = ns["_raw_outputs"].astype(np.float32)
+    out["pano_script_pred_rot"] = np.vstack(P["preds"]["rot"])
+    out["pano_script_gt_rot"] = np.vstack(P["gts"]["rot"]).astype(np.float64)
+    _metric_arrays("pano_script", ns["camera_metrics"], out)
+    d = os.path.join(tmp, "output", "e1", "interiornet_test")
+    for f in ("results.txt", "all_rotation_err_degrees.csv", "all_gt_rot_degrees.csv"):
+        out["pano_script_file_" + f] = np.array(open(os.path.join(d, f)).read())
+    # the ground-truth construction alone, on more viewpoints than the 5 pairs of the fake split (compute_gt_rmat, :124-128)
+    vp = O.hash_uniform(4 * 32, 123).reshape(32, 4) * np.array([1.5, 3.1, 1.5, 3.1])
+    from scipy.spatial.transform import Rotation as _R
+    gq = []
+    for x1, y1, x2, y2 in vp:
+        m = ns["compute_gt_rmat"](torch.tensor([[x1]]), torch.tensor([[y1]]), torch.tensor([[x2]]), torch.tensor([[y2]]), 1)
+        gq.append(_R.from_matrix(m).as_quat()[0])
+    out["pano_gt_quat_for_viewpoints"] = np.stack(gq)
+
+    # ---- (b2) eval_camera of test_streetlearn_interiornet.py on the hand-made cases -----------------------------------
+    for name, c in EC.panorama_metric_cases().items():
+        d = os.path.join(tmp, "k_pano_" + name)
+        os.makedirs(d, exist_ok=True)
+        pred = {"camera": {"preds": {"rot": list(c["pred_rot"])}, "gts": {"rot": list(c["gt_rot"])}}}
+        m = ns["eval_camera"](pred, d)
+        _metric_arrays("pano_case_" + name, m, out)
+        for f in ("all_rotation_err_degrees.csv", "all_gt_rot_degrees.csv"):
+            out["pano_case_%s_file_%s" % (name, f)] = np.array(open(os.path.join(d, f)).read())
+
+    np.savez_compressed(os.path.join(HERE, "reference_metrics.npz"), **out)
+    print("wrote reference_metrics.npz: %d arrays, %.1f KB" % (len(out), os.path.getsize(os.path.join(HERE, "reference_metrics.npz")) / 1024))
+    for k in ("mp_script", "pano_script"):
+        print(k, dict(zip(out[k + "_metric_names"].tolist(), out[k + "_metric_values"].tolist())))
+
+
 if __name__ == "__main__":
+    if "--metrics-only" in sys.argv:
+        metrics_fixture()
+        sys.exit(0)
     if "--demo-only" in sys.argv:
         demo_fixture()
         sys.exit(0)
@@ -354,3 +498,4 @@ if __name__ == "__main__":
         main()
     noess_fixtures()
     demo_fixture()
+    metrics_fixture()

@@ -205,3 +205,91 @@ def test_panorama_rotation_metrics_known_answers(tmp_path):
     assert np.isclose(m["rotation_geodesic_error_overlap_large/10deg"], 0.5)
     assert np.isclose(m["rotation_geodesic_error_overlap_small/median"], 19.0, atol=1e-4)   # 45 <= gt < 90: errors 8, 30
     assert np.loadtxt(tmp_path / "o" / "all_rotation_err_degrees.csv").shape == (4,)         # the 120-degree pair is dropped
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# SURVEY 8f row 4 pinned against the REFERENCE's own evaluation code: tests/golden/reference_metrics.npz holds what
+# test_matterport.py / test_streetlearn_interiornet.py of the reference produced (executed by tests/golden/make_fixtures.py
+# in the build container) on the closed-form inputs of tests/_eval_cases.py.
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def ref_metrics():
+    here = os.path.dirname(os.path.abspath(__file__))
+    return np.load(os.path.join(here, "golden", "reference_metrics.npz"))
+
+
+def _same_metrics(got, ref, prefix, tol=0.0):
+    names = ref[prefix + "_metric_names"].tolist()
+    vals = ref[prefix + "_metric_values"]
+    assert list(got.keys()) == names, (list(got.keys()), names)                       # same keys in the same order
+    for n, v in zip(names, vals):
+        assert abs(float(got[n]) - v) <= tol * max(1.0, abs(v)), (prefix, n, float(got[n]), v)
+
+
+def test_matterport_metrics_equal_the_references_eval_camera(ref_metrics, tmp_path):
+    from tests import _eval_cases as EC
+    for name, c in EC.matterport_metric_cases().items():
+        out = str(tmp_path / name)
+        m = E.camera_metrics_matterport(list(c["pred_tran"]), list(c["pred_rot"]), list(c["gt_tran"]), list(c["gt_rot"]), out)
+        _same_metrics(m, ref_metrics, "mp_case_" + name)                               # same numpy arithmetic: bit-identical
+        for f in ("gt_translation_magnitude_vs_error.csv", "gt_rotation_magnitude_vs_error.csv"):
+            assert open(os.path.join(out, f)).read() == str(ref_metrics["mp_case_%s_file_%s" % (name, f)]), (name, f)
+
+
+def test_matterport_script_conversions_equal_the_references(ref_metrics, tmp_path):
+    """the per-sample conversions of test_matterport.py:138-156 (w-positive ground truth; w back in front and metres again for
+    the prediction) and the metrics / files of the whole run, from the raw model outputs the reference's model produced"""
+    from tests import _eval_cases as EC
+    data = EC.matterport_entries()
+    raw = ref_metrics["mp_script_raw_outputs_f32"]
+    pt, pr, gt_t, gt_r = [], [], [], []
+    for e, r in zip(data, raw):
+        t, q = E.matterport_prediction(r)
+        pt.append(t)
+        pr.append(q)
+        gt_t.append(e["rel_pose"]["position"])
+        gt_r.append(E.matterport_gt_rotation(e["rel_pose"]["rotation"]))
+    assert np.array_equal(np.vstack(pt), ref_metrics["mp_script_pred_tran"])
+    assert np.array_equal(np.vstack(pr), ref_metrics["mp_script_pred_rot"])
+    assert np.array_equal(np.vstack(gt_t), ref_metrics["mp_script_gt_tran"])
+    assert np.array_equal(np.vstack(gt_r), ref_metrics["mp_script_gt_rot"])
+    assert (ref_metrics["mp_script_gt_rot"][:, 0] >= 0).all()
+    out = str(tmp_path / "o")
+    m = E.camera_metrics_matterport(pt, pr, gt_t, gt_r, out)
+    _same_metrics(m, ref_metrics, "mp_script")
+    for f in ("gt_translation_magnitude_vs_error.csv", "gt_rotation_magnitude_vs_error.csv"):
+        assert open(os.path.join(out, f)).read() == str(ref_metrics["mp_script_file_" + f])
+    text = "".join("%s %s\n" % (k, v) for k, v in m.items())                          # what the script prints into results.txt
+    assert text == str(ref_metrics["mp_script_file_results.txt"])
+
+
+def test_panorama_metrics_equal_the_references_eval_camera(ref_metrics, tmp_path):
+    from tests import _eval_cases as EC
+    for name, c in EC.panorama_metric_cases().items():
+        out = str(tmp_path / name)
+        m = E.rotation_metrics_panorama(list(c["pred_rot"]), list(c["gt_rot"]), out)
+        _same_metrics(m, ref_metrics, "pano_case_" + name)
+        for f in ("all_rotation_err_degrees.csv", "all_gt_rot_degrees.csv"):
+            assert open(os.path.join(out, f)).read() == str(ref_metrics["pano_case_%s_file_%s" % (name, f)]), (name, f)
+    assert len(ref_metrics["pano_case_none_metric_names"]) == 0                        # both buckets empty: the reference returns {}
+
+
+def test_panorama_script_ground_truth_and_metrics_equal_the_references(ref_metrics, tmp_path):
+    """ground-truth quaternions as test_streetlearn_interiornet.py:53-69,124-128,204-211 builds them (float32 viewpoint matrices ->
+    scipy), on the fake split and on 32 more viewpoint pairs; metrics and files of the whole run from the reference's raw outputs"""
+    from oracle import relpose_oracle as O
+    from tests import _eval_cases as EC
+    split = EC.panorama_entries()
+    gt = [V.relative_quaternion(e["img1"]["x"], e["img1"]["y"], e["img2"]["x"], e["img2"]["y"]) for _, e in sorted(split.items())]
+    assert np.array_equal(np.vstack(gt), ref_metrics["pano_script_gt_rot"])
+    vp = O.hash_uniform(4 * 32, 123).reshape(32, 4) * np.array([1.5, 3.1, 1.5, 3.1])
+    assert np.array_equal(np.stack([V.relative_quaternion(*v) for v in vp]), ref_metrics["pano_gt_quat_for_viewpoints"])
+    raw = ref_metrics["pano_script_raw_outputs_f32"]
+    pred = [r[3:] for r in raw]
+    assert np.array_equal(np.vstack(pred), ref_metrics["pano_script_pred_rot"])
+    out = str(tmp_path / "o")
+    m = E.rotation_metrics_panorama(pred, gt, out)
+    _same_metrics(m, ref_metrics, "pano_script")
+    for f in ("all_rotation_err_degrees.csv", "all_gt_rot_degrees.csv"):
+        assert open(os.path.join(out, f)).read() == str(ref_metrics["pano_script_file_" + f])
+    assert "".join("%s %s\n" % (k, v) for k, v in m.items()) == str(ref_metrics["pano_script_file_results.txt"])

@@ -269,3 +269,69 @@ def test_graphed_train_step_matches_the_eager_step():
     assert losses["graph"][-1] != losses["graph"][0]                      # the replayed optimiser really moves the weights
     for a, b in zip(losses["eager"][2:], losses["graph"]):
         assert abs(a - b) <= 2e-3 * abs(a), losses
+
+
+def _closed_form_checkpoint(path):
+    import types
+    import torch
+    from oracle import relpose_oracle as O
+    from rel_pose_amd.model import ViTEss
+    shapes = dict(O.vit_param_shapes())
+    shapes.update(O.cnn_param_shapes())
+    sd32 = O.make_state(shapes, torch.float32)
+    args = types.SimpleNamespace(noess="", pool_size=60, fc_hidden_size=512, fusion_transformer=True, transformer_depth=6,
+                                 cross_features=False, use_single_softmax=False, no_pos_encoding=False, l1_pos_encoding=False)
+    full = ViTEss(args).state_dict()
+    full.update(sd32)
+    torch.save({"model": {"module." + k: v for k, v in full.items()}, "optimizer": {}, "scheduler": {}}, path)
+
+
+def _metrics_close(got, ref, prefix, tol):
+    import numpy as np
+    names = ref[prefix + "_metric_names"].tolist()
+    assert list(got.keys()) == names
+    worst = 0.0
+    for n, v in zip(names, ref[prefix + "_metric_values"]):
+        worst = max(worst, abs(float(got[n]) - v) / max(1.0, abs(v)))
+    assert worst <= tol, (prefix, worst)
+    return worst
+
+
+def test_evaluation_scripts_reproduce_the_references_runs(tmp_path, monkeypatch):
+    """SURVEY 8f row 4 end to end: this repo's test_matterport.py / test_streetlearn_interiornet.py on the closed-form fake datasets
+    (tests/_eval_cases.py) with the closed-form checkpoint, HIP model, against what the REFERENCE's scripts produced on the same
+    files with the reference model on the CPU (tests/golden/reference_metrics.npz): raw model outputs (<= 1e-4 of max|ref|, the
+    north_star R,t bound), converted predictions, ground truths (bit-identical: host arithmetic), every metric (<= 1e-4)."""
+    import numpy as np
+    from tests import _eval_cases as EC
+    sys.path.insert(0, ROOT)
+    import test_matterport
+    import test_streetlearn_interiornet
+    ref = np.load(os.path.join(ROOT, "tests", "golden", "reference_metrics.npz"))
+    ck = str(tmp_path / "closed_form.pth")
+    _closed_form_checkpoint(ck)
+    monkeypatch.chdir(tmp_path)
+    root = str(tmp_path / "matterport_fake")
+    EC.write_matterport(root)
+    m, p = test_matterport.main(["--datapath", root, "--exp", "e0", "--ckpt", ck, "--fusion_transformer"])
+    raw_ref = ref["mp_script_raw_outputs_f32"]
+    e_raw = float(np.abs(np.stack(p["raw"]) - raw_ref).max() / np.abs(raw_ref).max())
+    assert np.array_equal(np.vstack(p["gt_rot"]), ref["mp_script_gt_rot"]) and np.array_equal(np.vstack(p["gt_tran"]), ref["mp_script_gt_tran"])
+    e_pt = float(np.abs(np.vstack(p["pred_tran"]) - ref["mp_script_pred_tran"]).max())
+    e_m = _metrics_close(m, ref, "mp_script", 1e-4)
+    assert e_raw < 1e-4 and e_pt < 5e-4 and np.vstack(p["pred_tran"]).dtype == np.float32
+    proot = str(tmp_path / "pano_fake")
+    EC.write_panorama(proot, "interiornet")
+    m2, p2 = test_streetlearn_interiornet.main(["--datapath", proot, "--exp", "e1", "--ckpt", ck, "--dataset", "interiornet", "--fusion_transformer"])
+    raw_ref2 = ref["pano_script_raw_outputs_f32"]
+    e_raw2 = float(np.abs(np.stack(p2["raw"]) - raw_ref2).max() / np.abs(raw_ref2).max())
+    assert np.array_equal(np.vstack(p2["gt_rot"]), ref["pano_script_gt_rot"])
+    e_m2 = _metrics_close(m2, ref, "pano_script", 1e-4)
+    assert e_raw2 < 1e-4
+    for f in ("results.txt", "all_rotation_err_degrees.csv", "all_gt_rot_degrees.csv"):
+        assert os.path.exists(os.path.join(p2["out_dir"], f))
+    assert open(os.path.join(p2["out_dir"], "all_gt_rot_degrees.csv")).read() == str(ref["pano_script_file_all_gt_rot_degrees.csv"])
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "test_report.txt"), "a") as f:
+        f.write("eval_scripts_vs_reference_runs: matterport raw=%.2e pred_t=%.2e metrics=%.2e | interiornet raw=%.2e metrics=%.2e\n"
+                % (e_raw, e_pt, e_m, e_raw2, e_m2))

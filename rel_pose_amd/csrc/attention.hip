@@ -829,7 +829,7 @@ extern "C" int rp_attn_fwd(const float* q, const float* k, const float* v, float
   if (!stats_only && ((ldv | ldo) & 3)) return RP_EALIGN;
   AttnP p{q, k, v, o, lse, H, ldq, ldk, ldv, ldo, q_xor, k_xor, scale, Z * H, nullptr};
   hipStream_t st = (hipStream_t)stream;
-  const char* ov = getenv("RP_ATTN_FWD");   // tuning aid: "<NW><WPS>", e.g. "32"
+  static const char* const ov = getenv("RP_ATTN_FWD");   // tuning aid: "<NW><WPS>", e.g. "32"
   // few problems (small batches): one-wave workgroups -- with <= two 2-wave workgroups per CU every workgroup's 18-tile
   // loop runs alone on its SIMDs and the launch takes one loop latency; twice as many half-size workgroups interleave (12 images:
   // 78 -> 52 us, dK/dV pass 156 -> 104 us)
@@ -874,7 +874,7 @@ static int attn_bwd_impl(const float* q, const float* k, const float* v, const f
              dk_colpart, dv_colpart, ldp};
   // both passes need ~190-240 VGPRs (2 waves/SIMD = 8 wave slots per CU): 2-wave workgroups pack 4 per CU, 3-wave ones only 2
   if (bf16) return launch_bwd<2, true>(p, Z, H, which, (hipStream_t)stream);
-  const char* ov = getenv("RP_ATTN_NW");
+  static const char* const ov = getenv("RP_ATTN_NW");
   if (ov && ov[0] == '3') return launch_bwd<3, false>(p, Z, H, which, (hipStream_t)stream);
   if ((ov && ov[0] == '1') || (!ov && Z * H * (NTILE / 2) <= 512)) return launch_bwd<1, false>(p, Z, H, which, (hipStream_t)stream);
   return launch_bwd<2, false>(p, Z, H, which, (hipStream_t)stream);
@@ -917,11 +917,11 @@ extern "C" int rp_ds_matmul(const float* ds, const float* b, float* out, int Z, 
   if (Z <= 0 || H <= 0 || !ds || !b || !out || (b_xor & ~1) || (b_xor && (Z & 1))) return RP_EBADSHAPE;
   if ((ldb | ldo) & 3) return RP_EALIGN;
   if (colpart && ldp < H * 64) return RP_EBADSHAPE;
-  const char* rv = getenv("RP_DSMM_REV");
+  static const char* const rv = getenv("RP_DSMM_REV");
   DsMmP p{ds, b, out, H, ldb, ldo, b_xor, Z * H, rv ? rv[0] - '0' : 1, colpart, ldp};
   // RP_DSMM=16: the v_mfma_f32_16x16x4_f32 form (A/B aid; both run ~200 us per 128 images: the stream of fragment-shaped dS reads, not
   // the MFMA form, is what bounds this kernel -- profiles/r3_ds_matmul.txt)
-  const char* ov = getenv("RP_DSMM");
+  static const char* const ov = getenv("RP_DSMM");
   hipStream_t st = (hipStream_t)stream;
   if (ds_bf16) hipLaunchKernelGGL((ds_matmul_bf16_kernel<3>), dim3(xcd_grid(NTILE / 3, Z * H)), dim3(192), 0, st, p);
   else if (ov && ov[0] == '1' && !colpart) hipLaunchKernelGGL((ds_matmul16_kernel<3>), dim3(xcd_grid(NTILE / 3, Z * H)), dim3(192), 0, st, p);

@@ -448,6 +448,11 @@ extern "C" int rp_gemm(const RpGemm* g, void* stream) {
     if (g->precision != 1 || batch > 1 || (p.io_bf16 & ~7)) return RP_EUNSUPPORTED;
     if ((p.io_bf16 & 2) && (split > 1 || g->ln_x || g->residual || (g->N & 3) || (g->a_layout == 1 && g->b_layout == 1))) return RP_EUNSUPPORTED;
     if ((p.io_bf16 & 4) && !g->aux) return RP_EBADSHAPE;
+    // bits 1 (bf16 C / pre_out) and 2 (bf16 aux) are only honoured by the LDS-staged epilogue: a combination that falls to the
+    // generic per-element epilogue (act without bias, dact with bias, ...) or to the split-K reduce kernel would write 4-byte
+    // floats into a 2-byte-per-element C, or read a bf16 aux as fp32
+    if ((p.io_bf16 & 6) && (p.epi_mode == EPI_GENERIC || (g->a_layout == 1 && g->b_layout == 1))) return RP_EUNSUPPORTED;
+    if ((p.io_bf16 & 4) && split > 1) return RP_EUNSUPPORTED;
   }
   const bool lnbwd = g->ln_x != nullptr;
   if (lnbwd) {
@@ -481,7 +486,7 @@ extern "C" int rp_gemm(const RpGemm* g, void* stream) {
   // (64-row tiles for the ragged batched 576-row products -- dQ = dS K, the EMM's 576x96 blocks -- were measured and are
   // NOT faster: those launches are bound by the 170 MB dS read (4.9 TB/s), the half-empty fifth row panel is free)
   if (lnbwd) { tm = 1; tn = 3; }                   // whole 192-wide rows in one workgroup
-  else if (const char* ov = getenv("RP_GEMM_TILE")) {   // tuning aid only: "TM,TN"
+  else if (static const char* const ov = getenv("RP_GEMM_TILE"); ov) {   // tuning aid only: "TM,TN" (read once per process)
     if (ov[0] >= '1' && ov[0] <= '2' && ov[1] == ',' && ov[2] >= '1' && ov[2] <= '3') { tm = ov[0] - '0'; tn = ov[2] - '0'; }
   }
   if (p.colsum_part && (tn == 3 || p.epi_mode == EPI_GENERIC)) return RP_EUNSUPPORTED;   // needs the staged epilogue, 64 % (8 TN) == 0

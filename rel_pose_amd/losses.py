@@ -44,8 +44,55 @@ def geodesic_loss_tensors_torch(Ps, Gs):
     return tau.norm(dim=-1).mean(), phi.norm(dim=-1).mean()
 
 
+class LazyMetrics(dict):
+    """The reference's metrics dict ({name: python float}, src/geom/losses.py:16-19) whose floats are only fetched from the device
+    when somebody LOOKS at them: the reference's two `.item()` calls per step are two host syncs per step, which at its own batch
+    of 6 pairs per GPU serialise the host enqueue time with the kernels.  train.py prints the metrics every 20
+    steps; the other 19 never synchronise.  Behaves as a plain dict for every read access."""
+
+    def __init__(self, tensors):
+        super().__init__(tensors)
+        self._pending = True
+
+    def _fetch(self):
+        if self._pending:
+            self._pending = False
+            for k in list(dict.keys(self)):
+                v = dict.__getitem__(self, k)
+                dict.__setitem__(self, k, v.item() if hasattr(v, "item") else v)
+
+    def __getitem__(self, k):
+        self._fetch()
+        return dict.__getitem__(self, k)
+
+    def get(self, k, default=None):
+        self._fetch()
+        return dict.get(self, k, default)
+
+    def items(self):
+        self._fetch()
+        return dict.items(self)
+
+    def values(self):
+        self._fetch()
+        return dict.values(self)
+
+    def copy(self):
+        self._fetch()
+        return dict(self)
+
+    def __repr__(self):
+        self._fetch()
+        return dict.__repr__(self)
+
+    __str__ = __repr__
+
+    def __reduce__(self):
+        self._fetch()
+        return (dict, (dict(dict.items(self)),))
+
+
 def geodesic_loss(Ps, Gs, train_val="train"):
     loss_tr, loss_rot = geodesic_loss_tensors(Ps, Gs)
-    metrics = {train_val + "_geo_loss_tr": loss_tr.detach().item(),
-               train_val + "_geo_loss_rot": loss_rot.detach().item()}
+    metrics = LazyMetrics({train_val + "_geo_loss_tr": loss_tr.detach(), train_val + "_geo_loss_rot": loss_rot.detach()})
     return loss_tr, loss_rot, metrics

@@ -287,9 +287,10 @@ class timed:
 TIMER = None
 
 # ------------------------------------------------------------------------------------------------
-# deferred split-K reduces: inside `with splitk_batch():` every plain split-K product (the weight-gradient GEMMs) launches only its
-# main kernel into a private slab region and the block ends with ONE rp_splitk_reduce_multi (bit-identical to the per-GEMM reduce).
-# The outputs are only FILLED at exit: return them, do not compute with them inside the block.
+# deferred split-K reduces: inside `with splitk_batch():` a split-K product that ASKS for it (gemm(..., defer=True): the weight-gradient
+# GEMMs of linear_dw) launches only its main kernel into a private slab region and the block ends with ONE rp_splitk_reduce_multi
+# (bit-identical to the per-GEMM reduce).  Those outputs are only FILLED at exit: return them, do not compute with them inside the
+# block.  Every other split-K gemm() inside the block reduces immediately as usual.  Blocks do not nest (one arena per stream).
 # ------------------------------------------------------------------------------------------------
 SPLITK_BATCHING = os.environ.get("RP_SPLITK_BATCH", "1") == "1"
 _SPLITK_BATCH = None
@@ -314,6 +315,8 @@ class splitk_batch:
     def __enter__(self):
         global _SPLITK_BATCH
         st = torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else None
+        if _SPLITK_BATCH is not None:
+            raise RuntimeError("splitk_batch blocks do not nest: the inner block would reuse the outer block's slab arena")
         self.prev, _SPLITK_BATCH = _SPLITK_BATCH, (([], [0], st) if SPLITK_BATCHING else None)
         return self
 
@@ -339,7 +342,7 @@ def gemm_instance(M, N, a_layout, b_layout, reads_mn=False):
 
 def gemm(A, B, M, N, K, *, a_layout=0, b_layout=0, lda=None, ldb=None, out=None, ldc=None, bias=None, act=0,
          pre_out=None, dact=0, aux=None, residual=None, split_k=None, batch=1, strides=(0, 0, 0), trans_c=False,
-         precision=None, want_colsum=False, ln=None, out_dtype=None):
+         precision=None, want_colsum=False, ln=None, out_dtype=None, defer=False):
     """C[M,N] = epilogue(op(A) op(B)); see RpGemm in include/relpose_hip.h.
     ln = (x, mean, rstd, gamma, part): LayerNorm backward fused into the epilogue (RpGemm.ln_*).
     bf16 storage (RpGemm.io_bf16, operand precision 1 only): A and aux may be bf16 tensors; out_dtype=torch.bfloat16 makes C (and
@@ -362,6 +365,21 @@ def gemm(A, B, M, N, K, *, a_layout=0, b_layout=0, lda=None, ldb=None, out=None,
             raise RuntimeError("rp_gemm operand: expected a contiguous %s GPU tensor, got %s %s" % (want, t.device, t.dtype))
     if io and (GEMM_PRECISION if precision is None else precision) != 1:
         raise RuntimeError("bf16-stored GEMM operands need operand precision 1 (the bf16 configuration)")
+    if io & 6:
+        # mirrors rp_gemm: a bf16 C / pre_out / aux is only honoured by the LDS-staged epilogue modes, never by the generic
+        # per-element epilogue or the split-K reduce
+        if dact == 0:
+            staged = ((act == 0 and pre_out is None) or (act == 1 and bias is not None and residual is None)
+                      or (act == 2 and bias is not None and residual is None and pre_out is None))
+        else:
+            staged = bias is None and pre_out is None and residual is None and act == 0 and aux is not None
+        if not staged or (a_layout == 1 and b_layout == 1):
+            raise RuntimeError("bf16-stored C / pre_out / aux: unsupported epilogue (act=%d dact=%d bias=%s pre_out=%s residual=%s) "
+                               "or layout" % (act, dact, bias is not None, pre_out is not None, residual is not None))
+        if (io & 4) and split_k is not None and split_k > 1:
+            raise RuntimeError("bf16-stored aux cannot be combined with split-K")
+        if split_k is None:
+            split_k = 1              # (the staged modes are forward / input-gradient shapes; never auto-split a bf16-output product)
     if lda is None:
         lda = K if a_layout == 0 else M
     if ldb is None:
@@ -384,7 +402,7 @@ def gemm(A, B, M, N, K, *, a_layout=0, b_layout=0, lda=None, ldb=None, out=None,
     if split_k > 1:
         nbytes = lib.rp_gemm_workspace_bytes(M, N, split_k)
         plain = bias is None and pre_out is None and aux is None and residual is None and act == 0 and dact == 0 and ln is None
-        if (_SPLITK_BATCH is not None and plain and not want_colsum
+        if (defer and _SPLITK_BATCH is not None and plain and not want_colsum
                 and torch.cuda.current_stream(A.device).cuda_stream == _SPLITK_BATCH[2]):       # (not under fork.on_side)
             ws = _arena_take(nbytes, A.device, _SPLITK_BATCH[1])
             g.defer_reduce = 1
@@ -625,8 +643,8 @@ def linear_dw(dy, x):
         # the split-K reduce write the transpose
         sk = max(2, pick_split_k(K, N, M, 1, 1))
         out = _empty(N, K, like=dy)
-        return gemm(x, dy, K, N, M, a_layout=1, b_layout=1, out=out, ldc=K, split_k=sk, trans_c=True)
-    return gemm(dy, x, N, K, M, a_layout=1, b_layout=1)
+        return gemm(x, dy, K, N, M, a_layout=1, b_layout=1, out=out, ldc=K, split_k=sk, trans_c=True, defer=True)
+    return gemm(dy, x, N, K, M, a_layout=1, b_layout=1, defer=True)
 
 
 COLSUM_BATCHING = os.environ.get("RP_COLSUM_BATCH", "1") == "1"      # A/B aid

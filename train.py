@@ -140,10 +140,12 @@ def run(args):
         smp = (torch.utils.data.distributed.DistributedSampler(db, num_replicas=world, rank=rank, shuffle=is_training)
                if ddp else None)
         # every rank runs its own worker pool: cap it so that the ranks of this node together do not oversubscribe the host cores
-        nw = parallel.loader_workers(args.num_workers, world if ddp else 1)
+        # (ranks on THIS node: under a multi-node launch the global world size would halve every rank's share)
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", min(world, torch.cuda.device_count() or 1))) if ddp else 1
+        nw = parallel.loader_workers(args.num_workers, local_world)
         if nw < args.num_workers and rank == 0 and subepoch == 0:
             print("note: --num_workers %d capped to %d per rank (%d ranks share this host's cores; ~14 decode cores feed one GPU, "
-                  "README.md)" % (args.num_workers, nw, world if ddp else 1))
+                  "README.md)" % (args.num_workers, nw, local_world))
         ld = torch.utils.data.DataLoader(db, batch_size=args.batch, sampler=smp, shuffle=(smp is None and is_training),
                                          num_workers=nw, pin_memory=True, drop_last=is_training)
         return ld, smp, is_training
@@ -245,10 +247,11 @@ if __name__ == "__main__":
             f.write("%s  %s\n" % (k, v))
     if a.resnet_weights:
         os.environ["RELPOSE_RESNET18_WEIGHTS"] = a.resnet_weights
-    if "WORLD_SIZE" not in os.environ and not a.no_ddp and torch.cuda.is_available() and a.gpus > torch.cuda.device_count():
-        # the reference would fail in mp.spawn here; a default of 4 on a smaller box is more useful clamped (deviation, stated)
-        print("note: --gpus %d but %d GPU(s) visible: running %d rank(s)" % (a.gpus, torch.cuda.device_count(), torch.cuda.device_count()))
-        a.gpus = torch.cuda.device_count()
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if "WORLD_SIZE" not in os.environ and not a.no_ddp and a.gpus > max(ndev, 1):
+        # the reference would fail in mp.spawn here; a default of 4 on a smaller (or GPU-less) box is more useful clamped (deviation, stated)
+        print("note: --gpus %d but %d GPU(s) visible: running %d rank(s)" % (a.gpus, ndev, max(ndev, 1)))
+        a.gpus = max(ndev, 1)
     if "WORLD_SIZE" in os.environ or a.no_ddp or a.gpus <= 1:
         run(a)                      # under a launcher (one rank per process already), or a single GPU
     else:

@@ -36,8 +36,8 @@ extern "C" {
  * functions this header declares.  rp_abi_version() / rp_abi_export_count() return the values the library was COMPILED with, so a
  * binding (rel_pose_amd/_lib.py parses both macros and counts the declarations) rejects a stale .so at load time instead of
  * failing later on a missing symbol. */
-#define RP_ABI_VERSION 10
-#define RP_ABI_EXPORTS 67
+#define RP_ABI_VERSION 11
+#define RP_ABI_EXPORTS 73
 int rp_abi_version(void);
 int rp_abi_export_count(void);
 const char* rp_target_arch(void);
@@ -250,6 +250,24 @@ int rp_tokens_bwd(const float* dx, float* dfeat, int Z, int C, int N, void* stre
  * BASELINE.json configs[4]. */
 int rp_attn_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int Z, int H, int ldq, int ldk,
                 int ldv, int ldo, int q_xor, int k_xor, float scale, int stats_only, int bf16, void* stream);
+/* The same operation on the bf16 DATA PATH of BASELINE.json configs[4] (csrc/attention_bf16.hip): q / k / v / o are BF16 in memory
+ * (same packing: col = h*64 + e, row strides ld* in ELEMENTS, multiples of 8); lse is fp32 in LOG2 units: lse2[z][h][i] =
+ * log2 sum_j exp2(scale log2(e) q_i . k_j) (= natural-log lse / ln 2), which is what rp_attn_bwd_bf16 consumes.  K / V tiles reach LDS by LDS-DMA,
+ * the matrix pipe is fed by ds_read_b128 / ds_read_b64_tr_b16 with no conversion instruction in the loop, P is packed once per tile;
+ * fp32 accumulation and softmax state.  xor / stats_only as rp_attn_fwd.  Replaces vision_transformer.py:325-329 (and, stats_only,
+ * the normalisers of :205-206) when the producing Linear (rp_linear_rows192 with io_bf16 bit 1) writes bf16. */
+int rp_attn_fwd_bf16(const void* q, const void* k, const void* v, void* o, float* lse, int Z, int H, int ldq, int ldk, int ldv,
+                     int ldo, int q_xor, int k_xor, float scale, int stats_only, void* stream);
+/* Autograd of the above on the same data path, RECOMPUTE form (no stored dS): delta[z][h][i] = sum_e dO O (fp32, from bf16 rows), then
+ * two deterministic kernels -- dK / dV (a wave owns 32 keys and streams Q / dO tiles) and dQ (a wave owns 32 queries and streams K / V
+ * tiles) -- that rebuild P = exp2(s - lse2) from the forward's lse2.  q / k / v / dout / dq / dk / dv are BF16 (strides in elements);
+ * kv_xor = 1: keys / values of problem z live at image z ^ 1 (backward of k_xor = 3); *_colpart (all NULL, or dk and dv together, dq
+ * optional): [Z*18][ldp] fp32 column sums of dq / dk / dv over each 32-token block (pointers at the first of the H*64 columns),
+ * taken from the fp32 accumulators -- the qkv bias gradient's partials (vision_transformer.py:323). */
+int rp_attn_bwd_delta_bf16(const void* dout, const void* o, float* delta, int Z, int H, int ld, void* stream);
+int rp_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* dout, const float* lse2, const float* delta, void* dq,
+                     void* dk, void* dv, int Z, int H, int ldq, int ldk, int ldv, int lddo, int lddq, int lddk, int lddv, float scale,
+                     int kv_xor, float* dq_colpart, float* dk_colpart, float* dv_colpart, int ldp, void* stream);
 /* The dual softmax's two normalisers (vision_transformer.py:205-206) of the EMM score matrix S_z = scale * q_{z^1} k_z^T (queries of the
  * partner image, keys of image z; q / k point at the first of the H*64 columns, rows (z*576 + i)*ld):
  *   rlse[z][h][i] = log sum_j exp(S_z[i][j]),   clse[z][h][j] = log sum_i exp(S_z[i][j])      ([Z,H,576] floats each)
@@ -336,6 +354,17 @@ int rp_emm_grad_ds(const float* qkv, int ldqkv, const float* x, const float* w, 
                    const float* rho, const float* gamma, float* dqkv, float* ds, int Z, int H, float scale, int single,
                    int bf16, void* stream);
 
+/* Weight gradient of a Linear on the bf16 data path (csrc/dw192_bf16.hip): slabs of C[n][k] = sum_m A[m][n] B[m][k] for A [M,N] BF16
+ * (row stride lda elements, N a multiple of 192), B [M,192] contiguous, BF16 or (b_is_f32) fp32 rounded to bf16 on chip, M a multiple
+ * of 64 -- the dW = dY^T X of vision_transformer.py:323,330 / vit_layers/mlp.py:22,24, where one operand is always 192 wide.  A
+ * streaming kernel (LDS-DMA stages, both operands by ds_read_b64_tr_b16, one [192 x 192] fp32 tile per workgroup over a slab of token
+ * rows); it leaves rp_dw192_bf16_splits(M, N) split-K slabs [split][N][192] fp32 in `workspace`, which the caller finishes with
+ * rp_splitk_reduce_multi (task {ws, C, M = N, N = 192, ldc, split_k, trans_c}: trans_c writes C^T, e.g. fc2's [192,768] weight from
+ * A = h [M,768]) -- deterministic, and batchable with the other weight gradients of a block. */
+int rp_dw192_bf16_splits(int M, int N);
+size_t rp_dw192_bf16_workspace_bytes(int M, int N);
+int rp_dw192_bf16(const void* a, int lda, const void* b, int b_is_f32, int M, int N, void* workspace, size_t workspace_bytes, void* stream);
+
 /* q / max(|q|, 0.01), slot 0 <- Gs  (normalize_preds, src/model.py:145-159) */
 int rp_pose_normalize_fwd(const float* pred, const float* gs, float* out, int B, void* stream);
 int rp_pose_normalize_bwd(const float* pred, const float* dout, float* dpred, int B, void* stream);
@@ -354,8 +383,10 @@ int rp_pose_normalize_bwd(const float* pred, const float* dout, float* dpred, in
  * precision: 0 exact fp32 MFMA; 1 = the bf16 configuration (operands rounded to bf16, fp32 accumulate:
  * v_mfma_f32_16x16x32_bf16; LayerNorm, bias, GELU and the residual stay fp32) -- in this precision w points to a BF16 copy of
  * the weight ([N,192] bf16, contiguous; the caller refreshes it when the fp32 master changes), x stays fp32 and is rounded to
- * nearest even on chip.  io_bf16 (precision 1 only; RpGemm.io_bf16's bits): bit 1 = y and y_pre are written as bf16, bit 2 =
- * dact_aux holds bf16.
+ * nearest even on chip.  io_bf16 (precision 1 only; RpGemm.io_bf16's bits): bit 0 = x holds BF16 rows (no LayerNorm: a lane's
+ * six 8-element MFMA operands are loaded as they lie, e.g. the bf16 attention output into proj), bit 1 = y and y_pre are written as
+ * bf16, bit 2 = dact_aux holds bf16, bit 3 = xn_out is written as bf16 (the rounded rows the MFMA consumed: what the bf16 weight-
+ * gradient product reads).  The bits select the bf16 data path of BASELINE.json configs[4].
  * ------------------------------------------------------------------------------------------- */
 int rp_linear_rows192_tile_rows(void);
 int rp_linear_rows192(const float* x, const float* w, const float* bias, const float* residual, const float* ln_gamma,

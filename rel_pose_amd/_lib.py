@@ -87,6 +87,9 @@ _SIGS = {
     "rp_tokens_fwd_nhwc": (c_int, [P, P, P, I, I, I, P]),
     "rp_tokens_bwd": (c_int, [P, P, I, I, I, P]),
     "rp_attn_fwd": (c_int, [P, P, P, P, P, I, I, I, I, I, I, I, I, F, I, I, P]),
+    "rp_attn_fwd_bf16": (c_int, [P, P, P, P, P, I, I, I, I, I, I, I, I, F, I, P]),
+    "rp_attn_bwd_delta_bf16": (c_int, [P, P, P, I, I, I, P]),
+    "rp_attn_bwd_bf16": (c_int, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, P, P, P, I, P]),
     "rp_attn_bwd_delta": (c_int, [P, P, P, I, I, I, P]),
     "rp_attn_bwd": (c_int, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, P]),
     "rp_attn_bwd_dkdv_ds": (c_int, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, F, I, P, P, I, P]),
@@ -96,6 +99,9 @@ _SIGS = {
     "rp_attn_bwd_cross": (c_int, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, I, P]),
     "rp_attn_bwd_dkdv": (c_int, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, F, I, P]),
     "rp_attn_bwd_dq": (c_int, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, F, I, P]),
+    "rp_dw192_bf16_splits": (c_int, [I, I]),
+    "rp_dw192_bf16_workspace_bytes": (c_size_t, [I, I]),
+    "rp_dw192_bf16": (c_int, [P, I, P, I, I, I, P, c_size_t, P]),
     "rp_posenc": (c_int, [P, P, P, I, I, P]),
     "rp_emm_build_x": (c_int, [P, P, P, I, I, I, P]),
     "rp_emm_build_x_bwd": (c_int, [P, P, I, I, I, P]),

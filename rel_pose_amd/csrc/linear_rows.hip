@@ -43,7 +43,8 @@ struct RowsP {
   float eps;
   int act;                   // 0 none, 1 GELU
   int nchunk, tiles, base, rem;
-  int io_bf16;               // BF only: bit 1 = y / ypre stored as bf16, bit 2 = aux holds bf16 (RpGemm.io_bf16's meaning)
+  int io_bf16;               // BF only: bit 0 = x holds bf16 rows (no LayerNorm), bit 1 = y / ypre stored as bf16, bit 2 = aux holds bf16
+                             // (RpGemm.io_bf16's meaning), bit 3 = xn_out stored as bf16 (the rounded rows the MFMA consumed)
 #ifdef RP_ROWS_PROBE
   long long* probe;          // tools/lab/rows_probe: shader-clock stamps [block][chunk][wave][5]
 #endif
@@ -125,11 +126,24 @@ __global__ __launch_bounds__(NT, 3) void linear_rows_kernel(RowsP p) {
     const long long rclamp = min(row, p.M - 1);
     const float* xr = p.x + rclamp * C;
     float xn[48];
+    bf16x8 xb[BF ? 6 : 1];
+    bool have_xb = false;
+    if constexpr (BF && !LN) {
+      if (p.io_bf16 & 1) {       // bf16 rows: lane (j, q) takes its six 8-element MFMA operands straight from memory, no conversion
+        const unsigned short* xr16 = reinterpret_cast<const unsigned short*>(p.x) + rclamp * C + 8 * q;
+#pragma unroll
+        for (int u = 0; u < 6; ++u) xb[u] = *reinterpret_cast<const bf16x8*>(xr16 + 32 * u);
+        have_xb = true;
+      }
+    }
+    if (!have_xb) {
 #pragma unroll
     for (int t = 0; t < 12; ++t) {
       const float4 v = ld4(xr + colof(t));
       xn[4 * t] = v.x; xn[4 * t + 1] = v.y; xn[4 * t + 2] = v.z; xn[4 * t + 3] = v.w;
     }
+    }
+    const bool xn_bf = BF && (p.io_bf16 & 8);
     if (LN) {
       float s = 0.f;
 #pragma unroll
@@ -154,17 +168,23 @@ __global__ __launch_bounds__(NT, 3) void linear_rows_kernel(RowsP p) {
         xn[4 * t + 1] = (xn[4 * t + 1] - mu) * rs * g.y + bb.y;
         xn[4 * t + 2] = (xn[4 * t + 2] - mu) * rs * g.z + bb.z;
         xn[4 * t + 3] = (xn[4 * t + 3] - mu) * rs * g.w + bb.w;
-        if (p.xn && owner) st4(p.xn + (long long)row * C + colof(t), make_float4(xn[4 * t], xn[4 * t + 1], xn[4 * t + 2], xn[4 * t + 3]));
+        if (p.xn && owner && !xn_bf) st4(p.xn + (long long)row * C + colof(t), make_float4(xn[4 * t], xn[4 * t + 1], xn[4 * t + 2], xn[4 * t + 3]));
       }
       if (owner && q == 0) {
         if (p.mean) p.mean[row] = mu;
         if (p.rstd) p.rstd[row] = rs;
       }
     }
-    bf16x8 xb[BF ? 6 : 1];
     if constexpr (BF) {
+      if (!have_xb) {
 #pragma unroll
-      for (int u = 0; u < 6; ++u) xb[u] = pack8(xn + 8 * u);
+        for (int u = 0; u < 6; ++u) xb[u] = pack8(xn + 8 * u);
+      }
+      if (LN && xn_bf && p.xn && c0 == 0 && live) {      // the normalised rows as the MFMA consumed them: 6 x 16 bytes instead of 12
+        unsigned short* xo = reinterpret_cast<unsigned short*>(p.xn) + (long long)row * C + 8 * q;
+#pragma unroll
+        for (int u = 0; u < 6; ++u) *reinterpret_cast<bf16x8*>(xo + 32 * u) = xb[u];
+      }
     }
     const bool y_bf = BF && (p.io_bf16 & 2), aux_bf = BF && (p.io_bf16 & 4);
     // The stores of chunk c are issued after the barrier of chunk c + 1, BEFORE the next weight DMA: loads and stores retire in
@@ -355,7 +375,8 @@ extern "C" int rp_linear_rows192(const float* x, const float* w, const float* bi
   const bool ln = ln_gamma != nullptr;
   if (!ln && (xn_out || mean_out || rstd_out)) return RP_EBADSHAPE;
   if (precision != 0 && precision != 1) return RP_EUNSUPPORTED;
-  if (io_bf16 && (precision != 1 || (io_bf16 & ~6) || ((io_bf16 & 4) && !dact_aux))) return RP_EUNSUPPORTED;
+  if (io_bf16 && (precision != 1 || (io_bf16 & ~15) || ((io_bf16 & 4) && !dact_aux) || ((io_bf16 & 1) && ln) || ((io_bf16 & 8) && !xn_out)))
+    return RP_EUNSUPPORTED;
   const bool bf = precision == 1;
   RowsP p{x, w, bias, residual, ln_gamma, ln_beta, y, y_pre, xn_out, mean_out, rstd_out, dact_aux, colsum_part, M, N, eps, act, N / CH, (M + ROWS - 1) / ROWS, 0, 0, io_bf16};
   const long long items = (long long)p.tiles * p.nchunk;

@@ -102,6 +102,17 @@ def set_attention_precision(bf16):
     ATTN_BF16 = 1 if bf16 else 0
 
 
+# The bf16 DATA PATH of the bf16 configuration (BASELINE.json configs[4]; operand precision 1 + bf16 attention): q | k | v, the attention
+# output and their gradients live in HBM as bf16 and the attention runs on csrc/attention_bf16.hip (LDS-DMA tiles, no conversions in the
+# loops, recompute-form backward).  The residual stream, LayerNorm statistics and every accumulation stay fp32.  RP_BF16_PATH=0 keeps
+# the round-3 form (fp32 storage, operands rounded per MFMA) for A/B.
+BF16_PATH = os.environ.get("RP_BF16_PATH", "1") == "1"
+
+
+def _bf16_path():
+    return BF16_PATH and GEMM_PRECISION == 1 and ATTN_BF16 == 1
+
+
 def gemm_tile(M, N, a_layout, b_layout, reads_mn=False, precision=None):
     """(TM, TN) that rp_gemm picks (mirrors csrc/gemm.hip)."""
     precision = GEMM_PRECISION if precision is None else precision
@@ -534,23 +545,29 @@ ROWS_DX = os.environ.get("RP_ROWS_DX", "1") != "0"      # input-gradient GEMMs t
 
 
 def _rows_ok(x, W):
-    return (ROWS_LINEAR and GEMM_PRECISION in (0, 1) and x.dtype == torch.float32 and x.shape[1] == DIM and W.shape[1] == DIM and W.shape[0] % 32 == 0
-            and W.shape[0] <= 1024 and x.is_contiguous() and W.is_contiguous())
+    return (ROWS_LINEAR and GEMM_PRECISION in (0, 1) and (x.dtype == torch.float32 or (x.dtype == torch.bfloat16 and GEMM_PRECISION == 1))
+            and x.shape[1] == DIM and W.shape[1] == DIM and W.shape[0] % 32 == 0 and W.shape[0] <= 1024 and x.is_contiguous() and W.is_contiguous())
 
 
 def linear_rows(x, W, b=None, act=0, want_pre=False, residual=None, ln=None, want_ln_out=False, dact_aux=None, want_colsum=False,
-                out_dtype=None):
+                out_dtype=None, xn_dtype=None):
     """rp_linear_rows192: y = act(LN?(x) W^T + b) (+ residual) for K = 192.  ln = (gamma, beta) fuses the LayerNorm;
     want_ln_out additionally returns (xn, mean, rstd).  dact_aux [M,N]: y *= GELU'(aux); want_colsum: also the column sums of y
     (from per-tile partials).  Returns y [, pre] [, xn, mean, rstd] [, colsum].  At operand precision 1 (the bf16 configuration)
-    dact_aux may be a bf16 tensor and out_dtype=torch.bfloat16 stores y (and pre) as bf16."""
+    dact_aux may be a bf16 tensor, x may be a bf16 tensor (no LayerNorm), out_dtype=torch.bfloat16 stores y (and pre) as bf16 and
+    xn_dtype=torch.bfloat16 the normalised rows."""
     lib = _lib.load()
-    _chk(x, W, b, residual)
+    _chk(W, b, residual)
+    _chk_act(x)
     _chk_act(dact_aux)
     M, K = x.shape
     N = W.shape[0]
     obf = out_dtype == torch.bfloat16
-    io = (2 if obf else 0) | (4 if (dact_aux is not None and dact_aux.dtype == torch.bfloat16) else 0)
+    xnbf = xn_dtype == torch.bfloat16 and ln is not None and want_ln_out
+    io = ((1 if x.dtype == torch.bfloat16 else 0) | (2 if obf else 0) | (4 if (dact_aux is not None and dact_aux.dtype == torch.bfloat16) else 0)
+          | (8 if xnbf else 0))
+    if (io & 1) and ln is not None:
+        raise RuntimeError("the fused LayerNorm reads the fp32 residual stream, not bf16 rows")
     if io and GEMM_PRECISION != 1:
         raise RuntimeError("bf16-stored operands need operand precision 1 (the bf16 configuration)")
     y = torch.empty(M, N, device=x.device, dtype=torch.bfloat16) if obf else _empty(M, N, like=x)
@@ -561,7 +578,8 @@ def linear_rows(x, W, b=None, act=0, want_pre=False, residual=None, ln=None, wan
         g, be = ln
         _chk(g, be)
         if want_ln_out:
-            xn, mean, rstd = torch.empty_like(x), _empty(M, like=x), _empty(M, like=x)
+            xn = torch.empty(M, K, device=x.device, dtype=torch.bfloat16 if xnbf else torch.float32)
+            mean, rstd = _empty(M, like=x), _empty(M, like=x)
     part = _empty(-(-M // lib.rp_linear_rows192_tile_rows()), N, like=x) if want_colsum else None
     nmn = 1 + (pre is not None) + (residual is not None) + (dact_aux is not None)
     with timed("linear_rows_ln" if ln is not None else "linear_rows", 2.0 * M * N * K,
@@ -575,11 +593,11 @@ def linear_rows(x, W, b=None, act=0, want_pre=False, residual=None, ln=None, wan
     return out[0] if len(out) == 1 else out
 
 
-def ln_linear(x, gamma, beta, W, b, act=0, want_pre=False, train=True, out_dtype=None):
+def ln_linear(x, gamma, beta, W, b, act=0, want_pre=False, train=True, out_dtype=None, xn_dtype=None):
     """(y [, pre], xn, mean, rstd) of  act(LayerNorm(x) W^T + b): one kernel when the row-resident path applies (xn / stats are
     None at inference), LayerNorm kernel + GEMM otherwise."""
     if _rows_ok(x, W):
-        r = linear_rows(x, W, b, act=act, want_pre=want_pre, ln=(gamma, beta), want_ln_out=train, out_dtype=out_dtype)
+        r = linear_rows(x, W, b, act=act, want_pre=want_pre, ln=(gamma, beta), want_ln_out=train, out_dtype=out_dtype, xn_dtype=xn_dtype)
         r = r if isinstance(r, tuple) else (r,)
         return r if train else r + (None, None, None)
     xn, m, rs = layernorm_fwd(x, gamma, beta)
@@ -605,7 +623,7 @@ def linear_dx(dy, W, dact=0, aux=None, want_colsum=False, out_dtype=None):
     M, N = dy.shape
     K = W.shape[1]
     if (ROWS_DX and N == DIM and K % 32 == 0 and K <= 1024 and GEMM_PRECISION in (0, 1) and dy.is_contiguous() and dact in (0, 1)
-            and dy.dtype == torch.float32):
+            and (dy.dtype == torch.float32 or GEMM_PRECISION == 1)):
         # contraction over the layer's 192 outputs: the row-resident kernel on the transposed weight (a 0.1-0.6 MB copy)
         return linear_rows(dy, transposed(W), dact_aux=aux if dact else None, want_colsum=want_colsum, out_dtype=out_dtype)
     return gemm(dy, W, M, K, N, b_layout=1, dact=dact, aux=aux, want_colsum=want_colsum, out_dtype=out_dtype)
@@ -630,10 +648,41 @@ def linear_dx_lnbwd(dy, W, x, gamma, mean, rstd, add=None):
     return dx, sums[:DIM], sums[DIM:2 * DIM], sums[2 * DIM:]
 
 
+DW192 = os.environ.get("RP_DW192", "1") == "1"      # A/B aid: the streaming bf16 weight-gradient kernel of the bf16 data path
+
+
+def _dw192(a, b, out, trans):
+    """slabs of a^T b by rp_dw192_bf16 (a [M,N] bf16, b [M,192] bf16 / fp32) + the fixed-order split-K reduce into `out`
+    ([N,192], or [192,N] when trans) -- deferred into the enclosing splitk_batch like every other weight gradient."""
+    lib = _lib.load()
+    M, N = a.shape
+    sk = lib.rp_dw192_bf16_splits(M, N)
+    nbytes = lib.rp_dw192_bf16_workspace_bytes(M, N)
+    deferred = (_SPLITK_BATCH is not None and torch.cuda.current_stream(a.device).cuda_stream == _SPLITK_BATCH[2])
+    ws = _arena_take(nbytes, a.device, _SPLITK_BATCH[1]) if deferred else _workspace(nbytes, a.device)
+    with timed("dw192_bf16", 2.0 * M * N * DIM, M * (2.0 * N + b.element_size() * DIM) + 4.0 * sk * N * DIM):
+        _lib.check(lib.rp_dw192_bf16(_p(a), N, _p(b), 1 if b.dtype == torch.float32 else 0, M, N, _p(ws), nbytes, _st()), "rp_dw192_bf16")
+    task = (ws, out, N, DIM, N if trans else DIM, sk, trans)
+    if deferred:
+        _SPLITK_BATCH[0].append(task)
+    else:
+        arr = (_lib.RpSplitkTask * 1)()
+        arr[0].ws, arr[0].C, arr[0].M, arr[0].N, arr[0].ldc, arr[0].split_k, arr[0].trans_c = ws.data_ptr(), out.data_ptr(), N, DIM, task[4], sk, 1 if trans else 0
+        _lib.check(lib.rp_splitk_reduce_multi(arr, 1, _st()), "rp_splitk_reduce_multi")
+    return out
+
+
 def linear_dw(dy, x):
     """dW = dy^T x; dy [M,N], x [M,K] -> [N,K]  (reduction over the M token rows, split-K)."""
     M, N = dy.shape
     K = x.shape[1]
+    if DW192 and GEMM_PRECISION == 1 and M % 64 == 0 and M >= 4096 and dy.is_contiguous() and x.is_contiguous():
+        bfd = torch.bfloat16
+        # one operand bf16 with a width that is a multiple of 192 (the streamed "A"), the other [M,192] bf16 or fp32
+        if dy.dtype == bfd and N % DIM == 0 and K == DIM and (N >= K or x.dtype != bfd):
+            return _dw192(dy, x, torch.empty(N, K, device=dy.device, dtype=torch.float32), False)
+        if x.dtype == bfd and K % DIM == 0 and N == DIM:
+            return _dw192(x, dy, torch.empty(N, K, device=dy.device, dtype=torch.float32), True)
     if x.dtype != torch.float32 and not (K > N and M >= 4096):
         x = x.float()              # (only the A operand of rp_gemm may be bf16-stored; small launches are not worth a second form)
     if dy.dtype != torch.float32 and K > N and M >= 4096:
@@ -749,6 +798,55 @@ def attn_fwd(qkv, Z, stats_only=False, q_off=0, k_off=DIM, v_off=2 * DIM, q_xor=
                                    ld, ld, ld, DIM, q_xor, k_xor, hd ** -0.5, 1 if stats_only else 0, ATTN_BF16, _st()),
                    "rp_attn_fwd")
     return o, lse
+
+
+def attn_fwd_bf16(qkv, Z, stats_only=False, q_off=0, k_off=DIM, v_off=2 * DIM, q_xor=0, k_xor=0):
+    """attn_fwd on the bf16 data path: qkv [Z*576, 576] BF16 packed (q | k | v) -> (o [Z*576,192] bf16 or None, lse [Z,H,576] fp32)
+    (rp_attn_fwd_bf16, csrc/attention_bf16.hip)."""
+    lib = _lib.load()
+    _chk_act(qkv)
+    if qkv.dtype != torch.bfloat16:
+        raise RuntimeError("attn_fwd_bf16 needs bf16 q | k | v")
+    ld = qkv.shape[1]
+    o = None if stats_only else torch.empty(Z * N_TOK, DIM, device=qkv.device, dtype=torch.bfloat16)
+    lse = torch.empty(Z, HEADS, N_TOK, device=qkv.device, dtype=torch.float32)
+    base = qkv.data_ptr()
+    P = ctypes.c_void_p
+    hd = DIM // HEADS
+    with timed("attn_stats_bf16" if stats_only else "attn_fwd_bf16", (2.0 if stats_only else 4.0) * Z * HEADS * N_TOK * N_TOK * hd,
+               2.0 * Z * N_TOK * ((2 if stats_only else 4) * DIM) + 4.0 * Z * N_TOK * HEADS):
+        _lib.check(lib.rp_attn_fwd_bf16(P(base + 2 * q_off), P(base + 2 * k_off), P(base + 2 * v_off), _p(o), _p(lse), Z, HEADS,
+                                        ld, ld, ld, DIM, q_xor, k_xor, hd ** -0.5, 1 if stats_only else 0, _st()),
+                   "rp_attn_fwd_bf16")
+    return o, lse
+
+
+def attn_bwd_bf16(qkv, o, lse2, do, Z, kv_xor=0, want_bias_partials=False):
+    """dqkv (bf16 [Z*576, 576]) of attn_fwd_bf16: rp_attn_bwd_delta_bf16 + rp_attn_bwd_bf16 (recompute form, deterministic).
+    want_bias_partials: also the [Z*18, 576] fp32 column sums of dq | dk | dv per 32-row block (the qkv bias gradient's partials)."""
+    lib = _lib.load()
+    for t in (qkv, o, do):
+        _chk_act(t)
+        if t.dtype != torch.bfloat16:
+            raise RuntimeError("attn_bwd_bf16 needs bf16 operands")
+    _chk(lse2)
+    ld = qkv.shape[1]
+    delta = torch.empty(Z, HEADS, N_TOK, device=qkv.device, dtype=torch.float32)
+    _lib.check(lib.rp_attn_bwd_delta_bf16(_p(do), _p(o), _p(delta), Z, HEADS, DIM, _st()), "rp_attn_bwd_delta_bf16")
+    dqkv = torch.empty_like(qkv)
+    P = ctypes.c_void_p
+    b, d = qkv.data_ptr(), dqkv.data_ptr()
+    part = pb = None
+    if want_bias_partials:
+        part = torch.empty(Z * (N_TOK // 32), 3 * DIM, device=qkv.device, dtype=torch.float32)
+        pb = part.data_ptr()
+    hd = DIM // HEADS
+    with timed("attn_bwd_bf16", 14.0 * Z * HEADS * N_TOK * N_TOK * hd, 2.0 * Z * N_TOK * 8 * DIM):
+        _lib.check(lib.rp_attn_bwd_bf16(P(b), P(b + 2 * DIM), P(b + 4 * DIM), _p(do), _p(lse2), _p(delta), P(d), P(d + 2 * DIM),
+                                        P(d + 4 * DIM), Z, HEADS, ld, ld, ld, DIM, ld, ld, ld, hd ** -0.5, kv_xor,
+                                        P(pb) if pb else None, P(pb + 4 * DIM) if pb else None, P(pb + 8 * DIM) if pb else None,
+                                        3 * DIM, _st()), "rp_attn_bwd_bf16")
+    return (dqkv, part) if want_bias_partials else dqkv
 
 
 ATTN_BWD_STORE_DS = os.environ.get("RP_ATTN_DS", "1") == "1"
@@ -1222,8 +1320,13 @@ class BlockFn(_Fn):
         x = x.contiguous()
         Z = x.shape[0]
         x2 = x.view(Z * N_TOK, DIM)
-        qkv, xn1, m1, r1 = ln_linear(x2, n1w, n1b, qkv_w, qkv_b, train=train)
-        o, lse = attn_fwd(qkv, Z, k_xor=3 if cross else 0)
+        bfp = _bf16_path()
+        if bfp:      # bf16 q | k | v -> bf16 o (lse in log2 units); xn1 kept as the bf16 rows the product consumed
+            qkv, xn1, m1, r1 = ln_linear(x2, n1w, n1b, qkv_w, qkv_b, train=train, out_dtype=torch.bfloat16, xn_dtype=torch.bfloat16)
+            o, lse = attn_fwd_bf16(qkv, Z, k_xor=3 if cross else 0)
+        else:
+            qkv, xn1, m1, r1 = ln_linear(x2, n1w, n1b, qkv_w, qkv_b, train=train)
+            o, lse = attn_fwd(qkv, Z, k_xor=3 if cross else 0)
         ctx.cross = cross
         x1 = linear(o, proj_w, proj_b, residual=x2)
         y, xn2, m2, r2, h, hpre = _mlp_block_fwd(x1, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b, train)
@@ -1249,8 +1352,12 @@ class BlockFn(_Fn):
                                                                          ln=(x1, n2w, m2, r2, dy))
             fork.sync_side()
             dprojw = fork.on_side(lambda: linear_dw(dx1, o))
-            do = linear_dx(dx1, proj_w)
-            dqkv, bpart = attn_bwd(qkv, o, lse, do, Z, fork, kv_xor=1 if ctx.cross else 0, want_bias_partials=True)
+            if qkv.dtype == torch.bfloat16:          # the bf16 data path (forward ran attn_fwd_bf16)
+                do = linear_dx(dx1, proj_w, out_dtype=torch.bfloat16)
+                dqkv, bpart = attn_bwd_bf16(qkv, o, lse, do, Z, kv_xor=1 if ctx.cross else 0, want_bias_partials=True)
+            else:
+                do = linear_dx(dx1, proj_w)
+                dqkv, bpart = attn_bwd(qkv, o, lse, do, Z, fork, kv_xor=1 if ctx.cross else 0, want_bias_partials=True)
             fork.sync_main()                                  # dQ pass (side) done before dqkv is consumed
             fork.sync_side()
             if bpart is not None:      # qkv bias gradient from the per-block column sums the attention backward's kernels left

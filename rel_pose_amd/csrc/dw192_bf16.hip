@@ -56,8 +56,12 @@ RP_DEV int swz_w(int r) { return ((r >> 1) & 1) << 2; }
 
 template <bool BF32>
 __global__ __launch_bounds__(256, 1) void dw192_bf16_kernel(DwP p) {
-  __shared__ __attribute__((aligned(16))) bf16_t As[2][ST_EL];
-  __shared__ __attribute__((aligned(16))) bf16_t Bs[2][ST_EL];
+  // bf16 B: both operands by DMA into a THREE-slot ring, the DMA two stages ahead with a counted vmcnt (144 KB of LDS).  fp32 B: its
+  // stage goes through registers, and hipcc's own s_waitcnt for those loads drains every younger DMA too, so a deeper ring would buy
+  // nothing there: two slots.
+  constexpr int NB = BF32 ? 2 : 3;
+  __shared__ __attribute__((aligned(16))) bf16_t As[NB][ST_EL];
+  __shared__ __attribute__((aligned(16))) bf16_t Bs[NB][ST_EL];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
   const int ntile = p.N / W;
   // workgroup b runs on XCD b % 8: the N / 192 tiles of one slab share its B rows, so they take consecutive slots of ONE XCD's L2
@@ -127,18 +131,7 @@ __global__ __launch_bounds__(256, 1) void dw192_bf16_kernel(DwP p) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) acc[i][j] = zero16();
 
-  if (nst > 0) {
-    issue_a(0, 0);
-    if (BF32) { load_b32(0); store_b32(0); } else issue_b(0, 0);
-  }
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  for (int s = 0; s < nst; ++s) {
-    const int buf = s & 1;
-    if (s + 1 < nst) {
-      issue_a(s + 1, buf ^ 1);
-      if (BF32) load_b32(s + 1); else issue_b(s + 1, buf ^ 1);
-    }
+  auto compute = [&](int buf) {
     const bf16_t* At = As[buf];
     const bf16_t* Bt = Bs[buf];
 #pragma unroll
@@ -154,9 +147,44 @@ __global__ __launch_bounds__(256, 1) void dw192_bf16_kernel(DwP p) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc[i][j] = mfma_bf(af[i], bfr[j], acc[i][j]);
     }
-    if (BF32 && s + 1 < nst) store_b32(buf ^ 1);                      // (the other buffer: last read in iteration s - 1, behind a barrier)
+  };
+  if constexpr (BF32) {
+    if (nst > 0) {
+      issue_a(0, 0);
+      load_b32(0);
+      store_b32(0);
+    }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    for (int s = 0; s < nst; ++s) {
+      const int buf = s & 1;
+      if (s + 1 < nst) {
+        issue_a(s + 1, buf ^ 1);
+        load_b32(s + 1);
+      }
+      compute(buf);
+      if (s + 1 < nst) store_b32(buf ^ 1);                            // (the other buffer: last read in iteration s - 1, behind a barrier)
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  } else {
+    if (nst > 0) { issue_a(0, 0); issue_b(0, 0); }
+    if (nst > 1) { issue_a(1, 1); issue_b(1, 1); }
+    int buf = 0;
+    for (int s = 0; s < nst; ++s) {
+      // stage s has landed (12 DMA instructions per wave and stage; stage s + 1 may stay in flight) -- for everybody -- and everybody
+      // is past iteration s - 1, whose slot the DMA of stage s + 2 refills
+      if (s + 1 < nst) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (s + 2 < nst) {
+        const int nb = buf == 0 ? 2 : buf - 1;                        // (s + 2) % 3
+        issue_a(s + 2, nb);
+        issue_b(s + 2, nb);
+      }
+      compute(buf);
+      buf = buf == 2 ? 0 : buf + 1;
+    }
   }
   // slab [N][192] of this split: rows n = nt 192 + 96 wr + 32 i + acc_row(r, hi), columns 96 wc + 32 j + l31 (128-byte runs per half-wave)
   float* slab = p.ws + (long long)sp * p.N * W + (long long)(nt * W + 96 * wr) * W + 96 * wc + l31;
@@ -174,7 +202,9 @@ __global__ __launch_bounds__(256, 1) void dw192_bf16_kernel(DwP p) {
 extern "C" int rp_dw192_bf16_splits(int M, int N) {
   if (M <= 0 || N <= 0 || N % W) return 0;
   const int ntile = N / W, stages = (M + SR - 1) / SR;
-  int sp = 256 / ntile;
+  // one workgroup per CU (96 KB of LDS), and workgroup b runs on XCD b % 8 with its 32 CUs: at most 32 / ntile slabs per XCD, or the
+  // surplus workgroup of an XCD runs as a second round (measured: 264 workgroups for N = 576 took twice the time of 240)
+  int sp = 8 * (32 / ntile);
   if (sp > stages) sp = stages;
   if (sp < 2) sp = 2;
   const int per = (stages + sp - 1) / sp;              // stages per slab; drop the empty tail slabs

@@ -22,5 +22,13 @@ for _ in range(reps):
     if what in ("all", "attn_bwd") and hasattr(ops, "attn_bwd_bf16"):
         o, lse = ops.attn_fwd_bf16(qkv, Z)
         ops.attn_bwd_bf16(qkv, o, lse, do, Z)
+    if what in ("all", "dw"):
+        ops.set_gemm_precision(1)
+        dy768 = torch.randn(M, 768, device=dev).to(bf)
+        x192 = torch.randn(M, 192, device=dev)
+        ops.linear_dw(qkv, x192.to(bf))            # qkv: A [M,576] bf16, B bf16
+        ops.linear_dw(dy768, x192)                 # fc1: A [M,768] bf16, B fp32
+        ops.linear_dw(x192, do)                    # proj: A = o [M,192] bf16, B = dx1 fp32 (transposed reduce)
+        ops.set_gemm_precision(0)
 torch.cuda.synchronize()
 print("ok")

@@ -404,7 +404,8 @@ int rp_linear_rows192(const float* x, const float* w, const float* bias, const f
  * and the hidden activation -- on the way: the forward of the MLP is then one launch in training too.
  * precision: 0 exact fp32 MFMA; 1 = the bf16 configuration (v_mfma_f32_16x16x32_bf16, fp32 accumulate; LayerNorm, bias, GELU, residual
  * fp32): w1 and w2 then point to BF16 copies ([hidden,dim] and [dim,hidden]), w2 with the hidden units of every 32-chunk in the order
- * documented at rp_mlp_fused_bwd.  io_bf16 (precision 1, training form only): bit 1 = h_out and hpre_out are written as bf16.
+ * documented at rp_mlp_fused_bwd.  io_bf16 (precision 1, training form only): bit 1 = h_out and hpre_out are written as bf16,
+ * bit 3 = xn_out is written as bf16 (the rounded rows the fc1 product consumed; what the bf16 weight-gradient kernel rp_dw192_bf16 reads).
  * ------------------------------------------------------------------------------------------- */
 size_t rp_mlp_fused_workspace_bytes(int M);
 int rp_mlp_fused_fwd(const float* x, const float* gamma, const float* beta, const float* w1, const float* b1, const float* w2,

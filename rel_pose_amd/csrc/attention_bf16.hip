@@ -297,7 +297,7 @@ RP_DEV void tr_offsets_d(int lane, int (&off)[2][2]) {
 }
 
 template <int NW>
-__global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkdv_bf16_kernel(AttnBwdBfP p) {
+__global__ __launch_bounds__(NW * 64, NW == 2 ? 3 : 2) void attn_bwd_dkdv_bf16_kernel(AttnBwdBfP p) {
   constexpr int SQ = 16 * NW;                // queries per stage
   constexpr int NSTAGE = NTOK / SQ;
   constexpr int ST_EL = SQ * 64;

@@ -48,7 +48,7 @@ struct MlpP {
   int M;
   float eps;
   int tiles, base, rem, P;
-  int io_bf16;       // BF only: bit 1 = dhp is written as bf16, bit 2 = hpre holds bf16
+  int io_bf16;       // BF only: bit 1 = dhp (MODE 1) / h, hpre (MODE 0) written as bf16, bit 2 = hpre holds bf16, bit 3 = xn_out written as bf16
   // MODE 0, TRAIN: what the backward needs, written on the way (all [M, .] fp32): the normalised rows and their statistics, the fc1
   // pre-activation (dhp doubles as its pointer) and the hidden activation
   float *xn_out, *mean_out, *rstd_out, *h_out;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
         xn[4 * t + 1] = fmaf((xn[4 * t + 1] - mu) * rs, g.y, bb.y);
         xn[4 * t + 2] = fmaf((xn[4 * t + 2] - mu) * rs, g.z, bb.z);
         xn[4 * t + 3] = fmaf((xn[4 * t + 3] - mu) * rs, g.w, bb.w);
-        if (TRAIN && owner)
+        if (TRAIN && owner && !(BF && (p.io_bf16 & 8)))
           st4(p.xn_out + (long long)row * C + colof(t), make_float4(xn[4 * t], xn[4 * t + 1], xn[4 * t + 2], xn[4 * t + 3]));
       }
       if (TRAIN && owner && q == 0) {
@@ -182,6 +182,11 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
     if constexpr (BF) {
 #pragma unroll
       for (int u = 0; u < 6; ++u) xb[u] = pack8(xn + 8 * u);
+      if (MODE == 0 && TRAIN && (p.io_bf16 & 8) && c0 == 0 && live) {      // xn as the bf16 rows the MFMA consumes: 6 x 16 bytes
+        unsigned short* xo = reinterpret_cast<unsigned short*>(p.xn_out) + (long long)row * C + 8 * q;
+#pragma unroll
+        for (int u = 0; u < 6; ++u) *reinterpret_cast<bf16x8*>(xo + 32 * u) = xb[u];
+      }
     }
     const bool dhp_bf = BF && (p.io_bf16 & 2), hpre_bf = BF && (p.io_bf16 & 4);
     const int bfo = (q & 1) ? 16 + 4 * (q - 1) - 4 * q : 0;      // element offset of a lane's 8 consecutive units in a bf16 row (st/ld_bf16x8)
@@ -474,7 +479,7 @@ extern "C" int rp_mlp_fused_fwd(const float* x, const float* gamma, const float*
     return RP_EBADSHAPE;
   const bool train = xn_out || mean_out || rstd_out || h_out || hpre_out;
   if (train && !(xn_out && mean_out && rstd_out && h_out && hpre_out)) return RP_EBADSHAPE;      // the training outputs come as a set
-  if ((precision != 0 && precision != 1) || (io_bf16 && (precision != 1 || !train || (io_bf16 & ~2)))) return RP_EUNSUPPORTED;
+  if ((precision != 0 && precision != 1) || (io_bf16 && (precision != 1 || !train || (io_bf16 & ~10)))) return RP_EUNSUPPORTED;
   MlpP p{x, gamma, beta, w1, b1, w2, b2, y, nullptr, hpre_out, nullptr, (float*)workspace, M, eps, 0, 0, 0, 0, io_bf16,
          xn_out, mean_out, rstd_out, h_out};
   hipStream_t st = (hipStream_t)stream;

@@ -1143,7 +1143,7 @@ FUSE_MLP_TRAIN = os.environ.get("RP_FUSE_MLP_TRAIN", "1") != "0"
 _mlp_ws = {}
 
 
-def mlp_fused(x2d, gamma, beta, w1, b1, w2, b2, eps=LN_EPS, train=False, out_dtype=None):
+def mlp_fused(x2d, gamma, beta, w1, b1, w2, b2, eps=LN_EPS, train=False, out_dtype=None, xn_dtype=None):
     """y = x + fc2(GELU(fc1(LayerNorm(x)) + b1)) + b2 for x [M,192], w1 [768,192], w2 [192,768] (rp_mlp_fused_fwd).
     train=True: returns (y, xn, mean, rstd, h, hpre) -- the same launch also stores what the backward needs.  At operand precision 1
     (the bf16 configuration) both products run on the bf16 MFMA from bf16 weight copies, and out_dtype=torch.bfloat16 stores h / hpre
@@ -1162,8 +1162,10 @@ def mlp_fused(x2d, gamma, beta, w1, b1, w2, b2, eps=LN_EPS, train=False, out_dty
         ws = _mlp_ws[key] = torch.empty(max(1, lib.rp_mlp_fused_workspace_bytes(M)) // 4 + 1, device=x2d.device, dtype=torch.float32)
     Hd = w1.shape[0]
     xn = mean = rstd = h = hpre = None
+    xnbf = xn_dtype == torch.bfloat16 and bf and train
     if train:
-        xn, mean, rstd = torch.empty_like(x2d), _empty(M, like=x2d), _empty(M, like=x2d)
+        xn = torch.empty(x2d.shape, device=x2d.device, dtype=torch.bfloat16 if xnbf else torch.float32)
+        mean, rstd = _empty(M, like=x2d), _empty(M, like=x2d)
         hdt = torch.bfloat16 if obf else torch.float32
         h, hpre = torch.empty(M, Hd, device=x2d.device, dtype=hdt), torch.empty(M, Hd, device=x2d.device, dtype=hdt)
     if bf:
@@ -1172,7 +1174,7 @@ def mlp_fused(x2d, gamma, beta, w1, b1, w2, b2, eps=LN_EPS, train=False, out_dty
         w1k, w2k = w1, w2
     with timed("mlp_fused_fwd", 4.0 * M * DIM * Hd, 4.0 * (2 * M * DIM + 2 * DIM * Hd + (M * DIM + 2 * M * Hd if train else 0))):
         _lib.check(lib.rp_mlp_fused_fwd(_p(x2d), _p(gamma), _p(beta), _p(w1k), _p(b1), _p(w2k), _p(b2), _p(y), _p(ws), M, x2d.shape[1],
-                                        Hd, eps, _p(xn), _p(mean), _p(rstd), _p(h), _p(hpre), 1 if bf else 0, 2 if obf else 0, _st()),
+                                        Hd, eps, _p(xn), _p(mean), _p(rstd), _p(h), _p(hpre), 1 if bf else 0, (2 if obf else 0) | (8 if xnbf else 0), _st()),
                    "rp_mlp_fused_fwd")
     return (y, xn, mean, rstd, h, hpre) if train else y
 
@@ -1250,7 +1252,8 @@ def _mlp_block_fwd(x1, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b, train):
     if (FUSE_MLP and GEMM_PRECISION in (0, 1) and x1.shape[1] == DIM and tuple(fc1_w.shape) == (4 * DIM, DIM)
             and tuple(fc2_w.shape) == (DIM, 4 * DIM) and (not train or FUSE_MLP_TRAIN) and x1.dtype == torch.float32):
         if train:
-            return mlp_fused(x1, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b, train=True, out_dtype=torch.bfloat16 if _act_bf16() else None)
+            return mlp_fused(x1, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b, train=True, out_dtype=torch.bfloat16 if _act_bf16() else None,
+                             xn_dtype=torch.bfloat16 if _bf16_path() else None)
         return mlp_fused(x1, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b), None, None, None, None, None
     hd = torch.bfloat16 if _act_bf16() else None          # bf16 configuration: the [tokens, 768] hidden tensors live in bf16
     if train:

@@ -37,7 +37,7 @@ extern "C" {
  * binding (rel_pose_amd/_lib.py parses both macros and counts the declarations) rejects a stale .so at load time instead of
  * failing later on a missing symbol. */
 #define RP_ABI_VERSION 11
-#define RP_ABI_EXPORTS 73
+#define RP_ABI_EXPORTS 80
 int rp_abi_version(void);
 int rp_abi_export_count(void);
 const char* rp_target_arch(void);
@@ -364,6 +364,30 @@ int rp_emm_grad_ds(const float* qkv, int ldqkv, const float* x, const float* w, 
 int rp_dw192_bf16_splits(int M, int N);
 size_t rp_dw192_bf16_workspace_bytes(int M, int N);
 int rp_dw192_bf16(const void* a, int lda, const void* b, int b_is_f32, int M, int N, void* workspace, size_t workspace_bytes, void* stream);
+
+/* rp_emm_finalize for f_part [Z][H][nparts][96][96] (nparts = 6: rp_emm_apply's workgroup partials; 1: rp_emm_f_bf16's whole F) */
+int rp_emm_finalize_parts(const float* f_part, float* g, int Z, int H, int ldg, int nparts, void* stream);
+
+/* The Essential Matrix Module on the bf16 data path of BASELINE.json configs[4] (csrc/emm_bf16.hip; same algebra and indexing as the
+ * fp32 entry points above, vision_transformer.py:198-223 and its autograd): qkv [Z*576, ldqkv] BF16, X / T / U / W / W' [Z][H][576][96]
+ * BF16, the normalisers rlse2 / clse2 [Z][H][576] fp32 in LOG2 units (rp_attn_fwd_bf16(stats_only): rlse2 with q_xor = 1, clse2 with
+ * the k pointer as q, the q pointer as k and k_xor = 1), rho / gamma [Z][H][576] and dF [Z][H][96][96] fp32.  Default flags only (dual
+ * softmax, F = X^T A X): the ablation variants keep the fp32-storage kernels.
+ *   build_x : X = [v | pos | 0]                        apply : T = A X (swap = 0) or U = A^T X (swap = 1)
+ *   f       : F = X^T T  -> f [Z][H][96][96] fp32 (then rp_emm_finalize_parts(nparts = 1))
+ *   w       : W = X dF, W' = X dF^T, rho = <W, T> (from the fp32 accumulators of W)
+ *   dx      : dX = T dF^T + U dF -> the v columns of dqkv (bf16), gamma = <W', U>
+ *   grad    : dq (swap = 0: x = X, w = W, writes the q columns of image z^1) / dk (swap = 1: w = W', the k columns of image z);
+ *             recompute form: S and dA are rebuilt per tile, no dS is stored */
+int rp_emm_build_x_bf16(const void* qkv, const float* pos, void* x, int Z, int H, int ldqkv, void* stream);
+int rp_emm_apply_bf16(const void* qkv, int ldqkv, const void* x, const float* rlse2, const float* clse2, void* t_out, int Z, int H,
+                      float scale, int swap, void* stream);
+int rp_emm_f_bf16(const void* x, const void* t, float* f, int Z, int H, void* stream);
+int rp_emm_w_bf16(const void* x, const void* t, const float* df, void* w, void* wp, float* rho, int Z, int H, void* stream);
+int rp_emm_dx_bf16(const void* t, const void* u, const void* wp, const float* df, void* dqkv, int ldqkv, float* gamma, int Z, int H,
+                   void* stream);
+int rp_emm_grad_bf16(const void* qkv, int ldqkv, const void* x, const void* w, const float* rlse2, const float* clse2, const float* rho,
+                     const float* gamma, void* dqkv, int Z, int H, float scale, int swap, void* stream);
 
 /* q / max(|q|, 0.01), slot 0 <- Gs  (normalize_preds, src/model.py:145-159) */
 int rp_pose_normalize_fwd(const float* pred, const float* gs, float* out, int B, void* stream);

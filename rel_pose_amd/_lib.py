@@ -102,6 +102,13 @@ _SIGS = {
     "rp_dw192_bf16_splits": (c_int, [I, I]),
     "rp_dw192_bf16_workspace_bytes": (c_size_t, [I, I]),
     "rp_dw192_bf16": (c_int, [P, I, P, I, I, I, P, c_size_t, P]),
+    "rp_emm_finalize_parts": (c_int, [P, P, I, I, I, I, P]),
+    "rp_emm_build_x_bf16": (c_int, [P, P, P, I, I, I, P]),
+    "rp_emm_apply_bf16": (c_int, [P, I, P, P, P, P, I, I, F, I, P]),
+    "rp_emm_f_bf16": (c_int, [P, P, P, I, I, P]),
+    "rp_emm_w_bf16": (c_int, [P, P, P, P, P, P, I, I, P]),
+    "rp_emm_dx_bf16": (c_int, [P, P, P, P, P, I, P, I, I, P]),
+    "rp_emm_grad_bf16": (c_int, [P, I, P, P, P, P, P, P, P, I, I, F, I, P]),
     "rp_posenc": (c_int, [P, P, P, I, I, P]),
     "rp_emm_build_x": (c_int, [P, P, P, I, I, I, P]),
     "rp_emm_build_x_bwd": (c_int, [P, P, I, I, I, P]),

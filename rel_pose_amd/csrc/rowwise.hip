@@ -614,6 +614,13 @@ extern "C" int rp_emm_finalize(const float* f_part, float* g, int Z, int H, int 
   return RP_OK;
 }
 
+extern "C" int rp_emm_finalize_parts(const float* f_part, float* g, int Z, int H, int ldg, int nparts, void* stream) {
+  if (Z <= 0 || (Z & 1) || H * 70 > ldg || nparts <= 0) return RP_EBADSHAPE;
+  hipLaunchKernelGGL(emm_finalize_kernel, dim3(H, Z), dim3(256), 0, (hipStream_t)stream, f_part, g, H, ldg, nparts);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
 extern "C" int rp_emm_finalize_bwd(const float* dg, float* df, int Z, int H, int ldg, void* stream) {
   if (Z <= 0 || (Z & 1) || H * 70 > ldg) return RP_EBADSHAPE;
   hipLaunchKernelGGL(emm_finalize_bwd_kernel, dim3(96, H, Z), dim3(256), 0, (hipStream_t)stream, dg, df, H, ldg);

@@ -1073,6 +1073,57 @@ def emm_backward(qkv, x, t, rlse, clse, df, Z, single=False, cross=False):
     return dqkv
 
 
+# ---- the EMM on the bf16 data path (csrc/emm_bf16.hip): default flags only; the ablation variants keep the fp32-storage kernels ----
+def _bf(*shape, like):
+    return torch.empty(shape, device=like.device, dtype=torch.bfloat16)
+
+
+def emm_forward_bf16(qkv, pos, Z, want_t=True):
+    """(g [Z*70, 224] fp32, saved = (xa, t, rlse2, clse2)) of the EMM for bf16 qkv [Z*576, 576]: statistics (two statistics-only passes
+    of the bf16 attention kernel, log2 units), X = [v | pos | 0], T = A X, F = X^T T, the reshape / transpose / flip of
+    vision_transformer.py:229-230,238."""
+    lib = _lib.load()
+    _chk_act(qkv)
+    _chk(pos)
+    ld = qkv.shape[1]
+    sc = (DIM // HEADS) ** -0.5
+    _, rlse2 = attn_fwd_bf16(qkv, Z, stats_only=True, q_off=0, k_off=DIM, q_xor=1, k_xor=0)          # rows i: queries of the partner image
+    _, clse2 = attn_fwd_bf16(qkv, Z, stats_only=True, q_off=DIM, k_off=0, q_xor=0, k_xor=1)          # columns j: keys as the owner rows
+    xa = _bf(Z, HEADS, N_TOK, XW, like=qkv)
+    _lib.check(lib.rp_emm_build_x_bf16(_p(qkv), _p(pos), _p(xa), Z, HEADS, ld, _st()), "rp_emm_build_x_bf16")
+    t = _bf(Z, HEADS, N_TOK, XW, like=qkv)
+    with timed("emm_apply_bf16", 2.0 * Z * HEADS * N_TOK * N_TOK * (64 + XW), 2.0 * Z * HEADS * N_TOK * (2 * 64 + 2 * XW)):
+        _lib.check(lib.rp_emm_apply_bf16(_p(qkv), ld, _p(xa), _p(rlse2), _p(clse2), _p(t), Z, HEADS, sc, 0, _st()), "rp_emm_apply_bf16")
+    f = torch.empty(Z, HEADS, XW, XW, device=qkv.device, dtype=torch.float32)
+    _lib.check(lib.rp_emm_f_bf16(_p(xa), _p(t), _p(f), Z, HEADS, _st()), "rp_emm_f_bf16")
+    g = _empty(Z * 70, GW, like=f)
+    _lib.check(lib.rp_emm_finalize_parts(_p(f), _p(g), Z, HEADS, GW, 1, _st()), "rp_emm_finalize_parts")
+    return g, (xa, t, rlse2, clse2)
+
+
+def emm_backward_bf16(qkv, xa, t, rlse2, clse2, df, Z):
+    """dqkv (bf16 [Z*576, 576]) of the EMM given df [Z,H,96,96] fp32 (zero-padded): W / W' / rho, U = A^T X, dX + gamma, then the two
+    recompute passes for dq and dk."""
+    lib = _lib.load()
+    _chk(df)
+    ld = qkv.shape[1]
+    sc = (DIM // HEADS) ** -0.5
+    w, wp = _bf(Z, HEADS, N_TOK, XW, like=qkv), _bf(Z, HEADS, N_TOK, XW, like=qkv)
+    rho = torch.empty(Z, HEADS, N_TOK, device=qkv.device, dtype=torch.float32)
+    gam = torch.empty_like(rho)
+    _lib.check(lib.rp_emm_w_bf16(_p(xa), _p(t), _p(df), _p(w), _p(wp), _p(rho), Z, HEADS, _st()), "rp_emm_w_bf16")
+    u = _bf(Z, HEADS, N_TOK, XW, like=qkv)
+    _lib.check(lib.rp_emm_apply_bf16(_p(qkv), ld, _p(xa), _p(rlse2), _p(clse2), _p(u), Z, HEADS, sc, 1, _st()), "rp_emm_apply_bf16(swap)")
+    dqkv = torch.empty_like(qkv)
+    _lib.check(lib.rp_emm_dx_bf16(_p(t), _p(u), _p(wp), _p(df), _p(dqkv), ld, _p(gam), Z, HEADS, _st()), "rp_emm_dx_bf16")
+    with timed("emm_grad_bf16", 2.0 * Z * HEADS * N_TOK * N_TOK * (64 + XW + 64), 2.0 * Z * HEADS * N_TOK * (3 * 64 + 2 * XW)):
+        _lib.check(lib.rp_emm_grad_bf16(_p(qkv), ld, _p(xa), _p(w), _p(rlse2), _p(clse2), _p(rho), _p(gam), _p(dqkv), Z, HEADS, sc, 0, _st()),
+                   "rp_emm_grad_bf16(q)")
+    _lib.check(lib.rp_emm_grad_bf16(_p(qkv), ld, _p(xa), _p(wp), _p(rlse2), _p(clse2), _p(rho), _p(gam), _p(dqkv), Z, HEADS, sc, 1, _st()),
+               "rp_emm_grad_bf16(k)")
+    return dqkv
+
+
 # ------------------------------------------------------------------------------------------------
 # autograd Functions
 # ------------------------------------------------------------------------------------------------
@@ -1383,13 +1434,17 @@ class CrossBlockFn(_Fn):
         x = x.contiguous()
         Z = x.shape[0]
         x2 = x.view(Z * N_TOK, DIM)
-        qkv, xn, m1, r1 = ln_linear(x2, n1w, n1b, qkv_w, qkv_b, train=train)
-        rlse, clse = emm_stats(qkv, Z, single)
-        xa = emm_build_x(qkv, pos, Z)
-        t, fpart = emm_apply(qkv, xa, rlse, clse, Z, swap=False, want_t=train, single=single,
-                             x_left=xa if cross else None)
         ctx.single, ctx.cross = single, cross
-        g = emm_finalize(fpart, Z)                                     # [Z*70, 224]
+        if _bf16_path() and not single and not cross:      # the bf16 data path (csrc/emm_bf16.hip): bf16 q | k | v, X, T; log2 normalisers
+            qkv, xn, m1, r1 = ln_linear(x2, n1w, n1b, qkv_w, qkv_b, train=train, out_dtype=torch.bfloat16, xn_dtype=torch.bfloat16)
+            g, (xa, t, rlse, clse) = emm_forward_bf16(qkv, pos, Z)
+        else:
+            qkv, xn, m1, r1 = ln_linear(x2, n1w, n1b, qkv_w, qkv_b, train=train)
+            rlse, clse = emm_stats(qkv, Z, single)
+            xa = emm_build_x(qkv, pos, Z)
+            t, fpart = emm_apply(qkv, xa, rlse, clse, Z, swap=False, want_t=train, single=single,
+                                 x_left=xa if cross else None)
+            g = emm_finalize(fpart, Z)                                 # [Z*70, 224]
         pf_wp = _padded(pf_w, (0, GW - pf_w.shape[1]))
         f = linear(g, pf_wp, pf_b)                                     # [Z*70, 192]
         y, fn, m2, r2, h, hpre = _mlp_block_fwd(f, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b, train)
@@ -1415,9 +1470,15 @@ class CrossBlockFn(_Fn):
             dpfw_full, dpfb = _param_grads(fork, df_, g)
             dg = linear_dx(df_, pf_wp)                                      # [Z*70, 224]
             dF = emm_finalize_bwd(dg, Z)
-            dqkv = emm_backward(qkv, xa, t, rlse, clse, dF, Z, single=ctx.single, cross=ctx.cross)
-            fork.sync_side()
-            dqkvw, dqkvb = _param_grads(fork, dqkv, xn)
+            if qkv.dtype == torch.bfloat16:
+                dqkv = emm_backward_bf16(qkv, xa, t, rlse, clse, dF, Z)
+                fork.sync_side()
+                dqkvw = fork.on_side(lambda: linear_dw(dqkv, xn))
+                dqkvb = dqkv.sum(0, dtype=torch.float32)                # (one bf16 pass per step; the Blocks get theirs from kernel epilogues)
+            else:
+                dqkv = emm_backward(qkv, xa, t, rlse, clse, dF, Z, single=ctx.single, cross=ctx.cross)
+                fork.sync_side()
+                dqkvw, dqkvb = _param_grads(fork, dqkv, xn)
             dx, dn1w, dn1b = linear_dx_lnbwd(dqkv, qkv_w, x2, n1w, m1, r1)
             fork.sync_main()
         dpfw = dpfw_full[:, :ctx.pf_cols].contiguous()

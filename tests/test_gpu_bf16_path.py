@@ -173,3 +173,47 @@ def test_row_resident_linear_bf16_rows_in_and_out(ops):
         assert do.dtype == torch.bfloat16 and torch.equal(do, ops.linear_dx(dy, W).to(torch.bfloat16))
     finally:
         ops.set_gemm_precision(0)
+
+
+def _emm_ref(qkv64, pos, Z):
+    """fp64 F_z = X^T A X, T = A X, U = A^T X per (z,h) (tests/test_gpu_kernels.py::_emm_ref; X from the given, possibly rounded, qkv)"""
+    t = qkv64.view(Z, 576, 3, 3, 64).permute(2, 0, 3, 1, 4)
+    q, k, v = t[0], t[1], t[2]
+    perm = [z ^ 1 for z in range(Z)]
+    s = (q[perm] @ k.transpose(-1, -2)) * 0.125
+    a = s.softmax(-1) * s.softmax(-2)
+    pe = pos.to(torch.bfloat16).double()[[z // 2 for z in range(Z)]].unsqueeze(1).expand(Z, 3, 576, 6)      # X holds bf16 positional features
+    x = torch.cat([v, pe], dim=-1)
+    T = a @ x
+    return x.transpose(-1, -2) @ T, T, a.transpose(-1, -2) @ x, x
+
+
+def test_emm_bf16_path_forward_and_backward(ops):
+    """csrc/emm_bf16.hip against fp64 on the same bf16 q | k | v (and bf16-rounded positional features): X bit-exact; T = A X and
+    U = A^T X (bf16 outputs of bf16 probabilities) 1e-2 of their maxima; F = X^T T and the reshaped g 1e-2; the gradient thirds dq, dk,
+    dv of <F, dF> 3e-2 of their maxima (two bf16-rounded intermediates, W / T / U, per product)."""
+    Z = 4
+    qkv = rnd(Z * 576, 576, seed=4)
+    intr = torch.tensor([[30.0, 26.0, 12.0, 12.0], [18.0, 21.0, 12.0, 9.0]])[:, None, :].repeat(1, 2, 1).contiguous().cuda()
+    pos = ops.posenc(intr, Z // 2, qkv.device)
+    qb = qkv.to(torch.bfloat16)
+    q64 = qb.double().requires_grad_(True)
+    F_ref, T_ref, U_ref, x_ref = _emm_ref(q64, pos, Z)
+    g, (xa, t, rlse2, clse2) = ops.emm_forward_bf16(qb, pos, Z)
+    assert torch.equal(xa[..., :70].double(), x_ref.detach()) and float(xa[..., 70:].float().abs().max()) == 0.0
+    lib = ops._lib.load()
+    u = torch.empty_like(t)
+    ops._lib.check(lib.rp_emm_apply_bf16(ops._p(qb), 576, ops._p(xa), ops._p(rlse2), ops._p(clse2), ops._p(u), Z, 3, 0.125, 1, ops._st()), "swap")
+    g_ref = F_ref[[z ^ 1 for z in range(Z)]].reshape(Z, 210, 70).transpose(-1, -2)      # vision_transformer.py:229-230,238
+    e = dict(T=rel(t[..., :70], T_ref), U=rel(u[..., :70], U_ref), g=rel(g.view(Z, 70, 224)[..., :210], g_ref))
+    report("emm_bf16_fwd", **e)
+    assert max(e.values()) < 1e-2
+    assert float(g.view(Z, 70, 224)[..., 210:].abs().max()) == 0.0 and float(t[..., 70:].float().abs().max()) == 0.0
+    dF = torch.zeros(Z, 3, 96, 96, device="cuda")
+    dF[..., :70, :70] = rnd(Z, 3, 70, 70, seed=6)
+    (F_ref * dF[..., :70, :70].double()).sum().backward()
+    dqkv = ops.emm_backward_bf16(qb, xa, t, rlse2, clse2, dF, Z)
+    eb = [rel(dqkv[:, i * 192:(i + 1) * 192], q64.grad[:, i * 192:(i + 1) * 192]) for i in range(3)]
+    report("emm_bf16_bwd", dq=eb[0], dk=eb[1], dv=eb[2])
+    assert dqkv.dtype == torch.bfloat16 and max(eb) < 3e-2
+    assert torch.equal(dqkv, ops.emm_backward_bf16(qb, xa, t, rlse2, clse2, dF, Z))        # deterministic

@@ -231,13 +231,17 @@ __global__ __launch_bounds__(384, 2) void emm_small_bf16_kernel(EmmSmallP p) {
   const long long zh = zh_;
   const int h = zh_ % p.H, z = zh_ / p.H;
   const float* dfp = p.df + zh * XW * XW;
-  for (int e = tid; e < XW * XW / 4; e += 384) {
-    const float4 v = ld4(dfp + 4 * e);
-    const int a = (4 * e) / XW, c = (4 * e) % XW;
-    *reinterpret_cast<uint2*>(D + a * XW + c) = make_uint2(pk_bf16(v.x, v.y), pk_bf16(v.z, v.w));
-    const unsigned short b0 = (unsigned short)(pk_bf16(v.x, 0.f) & 0xffff), b1 = (unsigned short)(pk_bf16(v.y, 0.f) & 0xffff),
-                         b2 = (unsigned short)(pk_bf16(v.z, 0.f) & 0xffff), b3 = (unsigned short)(pk_bf16(v.w, 0.f) & 0xffff);
-    Dt[(c + 0) * XW + a] = b0; Dt[(c + 1) * XW + a] = b1; Dt[(c + 2) * XW + a] = b2; Dt[(c + 3) * XW + a] = b3;
+  for (int e = tid; e < (XW / 4) * (XW / 4); e += 384) {      // one 4 x 4 block per thread: 8-byte writes into both images
+    const int a = 4 * (e / (XW / 4)), c = 4 * (e % (XW / 4));
+    float4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = ld4(dfp + (a + k) * XW + c);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) *reinterpret_cast<uint2*>(D + (a + k) * XW + c) = make_uint2(pk_bf16(v[k].x, v[k].y), pk_bf16(v[k].z, v[k].w));
+    *reinterpret_cast<uint2*>(Dt + (c + 0) * XW + a) = make_uint2(pk_bf16(v[0].x, v[1].x), pk_bf16(v[2].x, v[3].x));
+    *reinterpret_cast<uint2*>(Dt + (c + 1) * XW + a) = make_uint2(pk_bf16(v[0].y, v[1].y), pk_bf16(v[2].y, v[3].y));
+    *reinterpret_cast<uint2*>(Dt + (c + 2) * XW + a) = make_uint2(pk_bf16(v[0].z, v[1].z), pk_bf16(v[2].z, v[3].z));
+    *reinterpret_cast<uint2*>(Dt + (c + 3) * XW + a) = make_uint2(pk_bf16(v[0].w, v[1].w), pk_bf16(v[2].w, v[3].w));
   }
   __syncthreads();
   const int i0 = (part * 6 + wave) * 32;
@@ -306,7 +310,7 @@ __global__ __launch_bounds__(384, 2) void emm_small_bf16_kernel(EmmSmallP p) {
 
 // ------------------------------------------------------------------------------------------------ dq / dk
 template <int NW>
-__global__ __launch_bounds__(NW * 64, 2) void emm_grad_bf16_kernel(EmmBfP p) {
+__global__ __launch_bounds__(NW * 64, 3) void emm_grad_bf16_kernel(EmmBfP p) {
   static_assert(NW == 2, "DMA plan written for 2-wave workgroups");
   __shared__ __attribute__((aligned(16))) bf16_t Ls[2][32 * 64];
   __shared__ __attribute__((aligned(16))) bf16_t Xs[2][32 * XW];

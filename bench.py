@@ -115,19 +115,35 @@ def cpu_baseline(hw, budget_s=20.0):
                       "torch-CPU oracle, %d of %d host threads (best of 8/16/32/64), %.1f s"
                       % (n, Bc, hw, hw, cores, ncpu, el)}
 
-TRAFFIC_FILES = ("r3_traffic.json", "r2_traffic.json")
+TRAFFIC_FILES = ("r4_traffic.json", "r3_traffic.json", "r2_traffic.json")
+
+
+def csrc_fingerprint():
+    """sha256 (first 16 hex digits) over rel_pose_amd/csrc/*.hip and *.h -- tools/pmc_bench.sh stores the same value in the traffic
+    file it writes, so a PMC figure measured on OTHER kernel sources is flagged instead of silently going stale."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "rel_pose_amd", "csrc")
+    for fn in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
+        with open(fn, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic(kname, files=TRAFFIC_FILES):
-    """HBM bytes per launch of `kname` from the committed rocprofv3 --pmc passes (they cannot run inside the timed process)."""
+    """(HBM bytes per launch of `kname`, source note, stale) from the committed rocprofv3 --pmc passes (they cannot run inside the timed
+    process).  stale = the kernel sources have changed since the passes ran (or the file predates the fingerprint)."""
     for fn in files:
         tpath = os.path.join(ROOT, "profiles", fn)
         if os.path.exists(tpath):
             with open(tpath) as f:
-                ent = json.load(f)["kernels"].get(kname)
+                doc = json.load(f)
+            ent = doc["kernels"].get(kname)
             if ent:
-                return round(ent["hbm_bytes_per_launch"]), "profiles/%s (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes)" % fn
-    return None, None
+                stale = doc.get("csrc_sha16") != csrc_fingerprint()
+                return (round(ent["hbm_bytes_per_launch"]), "profiles/%s (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes)" % fn, stale)
+    return None, None, None
 
 
 def supplementary_point(dev, tag, batch, hw, mode, precision, steps, warmup, timer_instance, kernel_symbol, traffic_files):
@@ -185,7 +201,7 @@ def supplementary_point(dev, tag, batch, hw, mode, precision, steps, warmup, tim
         pairs = batch * steps
         tf = flops / max(n_launch, 1) / max(t_launch, 1e-12) / 1e12
         gbs = timer.bytes / max(n_launch, 1) / max(t_launch, 1e-12) / 1e9
-        traffic, src = pmc_traffic(kernel_symbol, traffic_files)
+        traffic, src, stale = pmc_traffic(kernel_symbol, traffic_files)
         if nl == 1:
             # the bf16 configuration's Linear kernels move fp32-sized activations per bf16 MFMA flop: HBM is the roofline that binds
             roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
@@ -193,7 +209,7 @@ def supplementary_point(dev, tag, batch, hw, mode, precision, steps, warmup, tim
         else:
             roof = {"bound": "mfma", "achieved": round(tf, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4)}
-        roof.update({"traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": src,
+        roof.update({"traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": src, "traffic_stale": stale,
                      "algorithmic_bytes_per_launch_avg": timer.bytes / max(n_launch, 1), "kernel": kernel_symbol,
                      "launches_timed": n_launch, "avg_launch_us": round(t_launch * 1e6, 2), "flops_per_launch_avg": flops / max(n_launch, 1),
                      "hot_path_tflops_whole_step": round((3 if train else 1) * FLOPS_FWD_PER_PAIR * pairs / el / 1e12, 2)})
@@ -219,7 +235,8 @@ def parse_instance(text):
 
 TAG_SYMBOLS = {"mlp_fused_fwd": "mlp_fused_kernel<4, 3, 0, false, false>", "attn_fwd": "attn_fwd_kernel<2, false, 2, false, false>",
                "attn_stats": "attn_fwd_kernel<3, true, 2, false, true>", "linear_rows_ln": "linear_rows_kernel<true, false>",
-               "linear_rows": "linear_rows_kernel<false, false>"}
+               "linear_rows": "linear_rows_kernel<false, false>", "dw192_bf16": "dw192_bf16_kernel<false>",
+               "dw192_bf16_f32b": "dw192_bf16_kernel<true>", "attn_fwd_bf16": "attn_fwd_bf16_kernel<2, false, 1>"}
 
 
 def main():
@@ -249,7 +266,8 @@ def main():
                          "bf16 = operands rounded to bf16 (BASELINE.json configs[4]; NOT the headline metric)")
     args = ap.parse_args()
     if args.timer_instance is None:
-        args.timer_instance = "mlp_fused_fwd" if (args.mode == "fwd" and args.precision == "fp32") else "1,1,1,3"
+        args.timer_instance = ("mlp_fused_fwd" if (args.mode == "fwd" and args.precision == "fp32") else
+                               "dw192_bf16" if (args.precision == "bf16" and args.mode == "train") else "1,1,1,3")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -393,7 +411,7 @@ def main():
         n_launch, t_launch, flops = timer.summary()
         achieved = flops / max(n_launch, 1) / max(t_launch, 1e-12) / 1e12
         pairs = world * args.batch * args.steps
-        traffic, traffic_src = None, None
+        traffic, traffic_src, traffic_stale = None, None, None
         nl = PRECISIONS[args.precision]
         # exact-fp32 launches with whole 32-wide k-tiles run the LDS-DMA-staged kernel (csrc/gemm_dma.hip), the bf16-limb
         # precisions the register-staged one (csrc/gemm.hip); same tiles, same template arguments
@@ -416,8 +434,8 @@ def main():
             if args.batch == 64 and nl == 0:
                 tfiles = TRAFFIC_FILES if train else ("r3_traffic_fwd.json",)
             elif args.batch == 128 and nl == 1 and train:
-                tfiles = ("r3_traffic_bf16.json",)
-        traffic, traffic_src = pmc_traffic(kname, tfiles) if tfiles else (None, None)
+                tfiles = ("r4_traffic_bf16.json", "r3_traffic_bf16.json")
+        traffic, traffic_src, traffic_stale = pmc_traffic(kname, tfiles) if tfiles else (None, None, None)
         rec = {
             "metric": METRIC, "value": round(pairs / el, 2), "unit": "image-pairs/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 3),
@@ -437,7 +455,7 @@ def main():
                        "hot_path_share": "ViT+EMM+regressor on HIP kernels; ResNet front-end on MIOpen (SURVEY 8f-1)"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1),
                          "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "peak_note": peak_note, "traffic": traffic,
-                         "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": traffic_src,
+                         "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": traffic_src, "traffic_stale": traffic_stale,
                          "algorithmic_bytes_per_launch_avg": timer.bytes / max(n_launch, 1),
                          "kernel": kname, "launches_timed": n_launch,
                          "avg_launch_us": round(t_launch * 1e6, 2),
@@ -454,8 +472,8 @@ def main():
                                               kernel_symbol=TAG_SYMBOLS["mlp_fused_fwd"], traffic_files=("r3_traffic_fwd.json",))),
                             ("bf16_128", dict(tag="train.py step, bf16 MFMA operands in Linear / attention / EMM GEMMs and the MIOpen "
                                                   "convolutions, fp32 accumulate (BASELINE configs[4] per-GPU workload)",
-                                              batch=128, mode="train", precision="bf16", steps=20, warmup=3, timer_instance=(1, 1, 1, 3),
-                                              kernel_symbol="gemm_kernel<1, 1, 1, 3, 1>", traffic_files=("r3_traffic_bf16.json",)))):
+                                              batch=128, mode="train", precision="bf16", steps=20, warmup=3, timer_instance="dw192_bf16",
+                                              kernel_symbol="dw192_bf16_kernel<false>", traffic_files=("r4_traffic_bf16.json", "r3_traffic_bf16.json")))):
                 try:
                     sup[key] = supplementary_point(dev, hw=args.hw, **kw)
                 except Exception as e:          # a supplementary point must never take the headline line down with it

@@ -660,7 +660,7 @@ def _dw192(a, b, out, trans):
     nbytes = lib.rp_dw192_bf16_workspace_bytes(M, N)
     deferred = (_SPLITK_BATCH is not None and torch.cuda.current_stream(a.device).cuda_stream == _SPLITK_BATCH[2])
     ws = _arena_take(nbytes, a.device, _SPLITK_BATCH[1]) if deferred else _workspace(nbytes, a.device)
-    with timed("dw192_bf16", 2.0 * M * N * DIM, M * (2.0 * N + b.element_size() * DIM) + 4.0 * sk * N * DIM):
+    with timed("dw192_bf16" if b.dtype == torch.bfloat16 else "dw192_bf16_f32b", 2.0 * M * N * DIM, M * (2.0 * N + b.element_size() * DIM) + 4.0 * sk * N * DIM):
         _lib.check(lib.rp_dw192_bf16(_p(a), N, _p(b), 1 if b.dtype == torch.float32 else 0, M, N, _p(ws), nbytes, _st()), "rp_dw192_bf16")
     task = (ws, out, N, DIM, N if trans else DIM, sk, trans)
     if deferred:

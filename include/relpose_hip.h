@@ -37,7 +37,7 @@ extern "C" {
  * binding (rel_pose_amd/_lib.py parses both macros and counts the declarations) rejects a stale .so at load time instead of
  * failing later on a missing symbol. */
 #define RP_ABI_VERSION 11
-#define RP_ABI_EXPORTS 80
+#define RP_ABI_EXPORTS 82
 int rp_abi_version(void);
 int rp_abi_export_count(void);
 const char* rp_target_arch(void);
@@ -364,6 +364,16 @@ int rp_emm_grad_ds(const float* qkv, int ldqkv, const float* x, const float* w, 
 int rp_dw192_bf16_splits(int M, int N);
 size_t rp_dw192_bf16_workspace_bytes(int M, int N);
 int rp_dw192_bf16(const void* a, int lda, const void* b, int b_is_f32, int M, int N, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Input gradient of the qkv Linear with the LayerNorm backward behind it, on the bf16 data path (csrc/dx_lnbwd_bf16.hip):
+ *   dx = LayerNorm'(dY W; x, gamma, mean, rstd) (+ add)   for dY [M,576] BF16, wt = W^T [192][576] BF16 (host copy of the fp32 master),
+ *   x / add / dx [M,192] fp32 (vision_transformer.py:323,352 and their autograd).  Output-resident: a wave keeps 16 whole 192-wide
+ *   output rows in its accumulators, dY is read once as MFMA operands, the gradient of the LayerNorm output never reaches memory.
+ *   part [ceil(M / rp_dx_lnbwd_bf16_tile_rows())][np][192] (np = 3 with add, else 2) receives the per-tile column sums of dxn o xhat
+ *   (dgamma), dxn (dbeta) and add (the bias gradient of the Linear that produced it); the caller column-sums them. */
+int rp_dx_lnbwd_bf16_tile_rows(void);
+int rp_dx_lnbwd_bf16(const void* dy, const void* wt, const float* x, const float* gamma, const float* mean, const float* rstd,
+                     const float* add, float* dx, float* part, int M, int K, void* stream);
 
 /* rp_emm_finalize for f_part [Z][H][nparts][96][96] (nparts = 6: rp_emm_apply's workgroup partials; 1: rp_emm_f_bf16's whole F) */
 int rp_emm_finalize_parts(const float* f_part, float* g, int Z, int H, int ldg, int nparts, void* stream);

@@ -102,6 +102,8 @@ _SIGS = {
     "rp_dw192_bf16_splits": (c_int, [I, I]),
     "rp_dw192_bf16_workspace_bytes": (c_size_t, [I, I]),
     "rp_dw192_bf16": (c_int, [P, I, P, I, I, I, P, c_size_t, P]),
+    "rp_dx_lnbwd_bf16_tile_rows": (c_int, []),
+    "rp_dx_lnbwd_bf16": (c_int, [P, P, P, P, P, P, P, P, P, I, I, P]),
     "rp_emm_finalize_parts": (c_int, [P, P, I, I, I, I, P]),
     "rp_emm_build_x_bf16": (c_int, [P, P, P, I, I, I, P]),
     "rp_emm_apply_bf16": (c_int, [P, I, P, P, P, P, I, I, F, I, P]),

@@ -631,6 +631,7 @@ def linear_dx(dy, W, dact=0, aux=None, want_colsum=False, out_dtype=None):
 
 # LayerNorm backward fused into the epilogue of the input-gradient GEMM that feeds it (RpGemm.ln_*): the exact-fp32 GEMM only
 FUSE_LN_BWD = os.environ.get("RP_FUSE_LN_BWD", "1") == "1"
+DX_LNBWD_BF16 = os.environ.get("RP_DX_LNBWD_BF16", "1") == "1"      # A/B aid
 
 
 def linear_dx_lnbwd(dy, W, x, gamma, mean, rstd, add=None):
@@ -639,6 +640,21 @@ def linear_dx_lnbwd(dy, W, x, gamma, mean, rstd, add=None):
     if not FUSE_LN_BWD or W.shape[1] != DIM:
         return layernorm_bwd(linear_dx(dy, W), x, gamma, mean, rstd, add=add)
     M, N = dy.shape
+    if DX_LNBWD_BF16 and dy.dtype == torch.bfloat16 and GEMM_PRECISION == 1 and N == 3 * DIM and dy.is_contiguous():
+        # the bf16 data path: output-resident kernel, dY read once as MFMA operands (csrc/dx_lnbwd_bf16.hip)
+        lib = _lib.load()
+        _chk(x, gamma, mean, rstd, add)
+        np_ = 3 if add is not None else 2
+        part = _empty(-(-M // lib.rp_dx_lnbwd_bf16_tile_rows()), np_ * DIM, like=x)
+        dx = torch.empty_like(x)
+        wt = bf16_weight(transposed(W))
+        with timed("dx_lnbwd_bf16", 2.0 * M * N * DIM, M * (2.0 * N + 4.0 * DIM * (3 if add is not None else 2))):
+            _lib.check(lib.rp_dx_lnbwd_bf16(_p(dy), _p(wt), _p(x), _p(gamma), _p(mean), _p(rstd), _p(add), _p(dx), _p(part), M, N, _st()),
+                       "rp_dx_lnbwd_bf16")
+        sums = colsum(part)
+        if add is None:
+            return dx, sums[:DIM], sums[DIM:]
+        return dx, sums[:DIM], sums[DIM:2 * DIM], sums[2 * DIM:]
     np_ = 3 if add is not None else 2
     part = _empty(-(-M // 64), np_ * DIM, like=dy)
     dx = gemm(dy, W, M, DIM, N, b_layout=1, residual=add, ln=(x, mean, rstd, gamma, part))
@@ -1386,6 +1402,8 @@ class BlockFn(_Fn):
         y, xn2, m2, r2, h, hpre = _mlp_block_fwd(x1, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b, train)
         if train:
             register_transposed(proj_w, fc1_w, fc2_w)
+            if bfp:
+                register_transposed(qkv_w)          # W_qkv^T for the output-resident input-gradient kernel (rp_dx_lnbwd_bf16)
             ctx.save_for_backward(x2, m1, r1, xn1, qkv, o, lse, x1, m2, r2, xn2, h, hpre, n1w, qkv_w, proj_w, n2w,
                                   fc1_w, fc2_w)
             ctx.Z = Z
@@ -1450,6 +1468,8 @@ class CrossBlockFn(_Fn):
         y, fn, m2, r2, h, hpre = _mlp_block_fwd(f, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b, train)
         if train:
             register_transposed(fc1_w, fc2_w)
+            if qkv.dtype == torch.bfloat16:
+                register_transposed(qkv_w)
             ctx.save_for_backward(x2, m1, r1, xn, qkv, rlse, clse, xa, t, g, f, m2, r2, fn, h, hpre, n1w, qkv_w, pf_wp,
                                   n2w, fc1_w, fc2_w)
             ctx.Z = Z

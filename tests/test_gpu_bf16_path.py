@@ -217,3 +217,34 @@ def test_emm_bf16_path_forward_and_backward(ops):
     report("emm_bf16_bwd", dq=eb[0], dk=eb[1], dv=eb[2])
     assert dqkv.dtype == torch.bfloat16 and max(eb) < 3e-2
     assert torch.equal(dqkv, ops.emm_backward_bf16(qb, xa, t, rlse2, clse2, dF, Z))        # deterministic
+
+
+@pytest.mark.parametrize("M", [576 * 2, 576 * 3 + 40])
+@pytest.mark.parametrize("with_add", [True, False])
+def test_qkv_input_gradient_with_layernorm_backward_bf16(ops, M, with_add):
+    """rp_dx_lnbwd_bf16 through ops.linear_dx_lnbwd (bf16 dY [M,576]): dx, dgamma, dbeta (and the column sums of `add`) against fp64
+    autograd of y = LayerNorm(x) W^T with the rounded operands.  fp32 accumulation of exact bf16 products, fp32 LayerNorm algebra:
+    2e-5 of the maxima (a ragged last tile included)."""
+    ops.set_gemm_precision(1)
+    try:
+        W = rnd(576, 192, seed=21, scale=0.07)
+        x = rnd(M, 192, seed=22)
+        g, be = 1 + 0.1 * rnd(192, seed=23), 0.1 * rnd(192, seed=24)
+        dy = rnd(M, 576, seed=25).to(torch.bfloat16)
+        add = rnd(M, 192, seed=26) if with_add else None
+        _, mean, rstd = ops.layernorm_fwd(x, g, be)
+        out = ops.linear_dx_lnbwd(dy, W, x, g, mean, rstd, add=add)
+        x64 = x.double().requires_grad_(True)
+        g64, b64 = g.double().requires_grad_(True), be.double().requires_grad_(True)
+        xn = torch.nn.functional.layer_norm(x64, (192,), g64, b64, 1e-6)
+        (xn @ W.to(torch.bfloat16).double().t() * dy.double()).sum().backward()
+        dx_ref = x64.grad + (add.double() if with_add else 0)
+        e = dict(dx=rel(out[0], dx_ref), dgamma=rel(out[1], g64.grad), dbeta=rel(out[2], b64.grad))
+        if with_add:
+            e["colsum_add"] = rel(out[3], add.double().sum(0))
+        report("dx_lnbwd_bf16[M=%d,add=%d]" % (M, with_add), **e)
+        assert max(e.values()) < 2e-5
+        out2 = ops.linear_dx_lnbwd(dy, W, x, g, mean, rstd, add=add)
+        assert all(torch.equal(a, b) for a, b in zip(out, out2))
+    finally:
+        ops.set_gemm_precision(0)

@@ -16,7 +16,7 @@ done
 python3 - "$tag" <<'PY'
 import csv, glob, json, os, sys, collections
 tag = sys.argv[1]
-KEEP = ('dw192', 'gemm_', 'attn_', 'emm_', 'colsum', 'ln_', 'splitk', 'rowdot', 'tokens_', 'mlp_', 'linear_', 'ds_matmul', 'conv', 'bn_')
+KEEP = ('dw192', 'dx_lnbwd', 'gemm_', 'attn_', 'emm_', 'colsum', 'ln_', 'splitk', 'rowdot', 'tokens_', 'mlp_', 'linear_', 'ds_matmul', 'conv', 'bn_')
 def short(k):
     return k.replace('(anonymous namespace)::', '').replace('rpgemm::', '').replace('void ', '').split('(')[0]
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))

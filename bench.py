@@ -315,7 +315,7 @@ def main():
         net = model                                                    # the graphs do their own single flat all-reduce
     # fused=True: the reference's torch.optim.Adam update (train.py:69) as one multi-tensor kernel instead of ~10
     opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=5e-4, weight_decay=1e-5,
-                           capturable=graphed, fused=not graphed)
+                           capturable=graphed, fused=True)
     images, poses, intr = synthetic_batch(args.batch, args.hw, dev, 1234 + rank)
     Ps = SE3(poses)
     Gs = SE3.IdentityLike(Ps)

@@ -6,8 +6,8 @@
 //     A = softmax(S, -1) * softmax(S, -2) = exp(2 S - rlse_i - clse_j)      (dual softmax, :205-206)
 //     X = [v_z | pos | 0]                              [576 x 96], 70 live columns (:215-216)
 //     F = X^T A X                                      [70 x 70] (:222-223)
-// The 576x576 matrices never exist in memory: rlse / clse come from two stats-only passes of the
-// attention kernel; rp_emm_apply recomputes S tile by tile (one wave = 32 "owner" rows, tiles of 32 "loop"
+// The 576x576 matrices never exist in memory: rlse / clse come from ONE statistics pass over S (rp_emm_stats: the attention
+// kernel's statistics form with per-block column partials; two statistics-only passes in the bf16-MFMA mode); rp_emm_apply recomputes S tile by tile (one wave = 32 "owner" rows, tiles of 32 "loop"
 // rows staged in LDS), forms A in registers, accumulates T = A X with the score accumulators used directly as
 // the MFMA A operand, then contracts F_partial = X_blk^T T_blk per workgroup through LDS (the "LDS-tiled
 // outer product" of the task statement).  Six workgroup partials per (z, h) are summed in fixed order by

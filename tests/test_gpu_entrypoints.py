@@ -319,7 +319,8 @@ def test_graphed_train_step_matches_the_eager_step():
     losses = {}
     for mode in ("eager", "graph"):
         net = copy.deepcopy(net0)
-        opt = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=1e-4, capturable=True)
+        opt = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=1e-4, capturable=True)      # (non-fused: torch's fused capturable Adam is itself only reproducible to ~2e-3 of the loss after two
+        # steps between two processes' orderings, tools/lab/graph_probe.py; bench.py --graph uses the fused one for speed)
         gs = GraphedTrainStep(net, opt, images, poses, intr)
         out = []
         if mode == "graph":

@@ -92,6 +92,26 @@ RP_DEV float gelu_grad_fast(float x) {
   return fmaf(x, pdf, cdf);
 }
 
+// GELU of the bf16 configuration (BASELINE.json configs[4]; the BF instantiations of mlp_fused.hip / linear_rows.hip only): the
+// sigmoid ("tanh") form  x / (1 + exp2(-x (K0 + K1 x^2))),  K0 = 2 sqrt(2/pi) log2(e), K1 = 0.044715 K0 -- 5 VALU + v_exp + v_rcp
+// against the 14 + v_exp of gelu_fast: torch's GELU(approximate='tanh').  |gelu_bf - exact-erf GELU| <= 4.8e-4 ABSOLUTE over the reals
+// (at x = +-2.7; 2e-4 of the value for x > 0.5, but up to 5 % of the value in the negative tail where |GELU| ~ 1e-2): the size of the
+// bf16 storage rounding (2e-3 of the value; h is stored as bf16 in this configuration) of an element of magnitude 0.24 -- small against
+// the rounding noise of the typical |h| ~ 1 elements it is summed with, NOT below the rounding of every element.  It buys epilogue VALU time, which ADDS to
+// the MFMA time on gfx950 and dominates these kernels (150 VALU per 24 MFMAs and chunk), drops by ~40 %.  gelu_bf_grad is the exact
+// derivative of gelu_bf (forward and backward stay consistent): s + x s (1 - s)(A + B x^2), s the sigmoid, 9 VALU + 2 transcendentals.
+RP_DEV float gelu_bf(float x) {
+  const float u = x * fmaf(x * x, 0.10294324f, 2.3022082f);
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-u));
+}
+RP_DEV float gelu_bf_grad(float x) {
+  const float x2 = x * x;
+  const float u = x * fmaf(x2, 0.10294324f, 2.3022082f);
+  const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-u));
+  const float dv = fmaf(x2, 0.21406445f, 1.5957692f);
+  return fmaf(x * fmaf(-s, s, s), dv, s);
+}
+
 // exp / softmax arithmetic runs in the log2 domain: scores are produced pre-multiplied by log2(e) (folded into the
 // operand prescale), so every probability is ONE v_exp_f32 instead of libm's ~25-instruction expf (which was ~half of
 // the non-MFMA time per attention tile).  v_exp_f32 is accurate to ~1 ulp; measured pose error stays ~1e-6.

@@ -307,12 +307,22 @@ __global__ __launch_bounds__(NT, 3) void linear_rows_kernel(RowsP p) {
       pp1 = v1;
       if (has_aux) {
         asm volatile("" : "+v"(g0.x), "+v"(g0.y), "+v"(g0.z), "+v"(g0.w), "+v"(g1.x), "+v"(g1.y), "+v"(g1.z), "+v"(g1.w) :: "memory");
+        if constexpr (BF) {       // (the bf16 configuration's GELU pair, common.h: gelu_bf / gelu_bf_grad -- the same one mlp_fused.hip uses)
+          v0 = make_float4(v0.x * gelu_bf_grad(g0.x), v0.y * gelu_bf_grad(g0.y), v0.z * gelu_bf_grad(g0.z), v0.w * gelu_bf_grad(g0.w));
+          v1 = make_float4(v1.x * gelu_bf_grad(g1.x), v1.y * gelu_bf_grad(g1.y), v1.z * gelu_bf_grad(g1.z), v1.w * gelu_bf_grad(g1.w));
+        } else {
         v0 = make_float4(v0.x * gelu_grad_fast(g0.x), v0.y * gelu_grad_fast(g0.y), v0.z * gelu_grad_fast(g0.z), v0.w * gelu_grad_fast(g0.w));
         v1 = make_float4(v1.x * gelu_grad_fast(g1.x), v1.y * gelu_grad_fast(g1.y), v1.z * gelu_grad_fast(g1.z), v1.w * gelu_grad_fast(g1.w));
+        }
       }
       if (p.act == 1) {
+        if constexpr (BF) {
+          v0 = make_float4(gelu_bf(v0.x), gelu_bf(v0.y), gelu_bf(v0.z), gelu_bf(v0.w));
+          v1 = make_float4(gelu_bf(v1.x), gelu_bf(v1.y), gelu_bf(v1.z), gelu_bf(v1.w));
+        } else {
         v0 = make_float4(gelu_fast(v0.x), gelu_fast(v0.y), gelu_fast(v0.z), gelu_fast(v0.w));
         v1 = make_float4(gelu_fast(v1.x), gelu_fast(v1.y), gelu_fast(v1.z), gelu_fast(v1.w));
+        }
       }
       pv0 = make_float4(v0.x + r0.x, v0.y + r0.y, v0.z + r0.z, v0.w + r0.w);
       pv1 = make_float4(v1.x + r1.x, v1.y + r1.y, v1.z + r1.z, v1.w + r1.w);

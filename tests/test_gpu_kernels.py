@@ -1096,7 +1096,7 @@ def test_fused_mlp_forward_bf16_configuration(ops, M):
 def test_fused_mlp_backward_bf16_configuration(ops, M):
     """rp_mlp_fused_bwd at operand precision 1 (v_mfma_f32_16x16x32_bf16 from bf16 weight copies, the second one in the kernel's
     chunk-permuted unit order).  With bf16-representable dy and weights the FIRST product is exact: dhp must match fp64 to fp32
-    accuracy (3e-6); dxn contracts the bf16-rounded dhp -- against the fp64 product of exactly those rounded values also 3e-6, and
+    accuracy (5e-6: v_exp_f32 / v_rcp_f32 are 1-ulp instructions); dxn contracts the bf16-rounded dhp -- against the fp64 product of exactly those rounded values also 3e-6, and
     within the stated bf16 tolerance (2e-2) of the unrounded chain.  bf16 storage: a bf16 hpre is read exactly and a bf16 dhp is the
     round-to-nearest-even of the fp32 one BIT FOR BIT; column sums come from the fp32 values."""
     import torch.nn.functional as F
@@ -1106,8 +1106,11 @@ def test_fused_mlp_backward_bf16_configuration(ops, M):
     w2 = q(rnd(192, 768, seed=6, scale=768 ** -0.5))
     dy = q(rnd(M, 192, seed=9))
     hp = q(rnd(M, 768, seed=8, scale=1.5))                     # bf16-representable pre-activation: the bf16-stored run reads the same values
-    a = hp.double()
-    gp = 0.5 * (1 + torch.erf(a / math.sqrt(2))) + a * torch.exp(-0.5 * a * a) / math.sqrt(2 * math.pi)
+    # the bf16 configuration's GELU is torch's approximate='tanh' form (csrc/common.h: gelu_bf, |difference to the erf form| <= 4.8e-4,
+    # below the bf16 storage rounding of the typical hidden value); the backward multiplies by ITS exact derivative
+    a = hp.double().requires_grad_(True)
+    F.gelu(a, approximate="tanh").sum().backward()
+    gp = a.grad
     dhp_ref = (dy.double() @ w2.double()) * gp
     prev = ops.GEMM_PRECISION
     ops.set_gemm_precision(1)
@@ -1122,7 +1125,7 @@ def test_fused_mlp_backward_bf16_configuration(ops, M):
     finally:
         ops.set_gemm_precision(prev)
     report("mlp_fused_bwd_bf16_M%d" % M, **e)
-    assert max(e["dhp"], e["db1"], e["dxn_of_rounded_dhp"]) < 3e-6 and e["dxn"] < 2e-2, e
+    assert max(e["dhp"], e["db1"]) < 5e-6 and e["dxn_of_rounded_dhp"] < 3e-6 and e["dxn"] < 2e-2, e
     with pytest.raises(RuntimeError):
         ops.mlp_fused_bwd(dy, hp.to(bf), w1, w2)                  # bf16 storage only in the bf16 configuration
 

@@ -236,7 +236,7 @@ def parse_instance(text):
 TAG_SYMBOLS = {"mlp_fused_fwd": "mlp_fused_kernel<4, 3, 0, false, false>", "attn_fwd": "attn_fwd_kernel<2, false, 2, false, false>",
                "attn_stats": "attn_fwd_kernel<3, true, 2, false, true>", "linear_rows_ln": "linear_rows_kernel<true, false>",
                "linear_rows": "linear_rows_kernel<false, false>", "dw192_bf16": "dw192_bf16_kernel<false>",
-               "dw192_bf16_f32b": "dw192_bf16_kernel<true>", "attn_fwd_bf16": "attn_fwd_bf16_kernel<2, false, 1>"}
+               "dw192_bf16_f32b": "dw192_bf16_kernel<true>", "dw192_f32": "dw192_f32_kernel", "attn_fwd_bf16": "attn_fwd_bf16_kernel<2, false, 1>"}
 
 
 def main():
@@ -267,7 +267,8 @@ def main():
     args = ap.parse_args()
     if args.timer_instance is None:
         args.timer_instance = ("mlp_fused_fwd" if (args.mode == "fwd" and args.precision == "fp32") else
-                               "dw192_bf16" if (args.precision == "bf16" and args.mode == "train") else "1,1,1,3")
+                               "dw192_bf16" if (args.precision == "bf16" and args.mode == "train") else
+                               "dw192_f32" if (args.precision == "fp32" and args.mode == "train") else "1,1,1,3")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -37,7 +37,7 @@ extern "C" {
  * binding (rel_pose_amd/_lib.py parses both macros and counts the declarations) rejects a stale .so at load time instead of
  * failing later on a missing symbol. */
 #define RP_ABI_VERSION 11
-#define RP_ABI_EXPORTS 82
+#define RP_ABI_EXPORTS 85
 int rp_abi_version(void);
 int rp_abi_export_count(void);
 const char* rp_target_arch(void);
@@ -361,6 +361,11 @@ int rp_emm_grad_ds(const float* qkv, int ldqkv, const float* x, const float* w, 
  * rows); it leaves rp_dw192_bf16_splits(M, N) split-K slabs [split][N][192] fp32 in `workspace`, which the caller finishes with
  * rp_splitk_reduce_multi (task {ws, C, M = N, N = 192, ldc, split_k, trans_c}: trans_c writes C^T, e.g. fc2's [192,768] weight from
  * A = h [M,768]) -- deterministic, and batchable with the other weight gradients of a block. */
+int rp_dw192_f32_splits(int M, int N);
+size_t rp_dw192_f32_workspace_bytes(int M, int N);
+/* the same product in EXACT fp32 (csrc/dw192_f32.hip; A and B fp32, M a multiple of 32): output-stationary [192 x 192] tiles, one wave
+ * per SIMD on v_mfma_f32_32x32x2_f32, LDS-DMA stages -- the parity path's weight gradients (replaces rp_gemm's split-K form for them) */
+int rp_dw192_f32(const float* a, int lda, const float* b, int M, int N, void* workspace, size_t workspace_bytes, void* stream);
 int rp_dw192_bf16_splits(int M, int N);
 size_t rp_dw192_bf16_workspace_bytes(int M, int N);
 int rp_dw192_bf16(const void* a, int lda, const void* b, int b_is_f32, int M, int N, void* workspace, size_t workspace_bytes, void* stream);

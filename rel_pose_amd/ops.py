@@ -667,17 +667,27 @@ def linear_dx_lnbwd(dy, W, x, gamma, mean, rstd, add=None):
 DW192 = os.environ.get("RP_DW192", "1") == "1"      # A/B aid: the streaming bf16 weight-gradient kernel of the bf16 data path
 
 
+DW192_F32 = os.environ.get("RP_DW192_F32", "1") == "1"      # A/B aid: the output-stationary exact-fp32 weight-gradient kernel
+
+
 def _dw192(a, b, out, trans):
-    """slabs of a^T b by rp_dw192_bf16 (a [M,N] bf16, b [M,192] bf16 / fp32) + the fixed-order split-K reduce into `out`
-    ([N,192], or [192,N] when trans) -- deferred into the enclosing splitk_batch like every other weight gradient."""
+    """slabs of a^T b by rp_dw192_bf16 (a [M,N] bf16, b [M,192] bf16 / fp32) or rp_dw192_f32 (both fp32, exact) + the fixed-order
+    split-K reduce into `out` ([N,192], or [192,N] when trans) -- deferred into the enclosing splitk_batch like every other
+    weight gradient."""
     lib = _lib.load()
     M, N = a.shape
-    sk = lib.rp_dw192_bf16_splits(M, N)
-    nbytes = lib.rp_dw192_bf16_workspace_bytes(M, N)
+    f32 = a.dtype == torch.float32
+    sk = (lib.rp_dw192_f32_splits if f32 else lib.rp_dw192_bf16_splits)(M, N)
+    nbytes = (lib.rp_dw192_f32_workspace_bytes if f32 else lib.rp_dw192_bf16_workspace_bytes)(M, N)
     deferred = (_SPLITK_BATCH is not None and torch.cuda.current_stream(a.device).cuda_stream == _SPLITK_BATCH[2])
     ws = _arena_take(nbytes, a.device, _SPLITK_BATCH[1]) if deferred else _workspace(nbytes, a.device)
-    with timed("dw192_bf16" if b.dtype == torch.bfloat16 else "dw192_bf16_f32b", 2.0 * M * N * DIM, M * (2.0 * N + b.element_size() * DIM) + 4.0 * sk * N * DIM):
-        _lib.check(lib.rp_dw192_bf16(_p(a), N, _p(b), 1 if b.dtype == torch.float32 else 0, M, N, _p(ws), nbytes, _st()), "rp_dw192_bf16")
+    if f32:
+        with timed("dw192_f32", 2.0 * M * N * DIM, 4.0 * (M * (N + DIM) + sk * N * DIM)):
+            _lib.check(lib.rp_dw192_f32(_p(a), N, _p(b), M, N, _p(ws), nbytes, _st()), "rp_dw192_f32")
+    else:
+        with timed("dw192_bf16" if b.dtype == torch.bfloat16 else "dw192_bf16_f32b", 2.0 * M * N * DIM,
+                   M * (2.0 * N + b.element_size() * DIM) + 4.0 * sk * N * DIM):
+            _lib.check(lib.rp_dw192_bf16(_p(a), N, _p(b), 1 if b.dtype == torch.float32 else 0, M, N, _p(ws), nbytes, _st()), "rp_dw192_bf16")
     task = (ws, out, N, DIM, N if trans else DIM, sk, trans)
     if deferred:
         _SPLITK_BATCH[0].append(task)
@@ -698,6 +708,13 @@ def linear_dw(dy, x):
         if dy.dtype == bfd and N % DIM == 0 and K == DIM and (N >= K or x.dtype != bfd):
             return _dw192(dy, x, torch.empty(N, K, device=dy.device, dtype=torch.float32), False)
         if x.dtype == bfd and K % DIM == 0 and N == DIM:
+            return _dw192(x, dy, torch.empty(N, K, device=dy.device, dtype=torch.float32), True)
+    if (DW192_F32 and GEMM_PRECISION == 0 and M % 32 == 0 and M >= 4096 and dy.dtype == torch.float32 and x.dtype == torch.float32
+            and dy.is_contiguous() and x.is_contiguous()):
+        # exact fp32: the wider operand streams as "A" of the output-stationary kernel, the 192-wide one as "B"
+        if N % DIM == 0 and K == DIM and N >= K:
+            return _dw192(dy, x, torch.empty(N, K, device=dy.device, dtype=torch.float32), False)
+        if K % DIM == 0 and N == DIM:
             return _dw192(x, dy, torch.empty(N, K, device=dy.device, dtype=torch.float32), True)
     if x.dtype != torch.float32 and not (K > N and M >= 4096):
         x = x.float()              # (only the A operand of rp_gemm may be bf16-stored; small launches are not worth a second form)

@@ -1265,3 +1265,27 @@ def test_transposed_weight_cache_and_batched_transposes(ops):
     ops.invalidate_pad_cache()
     fresh = ops.transposed(ws[3])
     assert fresh is not stale and torch.equal(fresh, ws[3].detach().t())
+
+
+@pytest.mark.parametrize("M,N", [(4096, 192), (4096 + 640, 576), (9 * 4096, 768)])
+def test_weight_gradient_output_stationary_fp32(ops, M, N, monkeypatch):
+    """rp_dw192_f32 (exact fp32, output-stationary [192 x 192] tiles + the fixed-order split-K reduce) through ops.linear_dw, both
+    orientations, against fp64 (3e-6 of max|dW|: fp32 products and sums over ~600-row slabs) and against the rp_gemm split-K form it
+    replaces (same arithmetic in another summation order: 3e-6); deterministic; deferred reduce inside ops.splitk_batch gives the
+    same bits."""
+    wide = rnd(M, N, seed=3)
+    nar = rnd(M, 192, seed=4)
+    ref = wide.double().t() @ nar.double()
+    dw = ops.linear_dw(wide, nar)                      # dy wide: [N,192]
+    dw2 = ops.linear_dw(nar, wide)                     # x wide: [192,N] (transposed by the reduce)
+    e1, e2 = rel(dw, ref), rel(dw2, ref.t())
+    monkeypatch.setattr(ops, "DW192_F32", False)
+    old, old2 = ops.linear_dw(wide, nar), ops.linear_dw(nar, wide)
+    monkeypatch.setattr(ops, "DW192_F32", True)
+    e3 = max(rel(dw, old), rel(dw2, old2))
+    report("dw192_f32[M=%d,N=%d]" % (M, N), direct=e1, transposed=e2, vs_rp_gemm=e3)
+    assert dw.shape == (N, 192) and dw2.shape == (192, N) and max(e1, e2, e3) < 3e-6
+    assert torch.equal(dw, ops.linear_dw(wide, nar))
+    with ops.splitk_batch():
+        d3, d4 = ops.linear_dw(wide, nar), ops.linear_dw(nar, wide)
+    assert torch.equal(d3, dw) and torch.equal(d4, dw2)

@@ -18,7 +18,9 @@
 // The contraction order inside a k-group is free, so both A operands are read as one ds_read_b128 per 4 k-steps.
 // Weights: W1 chunk [32 x 192] and W2 chunk [192 x 32] (24 KB each) are staged by LDS-DMA (global_load_lds_dwordx4, lane-linear
 // -> unpadded tiles, XOR-swizzled 16-byte chunks so that the 16 rows one read group touches fall into 16 distinct bank groups);
-// single-buffered, two barriers per chunk: W2(c) streams in under GEMM1(c), W1(c+1) under GEMM2(c).
+// single-buffered, two barriers per chunk: W2(c) streams in under GEMM1(c), W1(c+1) under GEMM2(c).  (The bf16 form -- one workgroup
+// per CU, an eighth of the matrix time per chunk -- stages W1 | W2 (| the chunk's h_pre rows, MODE 1) in a three-stage ring filled two
+// chunks ahead, with one barrier per chunk and hand-counted vmcnt waits that leave the chunk's stores in flight: see NS below.)
 //
 // Balance (stream-K).  The work list is (row tile of 16*NW rows) x (24 chunks), cut into gridDim.x equal contiguous ranges, one per
 // resident workgroup: 576 row tiles on 512 workgroup slots would otherwise run as 1 + 1/8 rounds.  A workgroup that owns all 24
@@ -81,16 +83,27 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
   static_assert((TILE_FL / 4) % NT == 0, "tile must be a whole number of DMA rounds");
   static_assert(!BF || NW == 12, "the bf16 form stages its 12 KB weight tiles in one DMA round of 768 threads");
   static_assert(!TRAIN || MODE == 0, "TRAIN is the training form of the forward");
-  __shared__ __attribute__((aligned(16))) float w1t[TILE_FL];
-  __shared__ __attribute__((aligned(16))) float w2t[TILE_FL];
+  // fp32: one W1 and one W2 tile, single-buffered (two barriers per chunk; three workgroups per CU cover each other's DMA latency).
+  // BF: ONE workgroup per CU and 8x less matrix time per chunk -- a ring of NS stages, each the W1 | W2 tiles of one chunk (24 KB), filled
+  // two chunks ahead; one barrier per chunk (a single-buffered tile exposed the L2 -> LDS latency twice per chunk: 3.3 us per chunk for
+  // 0.5 us of MFMA work)
+  constexpr int NS = BF ? 3 : 1;
+  constexpr int STG = (BF && MODE == 1 ? 3 : 2) * TILE_FL;      // floats per stage (BF, MODE 1: + the h_pre tile of the chunk, [192 rows][32 units] bf16)
+  __shared__ __attribute__((aligned(16))) float wt[NS * STG];
+  float* const w1t = wt;
+  float* const w2t = wt + TILE_FL;
   // MODE 0: gamma | beta of the LayerNorm (b1 is read from L2: staging all of it here would cost the third resident workgroup per
   // CU, measured with tools/lab/rows_probe); MODE 1: per-wave column sums of a chunk
-  __shared__ __attribute__((aligned(16))) float b1s[MODE == 0 ? 2 * C : NW * CH];
+  // (BF: + all of b1 for MODE 0 -- LDS is not what limits a 12-wave workgroup; MODE 1: two parities of the per-wave sums)
+  __shared__ __attribute__((aligned(16))) float b1s[MODE == 0 ? (BF ? 3 * C + HID : 3 * C) : (BF ? 2 : 1) * NW * CH];
   if (MODE == 0) {
     for (int i = threadIdx.x; i < C; i += NW * 64) {
       b1s[i] = p.gamma[i];
       b1s[C + i] = p.beta[i];
+      b1s[2 * C + i] = p.b2[i];
     }
+    if (BF)
+      for (int i = threadIdx.x; i < HID; i += NW * 64) b1s[3 * C + i] = p.b1[i];
     __syncthreads();
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, q = lane >> 4;
@@ -103,7 +116,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
     if (BF) {
       const int row1 = pp / 24, sl1 = pp % 24, ch1 = (sl1 & ~7) | ((sl1 & 7) ^ ((row1 >> 1) & 7));
       off1[r] = (unsigned)(row1 * C * 2 + ch1 * 16);
-      const int row2 = pp >> 2, ch2 = (pp & 3) ^ ((row2 >> 2) & 3);
+      const int row2 = pp >> 2, ch2 = (pp & 3) ^ ((0 - (row2 >> 2)) & 3);      // (key: dx_lnbwd_bf16.hip -- ds_read_b128's real lane groups)
       off2[r] = (unsigned)(row2 * HID * 2 + ch2 * 16);
     } else {
       const int row1 = pp / 48, ch1 = (pp % 48) ^ (row1 & 15);
@@ -124,10 +137,46 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
     for (int r = 0; r < DMA; ++r) glds16(src, off2[r], l2 + r * NT * 16);
   };
 
+  const bool hp_dma = BF && MODE == 1 && (p.io_bf16 & 4);       // bf16 h_pre rows travel with the weights (one more DMA instruction per wave)
+  auto issue_stage = [&](int item) {               // BF: the tiles of work item `item` (row tile item / 24, chunk item % 24) into ring stage item % NS
+    const int cc = item % NCHUNK;
+    const unsigned so = (unsigned)(item % NS) * (STG * 4);
+    glds16(uniform_ptr(p.w1 + (long long)cc * CH * (C / 2)), off1[0], l1 + so);
+    glds16(uniform_ptr(p.w2 + cc * (CH / 2)), off2[0], l2 + so);
+    if (MODE == 1 && hp_dma) {                      // LDS position tid = (row tid >> 2, 16-byte slot tid & 3), rows past M clamped
+      const long long r0 = (long long)(item / NCHUNK) * ROWS;
+      const int r = (int)min((long long)(tid >> 2), (long long)p.M - 1 - r0);
+      glds16(uniform_ptr(reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(p.hpre) + r0 * HID + cc * CH)), (unsigned)(r * HID * 2 + ((tid & 3) ^ ((tid >> 4) & 3)) * 16),
+             l2 + so + TILE_FL * 4);
+    }
+  };
+  auto wait_vm = [&](int n) {                       // s_waitcnt vmcnt(n) (+ lgkmcnt(0)) and the workgroup barrier; n is wave-uniform
+    switch (n) {
+      case 2: asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+      case 7: asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+      case 10: asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    }
+  };
+
   int it, cnt;
   item_range(p, blockIdx.x, it, cnt);
   const int end = it + cnt;
-  if (cnt > 0) issue_w1(it % NCHUNK);
+  if constexpr (BF) {
+    for (int i = 0; i < NS - 1; ++i)
+      if (cnt > i) issue_stage(it + i);
+  } else {
+    if (cnt > 0) issue_w1(it % NCHUNK);
+  }
+  // BF: besides its DMA instructions a wave issues ns stores of the hidden tensors per chunk.  Vector-memory operations retire in issue
+  // order (gfx9: loads and stores share vmcnt), so "stage `it` has landed" is vmcnt(K), K = everything issued after DMA(it) = the stores
+  // of chunks it - 2 and it - 1 and the DMA instructions of the top of chunk it - 1 (wave 0's column-sum stores of MODE 1 only make its
+  // wait stricter).  Exact only when every wave stores in every chunk: M a whole number of tiles (576 tokens = 3 tiles per image) --
+  // otherwise, and with fp32 h_pre rows (plain loads in the chunk), every wait is vmcnt(0).
+  const int ns_bf = TRAIN ? ((p.io_bf16 & 2) ? 2 : 4) : MODE == 1 ? ((p.io_bf16 & 2) ? 1 : 2) : 0;
+  const int kvm = (BF && p.M % ROWS == 0 && (MODE != 1 || hp_dma)) ? (NS - 1) * ns_bf + (NS - 2) * (MODE == 1 ? 3 : 2) : 0;
   int seg = 0;
   while (it < end) {
     const int tile = it / NCHUNK, c0 = it % NCHUNK, c1 = min(NCHUNK, c0 + end - it);
@@ -192,27 +241,54 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
     const int bfo = (q & 1) ? 16 + 4 * (q - 1) - 4 * q : 0;      // element offset of a lane's 8 consecutive units in a bf16 row (st/ld_bf16x8)
 
     for (int c = c0; c < c1; ++c, ++it) {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // W1(c) landed everywhere; W2 tile free
-      issue_w2(c);
       const long long ho = (long long)min(row, p.M - 1) * HID + c * CH + 4 * q;
       float4 g0p = make_float4(0.f, 0.f, 0.f, 0.f), g1p = g0p;
+      const float* w1s = w1t;                       // this chunk's staged tiles
+      const float* w2s = w2t;
+      if constexpr (BF) {
+        // stage `it` landed everywhere (exact count from the third chunk of a tile segment on and while the DMA of it + 1 was issued;
+        // everything older is complete after the first chunk's vmcnt(0)); everybody is past chunk it - 1: its stage takes it + 2
+        wait_vm((c >= c0 + NS - 1 && it + NS - 2 < end) ? kvm : 0);
+        if (MODE == 1) {
+          if (!hp_dma) {
+            if (hpre_bf) {
+              ld_bf16x8(reinterpret_cast<const unsigned short*>(p.hpre) + ho + bfo, g0p, g1p, q);
+            } else {
+              g0p = ld4(p.hpre + ho);
+              g1p = ld4(p.hpre + ho + 16);
+            }
+          }
+          if (c > c0 && tid < CH) {                 // the previous chunk's column sums (all waves passed the barrier after writing them)
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) sum += b1s[((c - 1) & 1) * NW * CH + w * CH + tid];
+            p.colpart[(long long)tile * HID + ((it - 1) % NCHUNK) * CH + tid] = sum;
+          }
+        }
+        if (MODE == 0) {
+          g0p = ld4(b1s + 3 * C + c * CH + 4 * q);
+          g1p = ld4(b1s + 3 * C + c * CH + 16 + 4 * q);
+        }
+        if (it + NS - 1 < end) issue_stage(it + NS - 1);
+        w1s = wt + (it % NS) * STG;
+        w2s = w1s + TILE_FL;
+      } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // W1(c) landed everywhere; W2 tile free
+      issue_w2(c);
       if (MODE == 0) {
         g0p = ld4(p.b1 + c * CH + 4 * q);
         g1p = ld4(p.b1 + c * CH + 16 + 4 * q);
       }
       if (MODE == 1) {
-        if (hpre_bf) {
-          ld_bf16x8(reinterpret_cast<const unsigned short*>(p.hpre) + ho + bfo, g0p, g1p, q);
-        } else {
-          g0p = ld4(p.hpre + ho);
-          g1p = ld4(p.hpre + ho + 16);
-        }
+        g0p = ld4(p.hpre + ho);
+        g1p = ld4(p.hpre + ho + 16);
         asm volatile("" ::: "memory");            // issue here, under GEMM1 -- not where the values are first used
+      }
       }
       // ---- GEMM1: two 16-unit blocks, K = 192
       f32x4v h0 = {0.f, 0.f, 0.f, 0.f}, h1 = {0.f, 0.f, 0.f, 0.f};
       if constexpr (BF) {
-        const float* w0 = w1t + j * (C / 2);
+        const float* w0 = w1s + j * (C / 2);
         const float* w1r = w0 + 16 * (C / 2);
         const int key = (j >> 1) & 7;
 #pragma unroll
@@ -268,6 +344,13 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
         h1[2] = gelu_fast(h1[2] + bb.z); h1[3] = gelu_fast(h1[3] + bb.w);
         }
       } else {
+        if (BF && hp_dma) {     // this lane's eight h_pre values from the staged tile: row 16 wave + j, units 4 q .. + 3 and 16 + 4 q .. + 3
+          // (16-byte slots of a row XOR-ed with (row >> 2) & 3 by the DMA: rows j, j + 4, j + 8, j + 12 of a half-wave land in different banks)
+          const unsigned short* hp = reinterpret_cast<const unsigned short*>(w2s + TILE_FL) + (wave * 16 + j) * CH + 4 * (q & 1);
+          const int hk = (j >> 2) & 3;
+          g0p = widen4(*reinterpret_cast<const uint2*>(hp + 8 * ((q >> 1) ^ hk)));
+          g1p = widen4(*reinterpret_cast<const uint2*>(hp + 8 * ((2 + (q >> 1)) ^ hk)));
+        }
         // (opaque redefinition after GEMM1's LDS reads: otherwise hipcc starts GELU' -- and waits for the loads -- at the chunk's top)
         asm volatile("" : "+v"(g0p.x), "+v"(g0p.y), "+v"(g0p.z), "+v"(g0p.w), "+v"(g1p.x), "+v"(g1p.y), "+v"(g1p.z), "+v"(g1p.w)
                      :: "memory");
@@ -292,12 +375,15 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) cs[r] = row16_sum(cs[r]);
         if (j == 0) {
-          st4(b1s + wave * CH + 4 * q, make_float4(cs[0], cs[1], cs[2], cs[3]));
-          st4(b1s + wave * CH + 16 + 4 * q, make_float4(cs[4], cs[5], cs[6], cs[7]));
+          float* cp = b1s + (BF ? (c & 1) * NW * CH : 0) + wave * CH;
+          st4(cp + 4 * q, make_float4(cs[0], cs[1], cs[2], cs[3]));
+          st4(cp + 16 + 4 * q, make_float4(cs[4], cs[5], cs[6], cs[7]));
         }
       }
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // W2(c) landed everywhere; W1 tile free
-      if (it + 1 < end) issue_w1((it + 1) % NCHUNK);
+      if constexpr (!BF) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // W2(c) landed everywhere; W1 tile free
+        if (it + 1 < end) issue_w1(((it + 1) % NCHUNK));
+      }
       if (TRAIN && live) {      // (after the DMA issue, like MODE 1's stores)
         if (dhp_bf) {           // bf16 configuration: the hidden tensors live in bf16
           st_bf16x8(reinterpret_cast<unsigned short*>(p.dhp) + ho + bfo, pre0, pre1, q);
@@ -320,7 +406,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
             st4(p.dhp + ho + 16, make_float4(h1[0], h1[1], h1[2], h1[3]));
           }
         }
-        if (tid < CH) {
+        if (!BF && tid < CH) {
           float sum = 0.f;
 #pragma unroll
           for (int w = 0; w < NW; ++w) sum += b1s[w * CH + tid];
@@ -333,7 +419,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
 #pragma unroll
         for (int ob = 0; ob < 12; ++ob) {
           const int r2 = 16 * ob + j;
-          const float4 a = ld4(w2t + r2 * (CH / 2) + ((q ^ ((r2 >> 2) & 3)) * 4));
+          const float4 a = ld4(w2s + r2 * (CH / 2) + ((q ^ ((0 - (r2 >> 2)) & 3)) * 4));
           acc[ob] = mfma16bf(__builtin_bit_cast(bf16x8, a), hb, acc[ob]);
         }
       } else {
@@ -365,19 +451,32 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
       }
       }
     }
+    if (BF && MODE == 1) {                          // the segment's last chunk's column sums
+      __syncthreads();
+      if (tid < CH) {
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) sum += b1s[((c1 - 1) & 1) * NW * CH + w * CH + tid];
+        p.colpart[(long long)tile * HID + ((it - 1) % NCHUNK) * CH + tid] = sum;
+      }
+    }
     // ---- epilogue: lane (j, q) holds Y[row j][16 ob + 4q + 0..3]
     if (c0 == 0 && c1 == NCHUNK) {
       if (live) {
         float* yr = p.y + (long long)row * C + 4 * q;
+        // ALL residual loads first, then the stores: y may alias x for the compiler, so "load, add, store" per block came out as twelve
+        // serialized round trips (s_waitcnt vmcnt(0) before every store, behind every store already in flight -- vmcnt retires in order)
+        float4 rr[12];
+#pragma unroll
+        for (int ob = 0; ob < 12; ++ob) rr[ob] = MODE == 0 ? ld4(xrow + 16 * ob + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (MODE == 0) asm volatile("" ::: "memory");
 #pragma unroll
         for (int ob = 0; ob < 12; ++ob) {
-          float4 r = make_float4(0.f, 0.f, 0.f, 0.f), b2 = r;
-          if (MODE == 0) {
-            r = ld4(xrow + 16 * ob + 4 * q);
-            b2 = ld4(p.b2 + 16 * ob + 4 * q);
-          }
-          st4(yr + 16 * ob, make_float4(acc[ob][0] + b2.x + r.x, acc[ob][1] + b2.y + r.y, acc[ob][2] + b2.z + r.z,
-                                        acc[ob][3] + b2.w + r.w));
+          float4 b2 = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (MODE == 0) b2 = ld4(b1s + 2 * C + 16 * ob + 4 * q);
+          const float4 r = rr[ob];
+          const float4 yv = make_float4(acc[ob][0] + b2.x + r.x, acc[ob][1] + b2.y + r.y, acc[ob][2] + b2.z + r.z, acc[ob][3] + b2.w + r.w);
+          st4(yr + 16 * ob, yv);
         }
       }
     } else {

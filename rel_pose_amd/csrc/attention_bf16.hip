@@ -122,7 +122,7 @@ __global__ __launch_bounds__(NW * 64 * GR, (NW * GR + 3) / 4 >= 3 ? 3 : 4) void 
   // accumulator set costs occupancy.  What bounds this kernel is the sum of the two pipes' work, not their overlap.)
   for (int s = 0; s < NSTAGE; ++s) {
     const int buf = s & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of stage s have landed ...
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // this wave's pieces of stage s have landed (and its LDS reads returned) ...
     __builtin_amdgcn_s_barrier();                         // ... and everybody's; everybody is also done reading the other buffer
     if (s + 1 < NSTAGE) issue(s + 1, buf ^ 1);
     const bf16_t* Kt = Ks[buf];
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 3 : 2) void attn_bwd_dkdv_bf16_k
   f32x16 dv0 = zero16(), dv1 = zero16(), dk0 = zero16(), dk1 = zero16();
   for (int s = 0; s < NSTAGE; ++s) {
     const int buf = s & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (s + 1 < NSTAGE) issue(s + 1, buf ^ 1);
 #pragma unroll
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_bwd_dq_bf16_kernel(AttnBwdBfP
   f32x16 dq0 = zero16(), dq1 = zero16();
   for (int s = 0; s < NSTAGE; ++s) {
     const int buf = s & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (s + 1 < NSTAGE) issue(s + 1, buf ^ 1);
 #pragma unroll

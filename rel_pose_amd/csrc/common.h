@@ -190,22 +190,21 @@ RP_DEV float4 widen4(uint2 w) {          // 4 bf16 -> fp32 (exact)
 // lane (j, q) holds units 4q..4q+3 of a 32-unit chunk's first 16 (v0) and second 16 (v1); after swapping halves with lane q ^ 1
 // (lane ^ 16) it stores 8 consecutive bf16: even q -> [own v0 | partner's v0], odd q -> [partner's v1 | own v1]
 RP_DEV void st_bf16x8(unsigned short* dst, float4 v0, float4 v1, int q) {
-  (void)q;
-  // v_permlane16_swap: odd 16-lane rows of the first operand <-> even rows of the second, i.e. (even q's v1) <-> (odd q's v0)
-  const auto s0 = __builtin_amdgcn_permlane16_swap(pk_bf16(v0.x, v0.y), pk_bf16(v1.x, v1.y), false, false);
-  const auto s1 = __builtin_amdgcn_permlane16_swap(pk_bf16(v0.z, v0.w), pk_bf16(v1.z, v1.w), false, false);
-  *reinterpret_cast<uint4*>(dst) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+  const unsigned a0 = pk_bf16(v0.x, v0.y), a1 = pk_bf16(v0.z, v0.w), b0 = pk_bf16(v1.x, v1.y), b1 = pk_bf16(v1.z, v1.w);
+  const bool odd = q & 1;
+  const unsigned s0 = odd ? a0 : b0, s1 = odd ? a1 : b1;
+  const unsigned r0 = __shfl_xor(s0, 16, 64), r1 = __shfl_xor(s1, 16, 64);
+  const uint4 w = odd ? make_uint4(r0, r1, b0, b1) : make_uint4(a0, a1, r0, r1);
+  *reinterpret_cast<uint4*>(dst) = w;
 }
 // the inverse for a bf16 aux row: one 16-byte load of 8 consecutive units per lane, halves swapped back into (v0, v1)
-RP_DEV void unpack_bf16x8(uint4 w, float4& v0, float4& v1) {
-  const auto s0 = __builtin_amdgcn_permlane16_swap(w.x, w.z, false, false);
-  const auto s1 = __builtin_amdgcn_permlane16_swap(w.y, w.w, false, false);
-  v0 = widen4(make_uint2(s0[0], s1[0]));
-  v1 = widen4(make_uint2(s0[1], s1[1]));
-}
 RP_DEV void ld_bf16x8(const unsigned short* src, float4& v0, float4& v1, int q) {
-  (void)q;
-  unpack_bf16x8(*reinterpret_cast<const uint4*>(src), v0, v1);
+  const uint4 w = *reinterpret_cast<const uint4*>(src);
+  const bool odd = q & 1;
+  const unsigned s0 = odd ? w.x : w.z, s1 = odd ? w.y : w.w;          // even q sends the partner's v0 half, odd q the partner's v1 half
+  const unsigned r0 = __shfl_xor(s0, 16, 64), r1 = __shfl_xor(s1, 16, 64);
+  v0 = odd ? widen4(make_uint2(r0, r1)) : widen4(make_uint2(w.x, w.y));
+  v1 = odd ? widen4(make_uint2(w.z, w.w)) : widen4(make_uint2(r0, r1));
 }
 
 // XCD-aware work order for the (image, head) x row-block kernels: workgroup b runs on XCD b % 8 (private 4 MB L2), so

@@ -174,8 +174,8 @@ __global__ __launch_bounds__(256, 1) void dw192_bf16_kernel(DwP p) {
     for (int s = 0; s < nst; ++s) {
       // stage s has landed (12 DMA instructions per wave and stage; stage s + 1 may stay in flight) -- for everybody -- and everybody
       // is past iteration s - 1, whose slot the DMA of stage s + 2 refills
-      if (s + 1 < nst) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (s + 1 < nst) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       if (s + 2 < nst) {
         const int nb = buf == 0 ? 2 : buf - 1;                        // (s + 2) % 3

@@ -40,6 +40,7 @@ template <int KC>                                // KC = K / 32 chunks (18 for K
 __global__ __launch_bounds__(NWV * 64, 3) void dx_lnbwd_bf16_kernel(DxP p) {
   __shared__ __attribute__((aligned(16))) bf16_t Ws[3][CHUNK_EL];
   __shared__ float red[3][NWV][C];
+  __shared__ __attribute__((aligned(16))) float gam[C];      // gamma (read back after the main loop's barriers)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, q = lane >> 4;
   const int tile = blockIdx.x;
   const int row = tile * ROWS + wave * 16 + j;
@@ -61,6 +62,7 @@ __global__ __launch_bounds__(NWV * 64, 3) void dx_lnbwd_bf16_kernel(DxP p) {
   };
   issue(0, 0);
   issue(1, 1);
+  if (tid < C) gam[tid] = p.gamma[tid];
 
   // the wave's 16 dY rows as B operands: lane (j, q) holds k = 32 c + 8 q .. + 7 of row j
   bf16x8 yb[KC];
@@ -78,8 +80,10 @@ __global__ __launch_bounds__(NWV * 64, 3) void dx_lnbwd_bf16_kernel(DxP p) {
 #pragma unroll
   for (int c = 0; c < KC; ++c) {
     // chunk c landed (chunk c + 1 may stay in flight: 3 DMA instructions per wave and chunk) for everybody; everybody is past chunk c - 1
-    if (c + 1 < KC) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (lgkmcnt(0): this wave's LDS reads of chunk c - 1 have RETURNED before it signals the barrier -- the MFMAs that consume them may be
+    // scheduled behind the barrier, and the slot they read is refilled by the DMA issued right after it)
+    if (c + 1 < KC) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (c + 2 < KC) issue(c + 2, (c + 2) % 3);
     const bf16_t* wtile = Ws[c % 3] + aoff;
@@ -93,7 +97,7 @@ __global__ __launch_bounds__(NWV * 64, 3) void dx_lnbwd_bf16_kernel(DxP p) {
 #pragma unroll
   for (int b = 0; b < 12; ++b) {
     // (requesting these rows under the last MFMA chunks was measured: 131 -> 143 us -- the extra live registers cost more than the exposed latency)
-    const float4 xv = ld4(p.x + rc * C + 16 * b + 4 * q), gv = ld4(p.gamma + 16 * b + 4 * q);
+    const float4 xv = ld4(p.x + rc * C + 16 * b + 4 * q), gv = ld4(gam + 16 * b + 4 * q);
     const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -108,12 +112,23 @@ __global__ __launch_bounds__(NWV * 64, 3) void dx_lnbwd_bf16_kernel(DxP p) {
   s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
   const float c1 = s1 * (1.0f / C), c2 = s2 * (1.0f / C);
   const float m = live ? 1.f : 0.f;
+  // the residual-branch rows are requested AHEAD of the stores (dx may alias add for the compiler: written as "load, compute, store"
+  // per block the twelve blocks were twelve serialized memory round trips -- s_waitcnt vmcnt(0) before every store, and vmcnt retires
+  // in order, so each wait also covered the previous store); a window of PF blocks stays in flight
+  constexpr int PF = 4;
+  float4 avq[12];
+#pragma unroll
+  for (int b = 0; b < 12; ++b) avq[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.add) {
+#pragma unroll
+    for (int b = 0; b < PF; ++b) avq[b] = ld4(p.add + rc * C + 16 * b + 4 * q);
+  }
 #pragma unroll
   for (int b = 0; b < 12; ++b) {
-    const float4 gv = ld4(p.gamma + 16 * b + 4 * q);
+    const float4 gv = ld4(gam + 16 * b + 4 * q);
     const float gs[4] = {gv.x, gv.y, gv.z, gv.w};
-    float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.add) av = ld4(p.add + rc * C + 16 * b + 4 * q);
+    if (p.add && b + PF < 12) avq[b + PF] = ld4(p.add + rc * C + 16 * (b + PF) + 4 * q);
+    const float4 av = avq[b];
     const float as[4] = {av.x, av.y, av.z, av.w};
     float o[4], cg[4], cb[4], ca[4];
 #pragma unroll

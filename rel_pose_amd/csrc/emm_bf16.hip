@@ -131,7 +131,7 @@ __global__ __launch_bounds__(NW * 64, 3) void emm_apply_bf16_kernel(EmmBfP p) {
   f32x16 tacc[3] = {zero16(), zero16(), zero16()};
   for (int s = 0; s < NTOK / 32; ++s) {
     const int buf = s & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (s + 1 < NTOK / 32) issue(s + 1, buf ^ 1);
     const bf16_t* Lt = Ls[buf];
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(192, 2) void emm_f_bf16_kernel(const bf16_t* __rest
   f32x16 acc[3] = {zero16(), zero16(), zero16()};
   for (int s = 0; s < NTOK / 64; ++s) {
     const int buf = s & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (s + 1 < NTOK / 64) issue(s + 1, buf ^ 1);
 #pragma unroll
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(NW * 64, 3) void emm_grad_bf16_kernel(EmmBfP p) {
   f32x16 d0 = zero16(), d1 = zero16();
   for (int s = 0; s < NTOK / 32; ++s) {
     const int buf = s & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (s + 1 < NTOK / 32) issue(s + 1, buf ^ 1);
     const bf16_t* Lt = Ls[buf];

@@ -90,7 +90,7 @@ class ViTEss(nn.Module):
         """preprocessing + CNN front-end -> [2B,192,24,24] (PyTorch-ROCm / MIOpen: 'next' row 8f-1)."""
         if intrinsics is not None:
             intrinsics = self.update_intrinsics(images.shape, intrinsics)
-        with ops.batches_tracked_batch():
+        with ops.batches_tracked_batch(), ops.conv_params_bf16(self.resnet.layer1, self.resnet.layer2, self.extractor_final_conv):
             return self._cnn_layers(images), intrinsics
 
     def _cnn_layers(self, images):

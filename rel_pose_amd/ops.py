@@ -1700,11 +1700,57 @@ def set_cnn_precision(p):
     CNN_PRECISION = p
 
 
+class _CastParamsFn(torch.autograd.Function):
+    """bf16 copies of a list of fp32 parameters as ONE multi-tensor launch each way (forward: fp32 -> bf16, backward: the bf16
+    gradients -> fp32).  Per convolution this was a cast kernel forward and another backward: 35 launches of 6-8 us per step."""
+
+    @staticmethod
+    def forward(ctx, *ps):
+        outs = [torch.empty_like(p, dtype=torch.bfloat16) for p in ps]
+        torch._foreach_copy_(outs, [p.detach() for p in ps])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        live = [g for g in gs if g is not None]
+        outs = [torch.empty_like(g, dtype=torch.float32) for g in live]
+        if live:
+            torch._foreach_copy_(outs, live)
+        it = iter(outs)
+        return tuple(None if g is None else next(it) for g in gs)
+
+
+class conv_params_bf16:
+    """`with conv_params_bf16(module):` -- at CNN precision 1 every nn.Conv2d below `module` finds its bf16 weight / bias copies ready
+    (made by one _CastParamsFn call) instead of casting them itself; the copies live for the block only (the optimizer changes the
+    masters between steps)."""
+
+    def __init__(self, *roots):
+        self.convs = [m for r in roots for m in r.modules() if isinstance(m, torch.nn.Conv2d)] if CNN_PRECISION == 1 else []
+
+    def __enter__(self):
+        if self.convs and self.convs[0].weight.is_cuda:
+            ps = [m.weight for m in self.convs] + [m.bias for m in self.convs if m.bias is not None]
+            cs = _CastParamsFn.apply(*ps)
+            nb = iter(cs[len(self.convs):])
+            for m, w in zip(self.convs, cs):
+                m._rp_bf16 = (w, None if m.bias is None else next(nb))
+        return self
+
+    def __exit__(self, et, ev, tb):
+        for m in self.convs:
+            m._rp_bf16 = None
+        return False
+
+
 def conv2d(m, x):
     """nn.Conv2d module `m` applied to x at the configured operand precision."""
     if CNN_PRECISION == 0 or not x.is_cuda:
         return m(x)
     bf = torch.bfloat16
+    ready = getattr(m, "_rp_bf16", None)
+    if ready is not None:
+        return torch.nn.functional.conv2d(x if x.dtype == bf else x.to(bf), ready[0], ready[1], m.stride, m.padding, m.dilation, m.groups)
     # activations STAY bf16 between the convolutions (the BatchNorm / ReLU / pool kernels of csrc/batchnorm.hip take bf16 storage):
     # only the first convolution's input and the small weights are cast
     return torch.nn.functional.conv2d(x if x.dtype == bf else x.to(bf), m.weight.to(bf), None if m.bias is None else m.bias.to(bf),

@@ -248,3 +248,67 @@ def test_qkv_input_gradient_with_layernorm_backward_bf16(ops, M, with_add):
         assert all(torch.equal(a, b) for a, b in zip(out, out2))
     finally:
         ops.set_gemm_precision(0)
+
+
+def _same(a, b):
+    if isinstance(a, (tuple, list)):
+        return all(_same(u, v) for u, v in zip(a, b) if u is not None)
+    return torch.equal(a, b)
+
+
+def test_bf16_path_kernels_are_bit_reproducible_at_full_size(ops):
+    """Every kernel of the bf16 data path, at BASELINE.json configs[4]'s per-GPU size (256 images, M = 147 456 token rows), launched
+    eight times on the same inputs: bit-identical outputs.  The kernels stage operands by LDS-DMA into rings whose slots are refilled
+    right behind a workgroup barrier; the small-size determinism checks above cannot see a slot being refilled while a slow wave's
+    LDS reads of it are still in flight (found in round 4: rp_dx_lnbwd_bf16 corrupted a 16-unit block of ~9 of 2304 row tiles per
+    launch under full load -- its barrier wait lacked lgkmcnt(0) and the unrolled loop let the MFMAs consuming the previous chunk's
+    reads be scheduled behind the barrier)."""
+    ops.set_gemm_precision(1)
+    ops.set_attention_precision(1)
+    try:
+        Z = 256
+        M = Z * 576
+        x, gm, bt = rnd(M, 192, seed=31), 1 + 0.1 * rnd(192, seed=32), 0.1 * rnd(192, seed=33)
+        W = rnd(576, 192, seed=34, scale=0.07)
+        dyb = rnd(M, 576, seed=35).to(torch.bfloat16)
+        add = rnd(M, 192, seed=36)
+        _, mean, rstd = ops.layernorm_fwd(x, gm, bt)
+        w1, b1 = rnd(768, 192, seed=37, scale=0.07), 0.1 * rnd(768, seed=38)
+        w2, b2 = rnd(192, 768, seed=39, scale=0.04), 0.1 * rnd(192, seed=40)
+        qb = rnd(M, 576, seed=41).to(torch.bfloat16)
+        dob = rnd(M, 192, seed=42).to(torch.bfloat16)
+        intr = torch.tensor([[30.0, 26.0, 12.0, 12.0]]).repeat(Z // 2, 2, 1).contiguous().cuda()
+        pos = ops.posenc(intr, Z // 2, qb.device)
+        dF = torch.zeros(Z, 3, 96, 96, device="cuda")
+        dF[..., :70, :70] = rnd(Z, 3, 70, 70, seed=43)
+        o, lse2 = ops.attn_fwd_bf16(qb, Z)
+        g, (xa, t, rl, cl) = ops.emm_forward_bf16(qb, pos, Z)
+        hpre = ops.mlp_fused(x, gm, bt, w1, b1, w2, b2, train=True, out_dtype=torch.bfloat16, xn_dtype=torch.bfloat16)[5]
+        xnb = x.to(torch.bfloat16)
+        cases = {
+            "dx_lnbwd": lambda: ops.linear_dx_lnbwd(dyb, W, x, gm, mean, rstd, add=add),
+            "attn_fwd": lambda: ops.attn_fwd_bf16(qb, Z),
+            "attn_bwd": lambda: ops.attn_bwd_bf16(qb, o, lse2, dob, Z),
+            "emm_fwd": lambda: ops.emm_forward_bf16(qb, pos, Z)[0],
+            "emm_bwd": lambda: ops.emm_backward_bf16(qb, xa, t, rl, cl, dF, Z),
+            "mlp_fwd": lambda: ops.mlp_fused(x, gm, bt, w1, b1, w2, b2, train=True, out_dtype=torch.bfloat16, xn_dtype=torch.bfloat16),
+            "mlp_bwd": lambda: ops.mlp_fused_bwd(add, hpre, w1, w2, out_dtype=torch.bfloat16),
+            "qkv_fwd": lambda: ops.ln_linear(x, gm, bt, W, 0.1 * gm.repeat(3), train=True, out_dtype=torch.bfloat16, xn_dtype=torch.bfloat16),
+            "dw_bf16": lambda: ops.linear_dw(dyb, xnb),
+            "dw_f32b": lambda: ops.linear_dw(dyb, x),
+        }
+        bad = {}
+        for name, fn in cases.items():
+            ref = fn()
+            torch.cuda.synchronize()
+            n = 0
+            for _ in range(8):
+                out = fn()
+                torch.cuda.synchronize()
+                n += 0 if _same(ref, out) else 1
+            bad[name] = float(n)
+        report("bf16_path_reproducible_256_images", **bad)
+        assert not any(bad.values()), bad
+    finally:
+        ops.set_gemm_precision(0)
+        ops.set_attention_precision(0)

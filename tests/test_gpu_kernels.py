@@ -1289,3 +1289,52 @@ def test_weight_gradient_output_stationary_fp32(ops, M, N, monkeypatch):
     with ops.splitk_batch():
         d3, d4 = ops.linear_dw(wide, nar), ops.linear_dw(nar, wide)
     assert torch.equal(d3, dw) and torch.equal(d4, dw2)
+
+
+def _same(a, b):
+    if isinstance(a, (tuple, list)):
+        return all(_same(u, v) for u, v in zip(a, b) if u is not None)
+    return torch.equal(a, b)
+
+
+def test_fp32_path_kernels_are_bit_reproducible_at_full_size(ops):
+    """The exact-fp32 kernels that stage operands through LDS rings (LDS-DMA, hand-counted waits), at the headline size (128 images,
+    M = 73 728 token rows), six launches each on the same inputs: bit-identical outputs.  Companion of
+    test_bf16_path_kernels_are_bit_reproducible_at_full_size (round 4 found a ring slot refilled under a slow wave's reads in one of the
+    bf16 kernels, visible only under full load)."""
+    Z = 128
+    M = Z * 576
+    x, gm, bt = rnd(M, 192, seed=51), 1 + 0.1 * rnd(192, seed=52), 0.1 * rnd(192, seed=53)
+    W = rnd(576, 192, seed=54, scale=0.07)
+    dy = rnd(M, 576, seed=55)
+    add = rnd(M, 192, seed=56)
+    _, mean, rstd = ops.layernorm_fwd(x, gm, bt)
+    w1, b1 = rnd(768, 192, seed=57, scale=0.07), 0.1 * rnd(768, seed=58)
+    w2, b2 = rnd(192, 768, seed=59, scale=0.04), 0.1 * rnd(192, seed=60)
+    qkv = rnd(M, 576, seed=61)
+    do = rnd(M, 192, seed=62)
+    o, lse = ops.attn_fwd(qkv, Z)
+    hpre = ops.mlp_fused(x, gm, bt, w1, b1, w2, b2, train=True)[5]
+    cases = {
+        "dw192_f32": lambda: ops.linear_dw(dy, x),
+        "qkv_dx_lnbwd": lambda: ops.linear_dx_lnbwd(dy, W, x, gm, mean, rstd, add=add),
+        "qkv_fwd": lambda: ops.ln_linear(x, gm, bt, W, 0.1 * gm.repeat(3), train=True),
+        "proj_fwd": lambda: ops.linear(do, W[:192], gm, residual=x),
+        "mlp_fwd": lambda: ops.mlp_fused(x, gm, bt, w1, b1, w2, b2, train=True),
+        "mlp_infer": lambda: ops.mlp_fused(x, gm, bt, w1, b1, w2, b2),
+        "mlp_bwd": lambda: ops.mlp_fused_bwd(add, hpre, w1, w2),
+        "attn_fwd": lambda: ops.attn_fwd(qkv, Z),
+        "attn_bwd": lambda: ops.attn_bwd(qkv, o, lse, do, Z),
+    }
+    bad = {}
+    for name, fn in cases.items():
+        ref = fn()
+        torch.cuda.synchronize()
+        n = 0
+        for _ in range(6):
+            out = fn()
+            torch.cuda.synchronize()
+            n += 0 if _same(ref, out) else 1
+        bad[name] = float(n)
+    report("fp32_path_reproducible_128_images", **bad)
+    assert not any(bad.values()), bad

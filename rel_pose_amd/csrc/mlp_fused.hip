@@ -225,8 +225,19 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
       }
     }
     f32x4v acc[12];
+    // BF forward, whole tile: the accumulators START at x + b2 (the row re-read here, in accumulator layout, hits L1 / L2 right behind the
+    // LayerNorm's load of it; the epilogue's re-read 24 chunks later came from HBM again, 113 MB per launch, in the phase where every
+    // workgroup of the chip waits on the same loads) -- the epilogue is then stores only
+    constexpr bool ACCX = BF && MODE == 0 && TRAIN;      // (the inference form is at its register limit: it keeps the epilogue re-read)
+    const bool acc_from_x = ACCX && c0 == 0 && c1 == NCHUNK;
 #pragma unroll
-    for (int ob = 0; ob < 12; ++ob) acc[ob] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    for (int ob = 0; ob < 12; ++ob) {
+      acc[ob] = f32x4v{0.f, 0.f, 0.f, 0.f};
+      if (ACCX && acc_from_x) {
+        const float4 xv = ld4(xrow + 16 * ob + 4 * q), bv = ld4(b1s + 2 * C + 16 * ob + 4 * q);
+        acc[ob] = f32x4v{xv.x + bv.x, xv.y + bv.y, xv.z + bv.z, xv.w + bv.w};
+      }
+    }
     bf16x8 xb[BF ? 6 : 1];
     if constexpr (BF) {
 #pragma unroll
@@ -468,12 +479,12 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
         // serialized round trips (s_waitcnt vmcnt(0) before every store, behind every store already in flight -- vmcnt retires in order)
         float4 rr[12];
 #pragma unroll
-        for (int ob = 0; ob < 12; ++ob) rr[ob] = MODE == 0 ? ld4(xrow + 16 * ob + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (MODE == 0) asm volatile("" ::: "memory");
+        for (int ob = 0; ob < 12; ++ob) rr[ob] = (MODE == 0 && !ACCX) ? ld4(xrow + 16 * ob + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (MODE == 0 && !ACCX) asm volatile("" ::: "memory");
 #pragma unroll
         for (int ob = 0; ob < 12; ++ob) {
           float4 b2 = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (MODE == 0) b2 = ld4(b1s + 2 * C + 16 * ob + 4 * q);
+          if (MODE == 0 && !ACCX) b2 = ld4(b1s + 2 * C + 16 * ob + 4 * q);      // (ACCX: already in the accumulators)
           const float4 r = rr[ob];
           const float4 yv = make_float4(acc[ob][0] + b2.x + r.x, acc[ob][1] + b2.y + r.y, acc[ob][2] + b2.z + r.z, acc[ob][3] + b2.w + r.w);
           st4(yr + 16 * ob, yv);

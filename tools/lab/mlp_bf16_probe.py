@@ -12,8 +12,8 @@ r = lambda *s: torch.randn(*s, device="cuda", generator=g)
 x, gm, bt = r(M, 192), 1 + 0.1 * r(192), 0.1 * r(192)
 w1, b1, w2, b2 = r(768, 192) * 192 ** -0.5, 0.1 * r(768), r(192, 768) * 768 ** -0.5, 0.1 * r(192)
 dy = r(M, 192)
-def t(fn, n=60):
-    for _ in range(10): fn()
+def t(fn, n=int(os.environ.get('ITERS', '60'))):
+    for _ in range(min(10, n)): fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

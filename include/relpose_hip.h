@@ -445,6 +445,8 @@ int rp_linear_rows192(const float* x, const float* w, const float* bias, const f
  * fp32): w1 and w2 then point to BF16 copies ([hidden,dim] and [dim,hidden]), w2 with the hidden units of every 32-chunk in the order
  * documented at rp_mlp_fused_bwd.  io_bf16 (precision 1, training form only): bit 1 = h_out and hpre_out are written as bf16,
  * bit 3 = xn_out is written as bf16 (the rounded rows the fc1 product consumed; what the bf16 weight-gradient kernel rp_dw192_bf16 reads).
+ * bit 4 (training and inference forms) = w2 is stored CHUNK-MAJOR, [hidden / 32][dim][32] (every staged tile 12 KB contiguous) instead of
+ * [dim][hidden].
  * ------------------------------------------------------------------------------------------- */
 size_t rp_mlp_fused_workspace_bytes(int M);
 int rp_mlp_fused_fwd(const float* x, const float* gamma, const float* beta, const float* w1, const float* b1, const float* w2,
@@ -458,7 +460,7 @@ int rp_mlp_fused_fwd(const float* x, const float* gamma, const float* beta, cons
  * precision: 0 exact fp32 MFMA.  1 = the bf16 configuration (v_mfma_f32_16x16x32_bf16, fp32 accumulate; GELU', column sums and dxn fp32):
  * w2t and w1t then point to BF16 copies, w1t with the 32 hidden units of every chunk c stored in the order a lane's accumulators form the
  * MFMA operand: position 8 q + e of chunk c holds unit 32 c + 4 q + e (e < 4) or 32 c + 16 + 4 q + e - 4 (e >= 4), q = 0..3.  io_bf16
- * (precision 1 only): bit 1 = dhp is written as bf16, bit 2 = hpre holds bf16. */
+ * (precision 1 only): bit 1 = dhp is written as bf16, bit 2 = hpre holds bf16, bit 4 = w1t is stored chunk-major, [hidden / 32][dim][32]. */
 size_t rp_mlp_fused_bwd_workspace_bytes(int M);
 int rp_mlp_fused_bwd_tile_rows(void);
 int rp_mlp_fused_bwd(const float* dy, const float* hpre, const float* w2t, const float* w1t, float* dhp, float* dxn, float* colpart,

@@ -117,7 +117,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
       const int row1 = pp / 24, sl1 = pp % 24, ch1 = (sl1 & ~7) | ((sl1 & 7) ^ ((row1 >> 1) & 7));
       off1[r] = (unsigned)(row1 * C * 2 + ch1 * 16);
       const int row2 = pp >> 2, ch2 = (pp & 3) ^ ((0 - (row2 >> 2)) & 3);      // (key: dx_lnbwd_bf16.hip -- ds_read_b128's real lane groups)
-      off2[r] = (unsigned)(row2 * HID * 2 + ch2 * 16);
+      // (io_bf16 bit 4: the second weight arrives CHUNK-MAJOR, [24][192][32] -- a staged tile is 12 KB contiguous, 128-byte L2 requests
+      // instead of 192 x 64-byte row pieces at a 1536-byte stride: the L1's pending-request limit is what bounds this kernel)
+      off2[r] = (p.io_bf16 & 16) ? (unsigned)(row2 * CH * 2 + ch2 * 16) : (unsigned)(row2 * HID * 2 + ch2 * 16);
     } else {
       const int row1 = pp / 48, ch1 = (pp % 48) ^ (row1 & 15);
       off1[r] = (unsigned)((row1 * C + ch1 * 4) * 4);
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
     const int cc = item % NCHUNK;
     const unsigned so = (unsigned)(item % NS) * (STG * 4);
     glds16(uniform_ptr(p.w1 + (long long)cc * CH * (C / 2)), off1[0], l1 + so);
-    glds16(uniform_ptr(p.w2 + cc * (CH / 2)), off2[0], l2 + so);
+    glds16(uniform_ptr((p.io_bf16 & 16) ? p.w2 + cc * (C * CH / 2) : p.w2 + cc * (CH / 2)), off2[0], l2 + so);
     if (MODE == 1 && hp_dma) {                      // LDS position tid = (row tid >> 2, 16-byte slot tid & 3), rows past M clamped
       const long long r0 = (long long)(item / NCHUNK) * ROWS;
       const int r = (int)min((long long)(tid >> 2), (long long)p.M - 1 - r0);
@@ -603,7 +605,7 @@ extern "C" int rp_mlp_fused_fwd(const float* x, const float* gamma, const float*
     return RP_EBADSHAPE;
   const bool train = xn_out || mean_out || rstd_out || h_out || hpre_out;
   if (train && !(xn_out && mean_out && rstd_out && h_out && hpre_out)) return RP_EBADSHAPE;      // the training outputs come as a set
-  if ((precision != 0 && precision != 1) || (io_bf16 && (precision != 1 || !train || (io_bf16 & ~10)))) return RP_EUNSUPPORTED;
+  if ((precision != 0 && precision != 1) || (io_bf16 && (precision != 1 || (!train && (io_bf16 & ~16)) || (io_bf16 & ~26)))) return RP_EUNSUPPORTED;
   MlpP p{x, gamma, beta, w1, b1, w2, b2, y, nullptr, hpre_out, nullptr, (float*)workspace, M, eps, 0, 0, 0, 0, io_bf16,
          xn_out, mean_out, rstd_out, h_out};
   hipStream_t st = (hipStream_t)stream;
@@ -643,7 +645,7 @@ extern "C" int rp_mlp_fused_bwd(const float* dy, const float* hpre, const float*
                                 float* colpart, void* workspace, int M, int dim, int hidden, int precision, int io_bf16, void* stream) {
   if (M <= 0 || dim != C || hidden != HID || !dy || !hpre || !w2t || !w1t || !dhp || !dxn || !colpart || !workspace)
     return RP_EBADSHAPE;
-  if ((precision != 0 && precision != 1) || (io_bf16 && (precision != 1 || (io_bf16 & ~6)))) return RP_EUNSUPPORTED;
+  if ((precision != 0 && precision != 1) || (io_bf16 && (precision != 1 || (io_bf16 & ~22)))) return RP_EUNSUPPORTED;
   MlpP p{dy, nullptr, nullptr, w2t, nullptr, w1t, nullptr, dxn, hpre, dhp, colpart, (float*)workspace, M, 0.f, 0, 0, 0, 0, io_bf16,
          nullptr, nullptr, nullptr, nullptr};
   if (precision == 1) return Variant<12, 3, 1, true>::launch(p, (hipStream_t)stream);      // (same 192-row tiles: same workspace / tile rows)

@@ -1258,7 +1258,7 @@ def mlp_fused(x2d, gamma, beta, w1, b1, w2, b2, eps=LN_EPS, train=False, out_dty
         w1k, w2k = w1, w2
     with timed("mlp_fused_fwd", 4.0 * M * DIM * Hd, 4.0 * (2 * M * DIM + 2 * DIM * Hd + (M * DIM + 2 * M * Hd if train else 0))):
         _lib.check(lib.rp_mlp_fused_fwd(_p(x2d), _p(gamma), _p(beta), _p(w1k), _p(b1), _p(w2k), _p(b2), _p(y), _p(ws), M, x2d.shape[1],
-                                        Hd, eps, _p(xn), _p(mean), _p(rstd), _p(h), _p(hpre), 1 if bf else 0, (2 if obf else 0) | (8 if xnbf else 0), _st()),
+                                        Hd, eps, _p(xn), _p(mean), _p(rstd), _p(h), _p(hpre), 1 if bf else 0, (2 if obf else 0) | (8 if xnbf else 0) | (16 if bf and MLP_W2_CHUNK_MAJOR else 0), _st()),
                    "rp_mlp_fused_fwd")
     return (y, xn, mean, rstd, h, hpre) if train else y
 
@@ -1280,6 +1280,9 @@ def _mlp_unit_perm(device):
     return pm
 
 
+MLP_W2_CHUNK_MAJOR = os.environ.get("RP_MLP_W2_CHUNK_MAJOR", "1") != "0"      # io_bf16 bit 4 of rp_mlp_fused_fwd / _bwd
+
+
 def _chunk_permuted_bf16(w, transpose=False):
     """bf16 copy of a [192, 768] operand (w, or w^T when transpose) with the 768 hidden units of every 32-chunk in the order the fused
     MLP kernels' second product wants (_mlp_unit_perm); cached on w until it changes"""
@@ -1288,6 +1291,8 @@ def _chunk_permuted_bf16(w, transpose=False):
         return c[3]
     src = w.detach().t() if transpose else w.detach()
     o = src.index_select(1, _mlp_unit_perm(w.device)).to(torch.bfloat16).contiguous()
+    if MLP_W2_CHUNK_MAJOR:      # [24 chunks][192][32]: every staged tile is 12 KB contiguous
+        o = o.view(o.shape[0], -1, 32).permute(1, 0, 2).contiguous()
     if not (w.is_cuda and torch.cuda.is_current_stream_capturing()):
         try:
             w._rp_bp = (w._version, w.data_ptr(), _PAD_GEN, o)
@@ -1316,6 +1321,7 @@ def mlp_fused_bwd(dy, hpre, w1, w2, out_dtype=None):
         raise RuntimeError("bf16-stored operands need operand precision 1 (the bf16 configuration)")
     if bf:
         w2t, w1t = _mlp_bwd_bf16_weights(w1, w2)
+        io |= 16 if MLP_W2_CHUNK_MAJOR else 0
     else:
         w2t, w1t = transposed(w2), transposed(w1)
     dhp = torch.empty(hpre.shape, device=dy.device, dtype=out_dtype or torch.float32)

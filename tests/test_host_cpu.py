@@ -347,11 +347,15 @@ def test_bf16_weight_copies_of_the_bf16_configuration():
         q, e = pos // 8, pos % 8
         assert int(perm[64 + pos]) == 64 + (4 * q + e if e < 4 else 16 + 4 * q + e - 4)
     w2 = torch.nn.Parameter(torch.randn(192, 768))
+    # chunk-major storage (io_bf16 bit 4 of rp_mlp_fused_fwd / _bwd): [24 chunks][192][32], every staged tile contiguous
+    cm = lambda t: t.reshape(192, 24, 32).permute(1, 0, 2)                                          # noqa: E731
+    assert ops.MLP_W2_CHUNK_MAJOR
     p2 = ops._chunk_permuted_bf16(w2)
-    assert p2.shape == (192, 768) and torch.equal(p2, w2.detach()[:, perm].to(torch.bfloat16)) and ops._chunk_permuted_bf16(w2) is p2
+    assert p2.shape == (24, 192, 32) and p2.is_contiguous() and torch.equal(p2, cm(w2.detach()[:, perm].to(torch.bfloat16)))
+    assert ops._chunk_permuted_bf16(w2) is p2
     w1 = torch.nn.Parameter(torch.randn(768, 192))
     p1 = ops._chunk_permuted_bf16(w1, transpose=True)
-    assert p1.shape == (192, 768) and torch.equal(p1, w1.detach().t()[:, perm].to(torch.bfloat16))
+    assert p1.shape == (24, 192, 32) and torch.equal(p1, cm(w1.detach().t()[:, perm].to(torch.bfloat16)))
     with torch.no_grad():
         w1.add_(1.0)
     assert ops._chunk_permuted_bf16(w1, transpose=True) is not p1

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-4 evidence set (run on the GPU box from the repo root: `bash tools/r4_artifacts.sh A|B|C`; everything lands in gpurun_out/,
+# round-4 evidence set (run on the GPU box from the repo root: `bash tools/r4_artifacts.sh A|B|C|D`; everything lands in gpurun_out/,
 # the files that are judged are copied into profiles/ by hand)
 set -x
 O=gpurun_out
@@ -35,5 +35,10 @@ C)  # other operating points, kernel timings, the test report
   rm -f $O/test_report.txt
   timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $O/r4_pytest_tail.txt
   cp $O/test_report.txt $O/r4_test_report.txt
+  ;;
+D)  # memory-path counters of the fused bf16 MLP (bounded passes) and the bf16 soak
+  ITERS=4 timeout 800 bash tools/pmc_mem.sh mlp "mlp_fused_kernel" $GRAFT_REPO_ROOT/tools/lab/mlp_bf16_probe.py > /dev/null
+  cp $O/pmcmem_mlp.txt $O/r4_pmcmem_mlp_bf16.txt
+  timeout 300 python bench.py --steps 300 --warmup 5 --batch 128 --precision bf16 --no-supplementary --no-cpu-baseline > $O/r4_bench_bf16_128pairs_soak300.json 2>/dev/null
   ;;
 esac

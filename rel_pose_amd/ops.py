@@ -1712,6 +1712,7 @@ class _CastParamsFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, *ps):
+        ctx.set_materialize_grads(False)      # a copy nobody used gets no gradient (None), like the per-layer casts it replaces
         outs = [torch.empty_like(p, dtype=torch.bfloat16) for p in ps]
         torch._foreach_copy_(outs, [p.detach() for p in ps])
         return tuple(outs)

@@ -455,3 +455,22 @@ def test_miopen_db_check_reports_a_foreign_miopen(tmp_path, monkeypatch):
     (d / "gfx950100.HIP.9_9_9_deadbeef.ufdb.txt").write_text("")
     found = [m for m in _env.check_db(warn=False) if "opened db files" in m]
     assert len(found) == 1 and "9_9_9_deadbeef" in found[0]
+
+
+def test_batched_parameter_cast_passes_gradients_through():
+    """ops._CastParamsFn (the bf16 configuration's one-launch cast of all convolution weights): bf16 copies forward, fp32 copies of the
+    bf16 gradients backward, None for outputs that received no gradient; ops.conv_params_bf16 is inert at CNN precision 0 / on CPU."""
+    from rel_pose_amd import ops
+    ps = [torch.nn.Parameter(torch.randn(4, 3, 3, 3)), torch.nn.Parameter(torch.randn(4)), torch.nn.Parameter(torch.randn(2, 2))]
+    outs = ops._CastParamsFn.apply(*ps)
+    assert all(o.dtype == torch.bfloat16 and torch.equal(o, p.detach().to(torch.bfloat16)) for o, p in zip(outs, ps))
+    g0, g1 = torch.randn(4, 3, 3, 3), torch.randn(4)
+    (outs[0].float() * g0).sum().backward(retain_graph=True)
+    (outs[1].float() * g1).sum().backward()
+    assert ps[0].grad.dtype == torch.float32 and torch.equal(ps[0].grad, g0.to(torch.bfloat16).float())
+    assert torch.equal(ps[1].grad, g1.to(torch.bfloat16).float()) and ps[2].grad is None
+    conv = torch.nn.Conv2d(3, 4, 3)
+    with ops.conv_params_bf16(conv):
+        assert getattr(conv, "_rp_bf16", None) is None          # precision 0: nothing is prepared, conv2d runs the module itself
+        y = ops.conv2d(conv, torch.randn(1, 3, 8, 8))
+    assert y.dtype == torch.float32 and y.shape == (1, 4, 6, 6)

@@ -447,6 +447,7 @@ extern "C" int rp_attn_fwd_bf16(const void* q, const void* k, const void* v, voi
   if (!stats_only && (!v || !o)) return RP_EBADSHAPE;
   if ((ldq | ldk | ldv | ldo) & 7) return RP_EALIGN;                       // 16-byte row segments
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) return RP_EALIGN;
+  if ((q_xor & ~1) || (k_xor & ~3)) return RP_EBADSHAPE;                   // as rp_attn_fwd: k_xor bit 0 = K from the partner image, bit 1 = V
   if ((q_xor | k_xor) && (Z & 1)) return RP_EBADSHAPE;
   AttnBfP p;
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (bf16_t*)o; p.lse = lse;
@@ -475,7 +476,7 @@ extern "C" int rp_attn_bwd_bf16(const void* q, const void* k, const void* v, con
   if (!q || !k || !v || !dout || !lse2 || !delta || !dq || !dk || !dv || Z <= 0 || H <= 0) return RP_EBADSHAPE;
   if ((ldq | ldk | ldv | lddo | lddq | lddk | lddv) & 7) return RP_EALIGN;
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)dout | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15) return RP_EALIGN;
-  if (kv_xor && (Z & 1)) return RP_EBADSHAPE;
+  if ((kv_xor & ~1) || (kv_xor && (Z & 1))) return RP_EBADSHAPE;       // as rp_attn_bwd: an image index z ^ kv_xor must stay inside the pair
   if ((dk_colpart == nullptr) != (dv_colpart == nullptr)) return RP_EBADSHAPE;
   AttnBwdBfP p;
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.dout = (const bf16_t*)dout; p.lse2 = lse2; p.delta = delta;

@@ -436,14 +436,14 @@ extern "C" int rp_emm_apply_bf16(const void* qkv, int ldqkv, const void* x, cons
 }
 
 extern "C" int rp_emm_f_bf16(const void* x, const void* t, float* f, int Z, int H, void* stream) {
-  if (!x || !t || !f || Z <= 0 || H <= 0) return RP_EBADSHAPE;
+  if (!x || !t || !f || Z <= 0 || (Z & 1) || H <= 0) return RP_EBADSHAPE;   // images come in pairs, as in rp_emm_apply_bf16
   hipLaunchKernelGGL(emm_f_bf16_kernel, dim3(Z * H), dim3(192), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)t, f, Z * H);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }
 
 extern "C" int rp_emm_w_bf16(const void* x, const void* t, const float* df, void* w, void* wp, float* rho, int Z, int H, void* stream) {
-  if (!x || !t || !df || !w || !wp || !rho || Z <= 0 || H <= 0) return RP_EBADSHAPE;
+  if (!x || !t || !df || !w || !wp || !rho || Z <= 0 || (Z & 1) || H <= 0) return RP_EBADSHAPE;
   EmmSmallP p{(const bf16_t*)x, (const bf16_t*)t, nullptr, df, (bf16_t*)w, (bf16_t*)wp, rho, H, 0, Z * H};
   hipLaunchKernelGGL(emm_small_bf16_kernel<0>, dim3(Z * H * 3), dim3(384), 0, (hipStream_t)stream, p);
   RP_CHECK_LAUNCH();
@@ -452,7 +452,7 @@ extern "C" int rp_emm_w_bf16(const void* x, const void* t, const float* df, void
 
 extern "C" int rp_emm_dx_bf16(const void* t, const void* u, const void* wp, const float* df, void* dqkv, int ldqkv, float* gamma, int Z, int H,
                               void* stream) {
-  if (!t || !u || !wp || !df || !dqkv || !gamma || Z <= 0 || H <= 0 || (ldqkv & 7)) return RP_EBADSHAPE;
+  if (!t || !u || !wp || !df || !dqkv || !gamma || Z <= 0 || (Z & 1) || H <= 0 || (ldqkv & 7)) return RP_EBADSHAPE;
   EmmSmallP p{(const bf16_t*)t, (const bf16_t*)u, (const bf16_t*)wp, df, (bf16_t*)dqkv, nullptr, gamma, H, ldqkv, Z * H};
   hipLaunchKernelGGL(emm_small_bf16_kernel<1>, dim3(Z * H * 3), dim3(384), 0, (hipStream_t)stream, p);
   RP_CHECK_LAUNCH();

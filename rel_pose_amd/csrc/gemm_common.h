@@ -51,13 +51,20 @@ RP_DEV void st4_io(float* base, long long off, float4 v, bool bf) {
   else st4(base + off, v);
 }
 
+// The activation pair of an epilogue follows the operand precision: precision 1 (the bf16 configuration) uses the same sigmoid-form
+// GELU and its exact derivative as the BF instantiations of mlp_fused.hip / linear_rows.hip (common.h: gelu_bf / gelu_bf_grad), so the
+// fallback paths (RP_ROWS_LINEAR=0, RP_ROWS_DX=0, RP_MLP_FUSED_*=0) compute the SAME function forward and backward as the default
+// ones; every other precision keeps the reference's erf GELU.
+RP_DEV float gelu_sel(float v, bool bf) { return bf ? gelu_bf(v) : gelu_exact(v); }
+RP_DEV float gelu_grad_sel(float v, bool bf) { return bf ? gelu_bf_grad(v) : gelu_grad(v); }
+
 RP_DEV float epilogue(float v, int m, int n, const GemmP& p) {
   if (p.bias) v += p.bias[n];
   const long long off = (long long)m * p.ldc + n;
   if (p.pre_out) p.pre_out[off] = v;
-  if (p.act == 1) v = gelu_exact(v);
+  if (p.act == 1) v = gelu_sel(v, p.limbs == 1);
   else if (p.act == 2) v = fmaxf(v, 0.f);
-  if (p.dact == 1) v *= gelu_grad(p.aux[off]);
+  if (p.dact == 1) v *= gelu_grad_sel(p.aux[off], p.limbs == 1);
   else if (p.dact == 2) v = p.aux[off] > 0.f ? v : 0.f;
   if (p.residual) v += p.residual[off];
   return v;
@@ -121,12 +128,14 @@ RP_DEV void staged_epilogue(const GemmP& p, f32x16 (&acc)[TM][TN], float* lds, i
     }
     if (MODE == EPI_BIAS_GELU_PRE && ok) st4_io(pre_out, off, v, c_bf);
     if (MODE == EPI_BIAS_GELU || MODE == EPI_BIAS_GELU_PRE) {
-      v.x = gelu_exact(v.x); v.y = gelu_exact(v.y); v.z = gelu_exact(v.z); v.w = gelu_exact(v.w);
+      const bool gb = p.limbs == 1;
+      v.x = gelu_sel(v.x, gb); v.y = gelu_sel(v.y, gb); v.z = gelu_sel(v.z, gb); v.w = gelu_sel(v.w, gb);
     } else if (MODE == EPI_BIAS_RELU) {
       v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
     } else if (MODE == EPI_DGELU) {
       const float4 a4 = o4[it];
-      v.x *= gelu_grad(a4.x); v.y *= gelu_grad(a4.y); v.z *= gelu_grad(a4.z); v.w *= gelu_grad(a4.w);
+      const bool gb = p.limbs == 1;
+      v.x *= gelu_grad_sel(a4.x, gb); v.y *= gelu_grad_sel(a4.y, gb); v.z *= gelu_grad_sel(a4.z, gb); v.w *= gelu_grad_sel(a4.w, gb);
     } else if (MODE == EPI_DRELU) {
       const float4 a4 = o4[it];
       v.x = a4.x > 0.f ? v.x : 0.f; v.y = a4.y > 0.f ? v.y : 0.f; v.z = a4.z > 0.f ? v.z : 0.f; v.w = a4.w > 0.f ? v.w : 0.f;

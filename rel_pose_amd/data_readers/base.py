@@ -15,7 +15,7 @@ def imread_bgr(path):
 
 class RGBDDataset(data.Dataset):
     def __init__(self, name, datapath, reshape_size=[384, 512], subepoch=None, is_training=True, gpu=0,
-                 streetlearn_interiornet_type=None, use_mini_dataset=False, raw=False):
+                 streetlearn_interiornet_type=None, use_mini_dataset=False, raw=False, jitter=True):
         # raw=True (not in the reference): samples are (uint8 [2,H,W,3] BGR as decoded, poses, UNSCALED intrinsics); the colour
         # jitter + resize + intrinsics rescale then run once per batch on the GPU (RGBDAugmentor.augment_batch_hip).  The
         # reference's per-sample CPU augmentation feeds ~26 pairs/s per core (profiles/r2_loader_bench.txt).
@@ -23,7 +23,8 @@ class RGBDDataset(data.Dataset):
         self.root = datapath
         self.name = name
         self.streetlearn_interiornet_type = streetlearn_interiornet_type
-        self.aug = RGBDAugmentor(reshape_size=reshape_size, datapath=datapath)
+        # jitter=False (not in the reference): colour jitter off -- what the parity fixtures of the reference's own readers are compared in
+        self.aug = RGBDAugmentor(reshape_size=reshape_size, datapath=datapath, jitter=jitter)
         self.matterport = "matterport" in datapath
         if self.matterport:
             self.scene_info = self._build_dataset(subepoch == 10)          # sub-epoch 10 is the validation pass

@@ -69,6 +69,18 @@ class LazyMetrics(dict):
         self._fetch()
         return dict.get(self, k, default)
 
+    # CPython's dict fast paths (`dict(m)`, `{}.update(m)`, `{**m}`, `m | other`) read a dict SUBCLASS's storage directly
+    # unless `__iter__` is overridden (dictobject.c: dict_merge tests `tp_iter == dict_iter`); the reference loop does
+    # `metrics.update(geo_metrics)` (train.py:168) before handing the dict to its Logger, so the override is what keeps device
+    # tensors from leaking into a plain dict.
+    def __iter__(self):
+        self._fetch()
+        return dict.__iter__(self)
+
+    def keys(self):
+        self._fetch()
+        return dict.keys(self)
+
     def items(self):
         self._fetch()
         return dict.items(self)

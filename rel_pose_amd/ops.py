@@ -14,6 +14,7 @@ front-end's bn_act / maxpool3x3s2 wrappers hand CPU tensors to the stock torch m
 import ctypes
 import math
 import os
+import threading
 
 import torch
 
@@ -301,11 +302,18 @@ TIMER = None
 # deferred split-K reduces: inside `with splitk_batch():` a split-K product that ASKS for it (gemm(..., defer=True): the weight-gradient
 # GEMMs of linear_dw) launches only its main kernel into a private slab region and the block ends with ONE rp_splitk_reduce_multi
 # (bit-identical to the per-GEMM reduce).  Those outputs are only FILLED at exit: return them, do not compute with them inside the
-# block.  Every other split-K gemm() inside the block reduces immediately as usual.  Blocks do not nest (one arena per stream).
+# block.  Every other split-K gemm() inside the block reduces immediately as usual.  The batch state is per THREAD (autograd runs one
+# backward thread per device) and is honoured only on the stream it was opened on; a block opened inside another one (a re-entrant
+# backward: torch.autograd.grad or a checkpoint recompute inside a BlockFn.backward) does not share the outer block's slab arena --
+# its products reduce immediately, and the outer block resumes deferring when it closes.
 # ------------------------------------------------------------------------------------------------
 SPLITK_BATCHING = os.environ.get("RP_SPLITK_BATCH", "1") == "1"
-_SPLITK_BATCH = None
+_TLS = threading.local()
 _ARENA = {}
+
+
+def _sk_batch():
+    return getattr(_TLS, "batch", None)
 
 
 def _arena_take(nbytes, device, state):
@@ -324,16 +332,16 @@ def _arena_take(nbytes, device, state):
 
 class splitk_batch:
     def __enter__(self):
-        global _SPLITK_BATCH
         st = torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else None
-        if _SPLITK_BATCH is not None:
-            raise RuntimeError("splitk_batch blocks do not nest: the inner block would reuse the outer block's slab arena")
-        self.prev, _SPLITK_BATCH = _SPLITK_BATCH, (([], [0], st) if SPLITK_BATCHING else None)
+        self.prev = _sk_batch()
+        nested = getattr(_TLS, "depth", 0) > 0
+        _TLS.depth = getattr(_TLS, "depth", 0) + 1
+        _TLS.batch = ([], [0], st) if (SPLITK_BATCHING and not nested) else None
         return self
 
     def __exit__(self, et, ev, tb):
-        global _SPLITK_BATCH
-        cur, _SPLITK_BATCH = _SPLITK_BATCH, self.prev
+        cur, _TLS.batch = _sk_batch(), self.prev
+        _TLS.depth -= 1
         if et is None and cur and cur[0]:
             tasks = cur[0]
             lib = _lib.load()
@@ -413,9 +421,9 @@ def gemm(A, B, M, N, K, *, a_layout=0, b_layout=0, lda=None, ldb=None, out=None,
     if split_k > 1:
         nbytes = lib.rp_gemm_workspace_bytes(M, N, split_k)
         plain = bias is None and pre_out is None and aux is None and residual is None and act == 0 and dact == 0 and ln is None
-        if (defer and _SPLITK_BATCH is not None and plain and not want_colsum
-                and torch.cuda.current_stream(A.device).cuda_stream == _SPLITK_BATCH[2]):       # (not under fork.on_side)
-            ws = _arena_take(nbytes, A.device, _SPLITK_BATCH[1])
+        if (defer and _sk_batch() is not None and plain and not want_colsum
+                and torch.cuda.current_stream(A.device).cuda_stream == _sk_batch()[2]):       # (not under fork.on_side)
+            ws = _arena_take(nbytes, A.device, _sk_batch()[1])
             g.defer_reduce = 1
             defer = (ws, out, M, N, ldc, split_k, trans_c)
         else:
@@ -448,7 +456,7 @@ def gemm(A, B, M, N, K, *, a_layout=0, b_layout=0, lda=None, ldb=None, out=None,
         g.ev_start, g.ev_stop = e0, e1
         _lib.check(lib.rp_gemm(ctypes.byref(g), _st()), "rp_gemm")
         if defer is not None and g.split_k > 1:
-            _SPLITK_BATCH[0].append(defer)
+            _sk_batch()[0].append(defer)
         tm.events.append((e0, e1))
         tm.flops += 2.0 * M * N * K * batch
         ob = 2.0 if (out_dtype == torch.bfloat16) else 4.0                     # bf16-stored operands (RpGemm.io_bf16) count 2 bytes
@@ -457,7 +465,7 @@ def gemm(A, B, M, N, K, *, a_layout=0, b_layout=0, lda=None, ldb=None, out=None,
         return (out, colsum(cpart)) if want_colsum else out
     _lib.check(lib.rp_gemm(ctypes.byref(g), _st()), "rp_gemm")
     if defer is not None and g.split_k > 1:
-        _SPLITK_BATCH[0].append(defer)
+        _sk_batch()[0].append(defer)
     return (out, colsum(cpart)) if want_colsum else out
 
 
@@ -679,8 +687,8 @@ def _dw192(a, b, out, trans):
     f32 = a.dtype == torch.float32
     sk = (lib.rp_dw192_f32_splits if f32 else lib.rp_dw192_bf16_splits)(M, N)
     nbytes = (lib.rp_dw192_f32_workspace_bytes if f32 else lib.rp_dw192_bf16_workspace_bytes)(M, N)
-    deferred = (_SPLITK_BATCH is not None and torch.cuda.current_stream(a.device).cuda_stream == _SPLITK_BATCH[2])
-    ws = _arena_take(nbytes, a.device, _SPLITK_BATCH[1]) if deferred else _workspace(nbytes, a.device)
+    deferred = (_sk_batch() is not None and torch.cuda.current_stream(a.device).cuda_stream == _sk_batch()[2])
+    ws = _arena_take(nbytes, a.device, _sk_batch()[1]) if deferred else _workspace(nbytes, a.device)
     if f32:
         with timed("dw192_f32", 2.0 * M * N * DIM, 4.0 * (M * (N + DIM) + sk * N * DIM)):
             _lib.check(lib.rp_dw192_f32(_p(a), N, _p(b), M, N, _p(ws), nbytes, _st()), "rp_dw192_f32")
@@ -690,7 +698,7 @@ def _dw192(a, b, out, trans):
             _lib.check(lib.rp_dw192_bf16(_p(a), N, _p(b), 1 if b.dtype == torch.float32 else 0, M, N, _p(ws), nbytes, _st()), "rp_dw192_bf16")
     task = (ws, out, N, DIM, N if trans else DIM, sk, trans)
     if deferred:
-        _SPLITK_BATCH[0].append(task)
+        _sk_batch()[0].append(task)
     else:
         arr = (_lib.RpSplitkTask * 1)()
         arr[0].ws, arr[0].C, arr[0].M, arr[0].N, arr[0].ldc, arr[0].split_k, arr[0].trans_c = ws.data_ptr(), out.data_ptr(), N, DIM, task[4], sk, 1 if trans else 0

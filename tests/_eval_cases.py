@@ -77,6 +77,74 @@ def write_panorama(root, dataset="interiornet", n=6, hw=(128, 128)):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# fake TRAINING datasets for the reader fixtures (reference layout: src/data_readers/matterport.py:31-36,
+# interiornet.py:60-85, streetlearn.py:60-86)
+# ---------------------------------------------------------------------------------------------------------------------
+PANORAMA_TRAIN = {                 # (dataset, streetlearn_interiornet_type) -> (metadata folder, file name, image folder under data/)
+    ("interiornet", ""): ("interiornet", "train_pair_rotation_overlap.npy", "interiornet"),
+    ("interiornet", "T"): ("interiornetT", "train_pair_translation_overlap.npy", "interiornet"),
+    ("streetlearn", ""): ("streetlearn", "train_pair_rotation_overlap.npy", "streetlearn"),
+    ("streetlearn", "T"): ("streetlearnT", "train_pair_translation_overlap.npy", "streetlearn_2016"),
+}
+PANORAMA_TRAIN_PAIRS = 43          # 43 // 10 = 4 pairs per sub-epoch, 3 left over that no sub-epoch ever reads
+PANORAMA_UNREADABLE = (5, 6, 13)   # pair 5: first image missing, pair 6: second image is not an image, pair 13: both missing
+
+
+def panorama_train_entries(dataset, typ, n=PANORAMA_TRAIN_PAIRS):
+    key = 300 + 17 * sorted(PANORAMA_TRAIN).index((dataset, typ))
+    split = {}
+    for i in range(n):
+        u = O.hash_uniform(4, key + i)
+        split[i] = {"img1": {"path": "scene%02d/%s_a.png" % (i // 4, i), "x": float(1.4 * u[0]), "y": float(3.1 * u[1])},
+                    "img2": {"path": "scene%02d/%s_b.png" % (i // 4, i), "x": float(1.4 * u[2]), "y": float(3.1 * u[3])}}
+    return split
+
+
+def write_panorama_train(root, dataset, typ, n=PANORAMA_TRAIN_PAIRS, hw=(32, 40), images_upto=16):
+    """metadata for n pairs, images for pairs 0 .. images_upto-1 except the PANORAMA_UNREADABLE ones"""
+    meta, fname, folder = PANORAMA_TRAIN[(dataset, typ)]
+    split = panorama_train_entries(dataset, typ, n)
+    key = 5000 + 1000 * sorted(PANORAMA_TRAIN).index((dataset, typ))
+    for i in range(min(n, images_upto)):
+        for j, k in enumerate(("img1", "img2")):
+            path = os.path.join(root, "data", folder, split[i][k]["path"])
+            if i in (5, 13) and (j == 0 or i == 13):
+                continue                                               # missing file
+            if i == 6 and j == 1:
+                os.makedirs(os.path.dirname(path), exist_ok=True)
+                with open(path, "wb") as f:
+                    f.write(b"not a png")                              # undecodable file
+                continue
+            _save_png(path, _image_u8(hw[0], hw[1], key + 10 * i + j))
+    os.makedirs(os.path.join(root, "metadata", meta), exist_ok=True)
+    np.save(os.path.join(root, "metadata", meta, fname), split, allow_pickle=True)
+    return split
+
+
+def write_matterport_train(root, n_train=7, n_val=3, hw=(48, 64)):
+    """like write_matterport, with DIFFERENT train / val splits (sub-epoch 10 reads the val file, base.py:30)"""
+    data = matterport_entries(n_train + n_val)
+    for i, e in enumerate(data):
+        for k in ("0", "1"):
+            rel = "/".join(e[k]["file_name"].split("/")[6:])
+            _save_png(os.path.join(root, rel), _image_u8(hw[0], hw[1], 1000 + 10 * i + int(k)))
+    os.makedirs(os.path.join(root, "mp3d_planercnn_json"), exist_ok=True)
+    for split, part in (("train", data[:n_train]), ("val", data[n_train:])):
+        with open(os.path.join(root, "mp3d_planercnn_json", "cached_set_%s.json" % split), "w") as f:
+            json.dump({"data": part}, f)
+    return data
+
+
+# a fixed ColorJitter / RandomGrayscale draw per case for the "fixed jitter" reader fixtures: order of the four ops
+# (0 brightness, 1 contrast, 2 saturation, 3 hue), their factors, greyscale yes/no
+FIXED_JITTER = {
+    "j0": dict(order=[0, 1, 2, 3], b=1.2, c=0.8, s=1.15, h=0.06, gray=False),
+    "j1": dict(order=[3, 2, 0, 1], b=0.8, c=1.2, s=0.8, h=-0.1, gray=False),
+    "j2": dict(order=[1, 0, 3, 2], b=1.1, c=1.1, s=1.25, h=0.0, gray=True),
+}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # hand-made prediction sets for the metric functions themselves
 # ---------------------------------------------------------------------------------------------------------------------
 def _wxyz(r):

@@ -487,7 +487,180 @@ def metrics_fixture():
         print(k, dict(zip(out[k + "_metric_names"].tolist(), out[k + "_metric_values"].tolist())))
 
 
+def _install_reader_shims():
+    """Harness for the reference's data readers: cv2.imread on PIL (BGR, alpha dropped, None for an unreadable
+    file like cv2) and a `torchvision.transforms` stand-in with torchvision's PIL-backend semantics for the five transforms the
+    reference composes (src/data_readers/augmentation.py:12-16).  ColorJitter / RandomGrayscale do not draw: JITTER["mode"] is either
+    None (both are the identity) or one fixed parameter set of tests/_eval_cases.FIXED_JITTER, applied the way torchvision's
+    functional_pil does (ImageEnhance blends, uint8 HSV hue wrap-around, convert("L") greyscale)."""
+    from PIL import Image, ImageEnhance
+    cv2 = types.ModuleType("cv2")
+
+    def imread(path):
+        try:
+            with Image.open(path) as im:
+                return np.ascontiguousarray(np.asarray(im.convert("RGB"))[:, :, ::-1])
+        except Exception:
+            return None
+    cv2.imread = imread
+    sys.modules["cv2"] = cv2
+    JITTER = {"mode": None, "ctor": {}}
+    tvt = types.ModuleType("torchvision.transforms")
+
+    class Compose:
+        def __init__(self, ts):
+            self.ts = ts
+
+        def __call__(self, x):
+            for t in self.ts:
+                x = t(x)
+            return x
+
+    class ToPILImage:
+        def __call__(self, pic):              # to_pil_image of a float CHW tensor: mul(255).byte(), HWC, mode RGB
+            assert pic.dim() == 3 and pic.shape[0] == 3 and pic.is_floating_point()
+            return Image.fromarray(pic.mul(255).byte().permute(1, 2, 0).contiguous().numpy(), "RGB")
+
+    class ToTensor:
+        def __call__(self, img):              # pil_to_tensor + float32 div(255)
+            a = torch.from_numpy(np.array(img, np.uint8, copy=True)).permute(2, 0, 1).contiguous()
+            return a.to(torch.float32).div(255)
+
+    class ColorJitter:
+        def __init__(self, brightness=0, contrast=0, saturation=0, hue=0):
+            JITTER["ctor"].update(brightness=brightness, contrast=contrast, saturation=saturation, hue=hue)
+
+        def __call__(self, img):
+            m = JITTER["mode"]
+            if m is None:
+                return img
+            for op in m["order"]:
+                if op == 0:
+                    img = ImageEnhance.Brightness(img).enhance(m["b"])
+                elif op == 1:
+                    img = ImageEnhance.Contrast(img).enhance(m["c"])
+                elif op == 2:
+                    img = ImageEnhance.Color(img).enhance(m["s"])
+                else:
+                    h, s_, v = img.convert("HSV").split()
+                    np_h = np.array(h, dtype=np.uint8)
+                    np_h = (np_h.astype(np.int32) + int(m["h"] * 255)).astype(np.uint8)       # uint8 wrap-around
+                    img = Image.merge("HSV", (Image.fromarray(np_h, "L"), s_, v)).convert("RGB")
+            return img
+
+    class RandomGrayscale:
+        def __init__(self, p=0.1):
+            JITTER["ctor"].update(p_gray=p)
+
+        def __call__(self, img):
+            m = JITTER["mode"]
+            if m is None or not m["gray"]:
+                return img
+            g = np.array(img.convert("L"), dtype=np.uint8)
+            return Image.fromarray(np.dstack([g, g, g]), "RGB")
+
+    tvt.Compose, tvt.ToPILImage, tvt.ToTensor, tvt.ColorJitter, tvt.RandomGrayscale = Compose, ToPILImage, ToTensor, ColorJitter, RandomGrayscale
+    sys.modules["torchvision"].transforms = tvt
+    sys.modules["torchvision.transforms"] = tvt
+    return JITTER
+
+
+def readers_fixture():
+    """the reference's OWN readers -- src/data_readers/{base,matterport,interiornet,streetlearn,factory,
+    augmentation}.py -- run here on the closed-form fake training datasets of tests/_eval_cases.py.  Committed: what they PRODUCED
+    (reference_readers.npz): lengths, file lists, scene_info poses / intrinsics, sub-epoch slices, samples (sha256 of the image tensor
+    bytes + a subsample; whole images as uint8 for the fixed-jitter cases), the skip-forward behaviour on unreadable samples."""
+    import hashlib
+    import tempfile
+    JITTER = _install_reader_shims()
+    from src.data_readers.factory import dataset_factory           # reference
+    from src.data_readers.matterport import Matterport            # reference
+    from src.data_readers.interiornet import InteriorNet          # reference
+    from src.data_readers.streetlearn import StreetLearn          # reference
+    import src.data_readers.base as RB
+    assert os.path.abspath(RB.__file__).startswith(os.path.abspath(REF)), RB.__file__
+    out = {}
+    tmp = tempfile.mkdtemp()
+
+    def rec_scene(prefix, db, root):
+        si = db.scene_info
+        out[prefix + "_len"] = np.array(len(db))
+        out[prefix + "_files"] = np.array("\n".join(os.path.relpath(f, root) for pair in si["images"] for f in pair))
+        out[prefix + "_scene_poses"] = np.stack(si["poses"]).astype(np.float64) if len(db) else np.zeros((0, 2, 7))
+        out[prefix + "_scene_intrinsics"] = np.stack(si["intrinsics"]).astype(np.float64) if len(db) else np.zeros((0, 2, 4))
+
+    def rec_sample(prefix, sample, whole=False):
+        im, po, K = sample
+        assert im.dtype == torch.float32 and po.dtype == torch.float32 and K.dtype == torch.float32
+        a = im.contiguous().numpy()
+        out[prefix + "_images_shape"] = np.array(a.shape)
+        out[prefix + "_images_sha256"] = np.array(hashlib.sha256(a.tobytes()).hexdigest())
+        out[prefix + "_images_sub"] = a.reshape(-1)[::53].copy()
+        if whole:
+            assert np.array_equal(a, np.round(a)) and a.min() >= 0 and a.max() <= 255
+            out[prefix + "_images_u8"] = a.astype(np.uint8)
+        out[prefix + "_poses"] = po.numpy().copy()
+        out[prefix + "_intrinsics"] = K.numpy().copy()
+
+    # ---- Matterport: train (sub-epochs 0..9 read the same file) and val (sub-epoch 10) ---------------------------------------
+    mroot = os.path.join(tmp, "matterport_fake")
+    EC.write_matterport_train(mroot)
+    for sub in (0, 4, 10):
+        db = Matterport(datapath=mroot, subepoch=sub, reshape_size=[96, 128])
+        rec_scene("mp_sub%d" % sub, db, mroot)
+        for i in range(len(db)):
+            rec_sample("mp_sub%d_i%d" % (sub, i), db[i])
+    db = Matterport(datapath=mroot, subepoch=0)                         # the default reshape_size (384 x 512)
+    rec_sample("mp_default_size_i2", db[2])
+    cat = dataset_factory(["matterport"], datapath=mroot, subepoch=10, reshape_size=[48, 64])
+    out["mp_factory_len"] = np.array(len(cat))
+    rec_sample("mp_factory_i1", cat[1])
+    for name, prm in EC.FIXED_JITTER.items():
+        JITTER["mode"] = prm
+        rec_sample("mp_%s_i3" % name, Matterport(datapath=mroot, subepoch=0, reshape_size=[96, 128])[3], whole=True)
+    JITTER["mode"] = None
+
+    # ---- the panorama datasets: rotation-only and translation ("T") sets, sub-epoch slices, mini dataset, skip-forward -------
+    proot = os.path.join(tmp, "pano_fake")
+    for (ds, typ) in sorted(EC.PANORAMA_TRAIN):
+        EC.write_panorama_train(proot, ds, typ)
+    for (ds, typ) in sorted(EC.PANORAMA_TRAIN):
+        cls = InteriorNet if ds == "interiornet" else StreetLearn
+        tag = "%s%s" % (ds, typ)
+        for sub in (0, 1, 3, 9):
+            db = cls(datapath=proot, subepoch=sub, streetlearn_interiornet_type=typ, reshape_size=[64, 80])
+            rec_scene("%s_sub%d" % (tag, sub), db, proot)
+        mini = cls(datapath=proot, subepoch=7, streetlearn_interiornet_type=typ, use_mini_dataset=True, reshape_size=[64, 80])
+        rec_scene("%s_mini" % tag, mini, proot)
+        # sub-epoch 0 = pairs 0..3 all readable; sub-epoch 1 = pairs 4..7 with 5 and 6 unreadable: index 1 and 2 skip forward to pair 7
+        db0 = cls(datapath=proot, subepoch=0, streetlearn_interiornet_type=typ, reshape_size=[64, 80])
+        db1 = cls(datapath=proot, subepoch=1, streetlearn_interiornet_type=typ, reshape_size=[64, 80])
+        for i in range(4):
+            rec_sample("%s_sub0_i%d" % (tag, i), db0[i])
+            rec_sample("%s_sub1_i%d" % (tag, i), db1[i])
+        # mini dataset: pair 13 (both files missing) skips to 14
+        rec_sample("%s_mini_i13" % tag, mini[13])
+        rec_sample("%s_mini_i12" % tag, mini[12])
+        if typ == "":
+            rec_sample("%s_default_size_i1" % tag, cls(datapath=proot, subepoch=0, streetlearn_interiornet_type=typ)[1])
+        for name, prm in EC.FIXED_JITTER.items():
+            JITTER["mode"] = prm
+            rec_sample("%s_%s_i2" % (tag, name), cls(datapath=proot, subepoch=0, streetlearn_interiornet_type=typ, reshape_size=[64, 80])[2], whole=True)
+        JITTER["mode"] = None
+    cat = dataset_factory(["interiornet", "streetlearn"], datapath=proot, subepoch=0, streetlearn_interiornet_type="", reshape_size=[64, 80])
+    out["pano_factory_len"] = np.array(len(cat))
+    rec_sample("pano_factory_i5", cat[5])                               # second dataset of the concatenation, its pair 1
+    out["jitter_ctor_names"] = np.array(sorted(JITTER["ctor"]))
+    out["jitter_ctor_values"] = np.array([float(JITTER["ctor"][k]) for k in sorted(JITTER["ctor"])])
+    path = os.path.join(HERE, "reference_readers.npz")
+    np.savez_compressed(path, **out)
+    print("wrote reference_readers.npz: %d arrays, %.1f KB" % (len(out), os.path.getsize(path) / 1024))
+
+
 if __name__ == "__main__":
+    if "--readers-only" in sys.argv:
+        readers_fixture()
+        sys.exit(0)
     if "--metrics-only" in sys.argv:
         metrics_fixture()
         sys.exit(0)
@@ -499,3 +672,4 @@ if __name__ == "__main__":
     noess_fixtures()
     demo_fixture()
     metrics_fixture()
+    readers_fixture()

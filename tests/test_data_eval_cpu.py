@@ -130,25 +130,37 @@ def test_panorama_readers_and_viewpoint_rotation(tmp_path):
     assert np.isclose(ang, np.degrees(0.7), atol=1e-3)
 
 
-def test_colour_jitter_matches_pil_enhancers():
-    """brightness / saturation / contrast are PIL's ImageEnhance blends (what torchvision's PIL path calls)"""
+def _pil_hue(img, hue_factor):
+    """torchvision functional_pil.adjust_hue (uint8 H channel + uint8(hue_factor * 255), wrapping)"""
+    h, s_, v = img.convert("HSV").split()
+    nh = (np.array(h, dtype=np.uint8).astype(np.int32) + int(hue_factor * 255)).astype(np.uint8)
+    return Image.merge("HSV", (Image.fromarray(nh, "L"), s_, v)).convert("RGB")
+
+
+def test_colour_ops_are_pils_arithmetic_bit_for_bit():
+    """brightness / contrast / saturation = PIL's ImageEnhance blends, hue = the uint8 HSV round trip, greyscale = convert("L") -- what
+    torchvision's PIL backend calls on the reference's ToPILImage output (reference augmentation.py:12-16) -- EXACTLY, on random
+    images and for the mode conversions on ALL 2^24 colours."""
     rng = np.random.default_rng(0)
-    rgb8 = rng.integers(0, 256, (24, 32, 3), dtype=np.uint8)
+    rgb8 = rng.integers(0, 256, (96, 128, 3), dtype=np.uint8)
+    rgb8[0, :, :] = rgb8[0, :, :1]                                  # a row of greys (min == max: hue / saturation 0)
     pil = Image.fromarray(rgb8)
-    x = torch.from_numpy(rgb8).permute(2, 0, 1).float() / 255.0
-    for fn, enh, f in ((A.adjust_brightness, ImageEnhance.Brightness, 1.2), (A.adjust_brightness, ImageEnhance.Brightness, 0.8),
-                       (A.adjust_saturation, ImageEnhance.Color, 0.77), (A.adjust_saturation, ImageEnhance.Color, 1.21),
-                       (A.adjust_contrast, ImageEnhance.Contrast, 0.8), (A.adjust_contrast, ImageEnhance.Contrast, 1.25)):
-        ref = np.asarray(enh(pil).enhance(f)).astype(np.float32)
-        got = (fn(x, f) * 255.0).permute(1, 2, 0).numpy()
-        assert np.abs(got - ref).max() <= 2.0, (fn.__name__, f)            # PIL rounds to 8 bits (and its gray mean too)
-    # hue: inverse shifts cancel, grays are fixed points, a shift of 1/3 rotates the primaries
-    y = A.adjust_hue(A.adjust_hue(x, 0.11), -0.11)
-    assert float((y - x).abs().max()) < 1e-4
-    g = torch.full((3, 4, 4), 0.4)
-    assert torch.allclose(A.adjust_hue(g, 0.3), g)
-    red = torch.tensor([1.0, 0.0, 0.0]).view(3, 1, 1)
-    assert torch.allclose(A.adjust_hue(red, 1.0 / 3.0), torch.tensor([0.0, 1.0, 0.0]).view(3, 1, 1), atol=1e-5)
+    x = torch.from_numpy(rgb8).permute(2, 0, 1)
+    hwc = lambda t: t.permute(1, 2, 0).numpy()                       # noqa: E731
+    for fn, enh in ((A.adjust_brightness, ImageEnhance.Brightness), (A.adjust_saturation, ImageEnhance.Color), (A.adjust_contrast, ImageEnhance.Contrast)):
+        for f in (0.75, 0.8, 0.9999, 1.0, 1.0001, 1.2, 1.25, 0.0, 2.0):
+            assert np.array_equal(hwc(fn(x, f)), np.asarray(enh(pil).enhance(f))), (fn.__name__, f)
+    for hf in (0.0, 0.06, -0.1, 0.4 / 3.14, -0.4 / 3.14, 0.5, -0.5, 1.0 / 255, -1.0 / 255):
+        assert np.array_equal(hwc(A.adjust_hue(x, hf)), np.asarray(_pil_hue(pil, hf))), hf
+    assert np.array_equal(hwc(A.to_grayscale(x))[..., 1], np.asarray(pil.convert("L")))
+    # the three mode conversions, exhaustively (16.7 M colours each)
+    ax = np.arange(256, dtype=np.uint8)
+    cube = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(4096, 4096, 3)
+    t = torch.from_numpy(cube).permute(2, 0, 1)
+    cpil = Image.fromarray(cube)
+    assert np.array_equal(A._luma_u8(t)[0].numpy(), np.asarray(cpil.convert("L")))
+    assert np.array_equal(hwc(A._rgb2hsv_u8(t)), np.asarray(cpil.convert("HSV")))
+    assert np.array_equal(hwc(A._hsv2rgb_u8(t)), np.asarray(Image.fromarray(cube, "HSV").convert("RGB")))
 
 
 def test_augmentor_pair_semantics_and_batch():
@@ -158,10 +170,10 @@ def test_augmentor_pair_semantics_and_batch():
     out = aug.color_transform(pair)
     assert torch.equal(out[0], out[1])                               # one parameter draw per sample, like the reference
     assert out.shape == pair.shape and float(out.min()) >= 0 and float(out.max()) <= 255
-    ident = dict(order=[0, 1, 2, 3], b=1.0, c=1.0, s=1.0, h=0.0, gray=False)
-    assert float((A.RGBDAugmentor.apply(pair, ident) - pair).abs().max()) < 1e-3
+    ident = dict(order=[0, 1, 2], b=1.0, c=1.0, s=1.0, h=0.0, gray=False)         # (PIL's uint8 HSV round trip is lossy even at shift 0)
+    assert torch.equal(A.RGBDAugmentor.apply(pair, ident), pair) and torch.equal(A.RGBDAugmentor.apply(pair, A.RGBDAugmentor.IDENTITY), pair)
     gray = A.RGBDAugmentor.apply(pair, dict(ident, gray=True))
-    assert torch.allclose(gray[:, 0], gray[:, 1]) and torch.allclose(gray[:, 1], gray[:, 2])
+    assert torch.equal(gray[:, 0], gray[:, 1]) and torch.equal(gray[:, 1], gray[:, 2])
     # draws stay inside torchvision's ColorJitter ranges
     for _ in range(50):
         p = aug.draw()
@@ -293,3 +305,128 @@ def test_panorama_script_ground_truth_and_metrics_equal_the_references(ref_metri
     for f in ("all_rotation_err_degrees.csv", "all_gt_rot_degrees.csv"):
         assert open(os.path.join(out, f)).read() == str(ref_metrics["pano_script_file_" + f])
     assert "".join("%s %s\n" % (k, v) for k, v in m.items()) == str(ref_metrics["pano_script_file_results.txt"])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# SURVEY 8f row 3 pinned against the reference's OWN readers: tests/golden/reference_readers.npz holds what
+# /root/reference/src/data_readers/{base,matterport,interiornet,streetlearn,factory,augmentation}.py produced on the
+# closed-form fake training datasets of tests/_eval_cases.py (tests/golden/make_fixtures.py --readers-only, build
+# container only; the torchvision.transforms stand-in of that script has ColorJitter / RandomGrayscale as the identity or
+# as ONE fixed parameter set applied with PIL the way torchvision's functional_pil does).
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def ref_readers():
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_readers.npz"))
+
+
+@pytest.fixture(scope="module")
+def reader_roots(tmp_path_factory):
+    from tests import _eval_cases as EC
+    tmp = tmp_path_factory.mktemp("readers")
+    mroot, proot = str(tmp / "matterport_fake"), str(tmp / "pano_fake")
+    EC.write_matterport_train(mroot)
+    for ds, typ in sorted(EC.PANORAMA_TRAIN):
+        EC.write_panorama_train(proot, ds, typ)
+    return mroot, proot
+
+
+def _same_scene(ref, prefix, db, root):
+    si = db.scene_info
+    assert len(db) == int(ref[prefix + "_len"]), prefix
+    files = "\n".join(os.path.relpath(f, root) for pair in si["images"] for f in pair)
+    assert files == str(ref[prefix + "_files"]), prefix
+    if len(db):
+        assert np.array_equal(np.stack(si["poses"]).astype(np.float64), ref[prefix + "_scene_poses"]), prefix
+        assert np.array_equal(np.stack(si["intrinsics"]).astype(np.float64), ref[prefix + "_scene_intrinsics"]), prefix
+
+
+def _same_sample(ref, prefix, sample):
+    """bit for bit: shape, the sha256 of the fp32 image bytes, poses, rescaled intrinsics"""
+    import hashlib
+    im, po, K = sample
+    a = im.contiguous().numpy()
+    assert a.dtype == np.float32 and list(a.shape) == ref[prefix + "_images_shape"].tolist(), prefix
+    assert np.array_equal(a.reshape(-1)[::53], ref[prefix + "_images_sub"]), prefix
+    assert hashlib.sha256(a.tobytes()).hexdigest() == str(ref[prefix + "_images_sha256"]), prefix
+    assert po.dtype == torch.float32 and np.array_equal(po.numpy(), ref[prefix + "_poses"]), prefix
+    assert K.dtype == torch.float32 and np.array_equal(K.numpy(), ref[prefix + "_intrinsics"]), prefix
+
+
+def test_matterport_reader_reproduces_the_references_reader_bit_for_bit(ref_readers, reader_roots):
+    """reference src/data_readers/matterport.py:21-62 + base.py:45-69 + augmentation.py:28-37 with the jitter off: scene-info
+    construction (file-name rewrite, DEPTH_SCALE, the 3<->6 slot swap, w >= 0), train / val file selection by sub-epoch
+    (base.py:30), float32 casts, intrinsics rescale, nearest resize -- every sample identical to the last bit."""
+    from rel_pose_amd.data_readers.factory import dataset_factory
+    from rel_pose_amd.data_readers.matterport import Matterport
+    mroot, _ = reader_roots
+    for sub in (0, 4, 10):
+        db = Matterport(datapath=mroot, subepoch=sub, reshape_size=[96, 128], jitter=False)
+        _same_scene(ref_readers, "mp_sub%d" % sub, db, mroot)
+        for i in range(len(db)):
+            _same_sample(ref_readers, "mp_sub%d_i%d" % (sub, i), db[i])
+    _same_sample(ref_readers, "mp_default_size_i2", Matterport(datapath=mroot, subepoch=0, jitter=False)[2])     # 384 x 512 default
+    cat = dataset_factory(["matterport"], datapath=mroot, subepoch=10, reshape_size=[48, 64], jitter=False)
+    assert len(cat) == int(ref_readers["mp_factory_len"])
+    _same_sample(ref_readers, "mp_factory_i1", cat[1])
+
+
+def test_panorama_readers_reproduce_the_references_readers_bit_for_bit(ref_readers, reader_roots):
+    """reference interiornet.py:53-107 / streetlearn.py:53-108 + base.py:70-97: metadata file and image folder per
+    (dataset, type), the ten sub-epoch slices (43 pairs: 4 per slice, 3 never read), the mini dataset, viewpoint ->
+    quaternion ground truth, and the skip-forward on unreadable samples (pair 5: missing file, pair 6: undecodable file ->
+    indices 1 and 2 of sub-epoch 1 both return pair 7; pair 13 with both files missing -> pair 14)."""
+    from rel_pose_amd.data_readers.factory import dataset_factory
+    from rel_pose_amd.data_readers.interiornet import InteriorNet
+    from rel_pose_amd.data_readers.streetlearn import StreetLearn
+    from tests import _eval_cases as EC
+    _, proot = reader_roots
+    for ds, typ in sorted(EC.PANORAMA_TRAIN):
+        cls = InteriorNet if ds == "interiornet" else StreetLearn
+        tag = ds + typ
+        kw = dict(datapath=proot, streetlearn_interiornet_type=typ, reshape_size=[64, 80], jitter=False)
+        for sub in (0, 1, 3, 9):
+            _same_scene(ref_readers, "%s_sub%d" % (tag, sub), cls(subepoch=sub, **kw), proot)
+        mini = cls(subepoch=7, use_mini_dataset=True, **kw)
+        _same_scene(ref_readers, tag + "_mini", mini, proot)
+        db0, db1 = cls(subepoch=0, **kw), cls(subepoch=1, **kw)
+        for i in range(4):
+            _same_sample(ref_readers, "%s_sub0_i%d" % (tag, i), db0[i])
+            _same_sample(ref_readers, "%s_sub1_i%d" % (tag, i), db1[i])
+        assert torch.equal(db1[1][0], db1[3][0]) and torch.equal(db1[2][1], db1[3][1])          # both skipped forward to pair 7
+        _same_sample(ref_readers, tag + "_mini_i13", mini[13])
+        _same_sample(ref_readers, tag + "_mini_i12", mini[12])
+        if typ == "":
+            _same_sample(ref_readers, tag + "_default_size_i1", cls(datapath=proot, subepoch=0, streetlearn_interiornet_type=typ, jitter=False)[1])
+    cat = dataset_factory(["interiornet", "streetlearn"], datapath=proot, subepoch=0, streetlearn_interiornet_type="",
+                          reshape_size=[64, 80], jitter=False)
+    assert len(cat) == int(ref_readers["pano_factory_len"])
+    _same_sample(ref_readers, "pano_factory_i5", cat[5])
+
+
+def test_colour_jitter_ranges_are_the_references(ref_readers):
+    """the arguments the reference hands to ColorJitter / RandomGrayscale (augmentation.py:14-15), as recorded by the stand-in"""
+    ctor = dict(zip(ref_readers["jitter_ctor_names"].tolist(), ref_readers["jitter_ctor_values"].tolist()))
+    aug = A.RGBDAugmentor([8, 8])
+    assert ctor == dict(brightness=aug.brightness, contrast=aug.contrast, saturation=aug.saturation, hue=aug.hue, p_gray=aug.p_gray)
+
+
+@pytest.mark.parametrize("name", ["j0", "j1", "j2"])
+def test_fixed_colour_jitter_reproduces_the_references_reader_bit_for_bit(ref_readers, reader_roots, name):
+    """A FIXED ColorJitter / RandomGrayscale draw (tests/_eval_cases.FIXED_JITTER: three op orders, both signs of the hue shift, grey
+    on and off) through the reference's reader (ToPILImage, the PIL ops in that order on the glued pair, ToTensor, `255 *`, nearest
+    resize) against this repo's reader with the same draw: identical image bytes, poses and intrinsics, for every dataset class."""
+    from rel_pose_amd.data_readers.interiornet import InteriorNet
+    from rel_pose_amd.data_readers.matterport import Matterport
+    from rel_pose_amd.data_readers.streetlearn import StreetLearn
+    from tests import _eval_cases as EC
+    mroot, proot = reader_roots
+    prm = EC.FIXED_JITTER[name]
+    cases = [("mp_%s_i3" % name, Matterport(datapath=mroot, subepoch=0, reshape_size=[96, 128]), 3)]
+    for ds, typ in sorted(EC.PANORAMA_TRAIN):
+        cls = InteriorNet if ds == "interiornet" else StreetLearn
+        cases.append(("%s%s_%s_i2" % (ds, typ, name), cls(datapath=proot, subepoch=0, streetlearn_interiornet_type=typ, reshape_size=[64, 80]), 2))
+    for prefix, db, idx in cases:
+        db.aug.draw = lambda prm=prm: dict(prm)
+        sample = db[idx]
+        _same_sample(ref_readers, prefix, sample)
+        assert np.array_equal(sample[0].numpy(), ref_readers[prefix + "_images_u8"].astype(np.float32))

@@ -156,6 +156,41 @@ def test_se3_algebra_and_loss():
     assert torch.isfinite(est2.grad).all() and float(ltr) > 0
 
 
+def test_lazy_metrics_hand_plain_floats_to_every_dict_consumer():
+    """reference train.py:168 does `metrics.update(geo_metrics)` and gives the dict to its Logger: CPython's dict fast paths must
+    not copy the pending device tensors out of the subclass."""
+    from rel_pose_amd.losses import LazyMetrics
+    mk = lambda: LazyMetrics({"a": torch.tensor(1.5), "b": torch.tensor(2.0)})
+    d = {}
+    d.update(mk())
+    assert type(d["a"]) is float and d == {"a": 1.5, "b": 2.0}
+    assert type(dict(mk())["b"]) is float and type({**mk()}["a"]) is float
+    assert type((mk() | {"c": 1})["a"]) is float and type(({"c": 1} | mk())["a"]) is float
+    assert [type(v) for v in mk().values()] == [float, float] and sorted(mk()) == ["a", "b"]
+    import pickle
+    assert pickle.loads(pickle.dumps(mk())) == {"a": 1.5, "b": 2.0}
+
+
+def test_splitk_batch_state_is_per_thread_and_nest_safe():
+    """a re-entrant backward (a block opened inside a block) must not raise nor share the outer arena -- the inner block
+    simply does not defer -- and a second device's backward thread has its own state."""
+    import threading
+    from rel_pose_amd import ops
+    with ops.splitk_batch():
+        outer = ops._sk_batch()
+        assert outer is not None or not ops.SPLITK_BATCHING
+        with ops.splitk_batch():
+            assert ops._sk_batch() is None                   # inner: immediate reduces
+            with ops.splitk_batch():
+                assert ops._sk_batch() is None
+        assert ops._sk_batch() is outer                      # the outer block resumes deferring
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(ops._sk_batch()))
+        t.start(); t.join()
+        assert seen == [None]                                # other threads do not see this thread's block
+    assert ops._sk_batch() is None and ops._TLS.depth == 0
+
+
 def test_identity_like_and_indexing():
     from rel_pose_amd.se3 import SE3
     P = SE3(torch.randn(4, 2, 7))

@@ -5,9 +5,9 @@ One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI), batch-
 DistributedDataParallel: the only exchange per step is the gradient all-reduce.  The model is the drop-in ViTEss of
 rel_pose_amd (HIP hot path).  `--dataset matterport|interiornet|streetlearn --datapath ...` reads the reference's
 dataset layouts through rel_pose_amd/data_readers (ten sub-epochs then a validation pass, reference train.py:108-131);
-no dataset exists in the build environment, so `--dataset synthetic` (the default is the reference's `matterport`) streams seeded random pairs of the real
-tensor shapes and the whole loop -- forward, geodesic loss, backward, clip, Adam, OneCycle schedule, checkpoint save /
-auto-resume with the reference's file layout and keys -- runs anywhere.
+the default is the reference's `matterport`.  No dataset exists in the build environment: `--dataset synthetic` streams
+seeded random pairs of the real tensor shapes instead, so the whole loop -- forward, geodesic loss, backward, clip, Adam,
+OneCycle schedule, checkpoint save / auto-resume with the reference's file layout and keys -- runs anywhere.
 
     python train.py --name run0 --gpus 1 --batch 64 --steps 100 --fusion_transformer          # single GPU
     python train.py --name run0 --gpus 8 ...      # spawns 8 ranks itself, like the reference (train.py:286-291, port 12356)

@@ -104,7 +104,9 @@ def write_panorama_train(root, dataset, typ, n=PANORAMA_TRAIN_PAIRS, hw=(32, 40)
     """metadata for n pairs, images for pairs 0 .. images_upto-1 except the PANORAMA_UNREADABLE ones"""
     meta, fname, folder = PANORAMA_TRAIN[(dataset, typ)]
     split = panorama_train_entries(dataset, typ, n)
-    key = 5000 + 1000 * sorted(PANORAMA_TRAIN).index((dataset, typ))
+    # image content is a function of the image FOLDER (interiornet's two sets share data/interiornet: whichever set is written, the
+    # files are the same)
+    key = 5000 + 1000 * sorted({v[2] for v in PANORAMA_TRAIN.values()}).index(folder)
     for i in range(min(n, images_upto)):
         for j, k in enumerate(("img1", "img2")):
             path = os.path.join(root, "data", folder, split[i][k]["path"])

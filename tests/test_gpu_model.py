@@ -586,9 +586,12 @@ def test_bf16_operand_mode_is_a_different_precision(model, states):
 def test_bf16_configuration_at_128_pairs_per_gpu(model, states):
     """BASELINE.json configs[4]: bf16 operands everywhere a GEMM runs -- rp_gemm precision 1 AND the bf16 MFMA mode of the
     attention / EMM kernels -- at that configuration's per-GPU batch (1024 global / 8 = 128 pairs), forward and backward.
-    128 pairs = 4 distinct pairs x 32 copies.  Stated tolerance vs the fp64 oracle: R,t within 5e-2, token gradients within
+    128 pairs = 4 distinct pairs x 32 copies.  Stated tolerance vs the fp64 oracle: R,t within 3e-2, token gradients within
     2e-1 of max|ref| in the max norm (bf16 has 8 significant bits; forward + backward cross 12 block passes -- measured
-    1.4e-2 / 1.8e-2 / 1.1e-1).  The kernels are deterministic in this mode too: a second run is bit-identical.  The 32 copies of a pair
+    1.4e-2 / 1.8e-2 / 1.1e-1: the bounds are <= 2x what is measured), and EVERY ViT / regressor parameter tensor's gradient
+    (= 32 x the oracle's on the 4 distinct pairs) keeps its direction and size: cosine >= 0.98, norm within 5 %.  A kernel that
+    computes a block of some row tiles from the wrong operands (the round-4 race) moves these far more than a bf16 rounding does; the
+    kernel-level full-size value checks live in tests/test_gpu_bf16_fullsize.py.  The kernels are deterministic in this mode too: a second run is bit-identical.  The 32 copies of a pair
     agree to bf16 resolution only (poses within 5e-3, token gradients within 2e-2 of the maximum), not bit for bit: the CrossBlock's
     MLP (rp_mlp_fused_fwd / _bwd on 256 x 70 rows) cuts its row tiles' chunk ranges at workgroup boundaries that depend on the tile
     index, so the fixed fp32 summation order of a tile's partial sums differs from tile to tile by an ulp, and the bf16 roundings
@@ -614,6 +617,8 @@ def test_bf16_configuration_at_128_pairs_per_gpu(model, states):
         out = model.forward_tokens(fmap, Gs4[src].cuda(), intr4[src].contiguous().cuda())
         (out * cot4[src].float().cuda()).sum().backward()
         g_first, fmap.grad = fmap.grad.clone(), None
+        for p in model.parameters():
+            p.grad = None                                   # (the parameter gradients checked below are those of ONE backward)
         out2 = model.forward_tokens(fmap, Gs4[src].cuda(), intr4[src].contiguous().cuda())
         (out2 * cot4[src].float().cuda()).sum().backward()
     finally:
@@ -629,8 +634,20 @@ def test_bf16_configuration_at_128_pairs_per_gpu(model, states):
         assert float((out[b] - out[b % 4]).abs().max()) < 5e-3
         assert float((g[b] - g[b % 4]).abs().max()) < 2e-2 * gmax
     e_tok = rel(g[:4].reshape(8, 192, 576).permute(0, 2, 1), gtok)
-    report("config5_bf16_128pairs", t=t_err, q=q_err, grad_tokens=e_tok)
-    assert 1e-5 < max(t_err, q_err) < 5e-2 and e_tok < 2e-1
+    cos, ratio = {}, {}
+    for name, p in model.named_parameters():
+        if name.startswith("fusion_transformer") or name.startswith("pose_regressor"):
+            a, b = p.grad.double().flatten().cpu(), 32.0 * sd[name].grad.flatten()
+            cos[name] = float(torch.dot(a, b) / (a.norm() * b.norm()).clamp_min(1e-300))
+            ratio[name] = float(a.norm() / b.norm().clamp_min(1e-300))
+    tg_a, tg_b = g[:4].reshape(8, 192, 576).permute(0, 2, 1).double().flatten().cpu(), gtok.flatten()
+    cos["tokens"] = float(torch.dot(tg_a, tg_b) / (tg_a.norm() * tg_b.norm()))
+    ratio["tokens"] = float(tg_a.norm() / tg_b.norm())
+    report("config5_bf16_128pairs", t=t_err, q=q_err, grad_tokens=e_tok, min_cosine=min(cos.values()),
+           min_norm_ratio=min(ratio.values()), max_norm_ratio=max(ratio.values()))
+    assert 1e-5 < max(t_err, q_err) < 3e-2 and e_tok < 2e-1
+    bad = {k: (cos[k], ratio[k]) for k in cos if cos[k] < 0.98 or not (0.95 < ratio[k] < 1.05)}
+    assert not bad, bad
 
 
 def test_bf16_convolution_front_end_of_the_bf16_configuration(model):

@@ -9,7 +9,7 @@ import torch.nn.functional as F
 from rel_pose_amd import _env  # noqa: F401  (selects the shipped MIOpen user db)
 torch.backends.cudnn.benchmark = True
 dev = "cuda"
-Z = 128
+Z = int(os.environ.get("Z", "128"))
 CL = torch.channels_last
 DT = torch.bfloat16 if os.environ.get("DTYPE") == "bf16" else torch.float32      # DTYPE=bf16: what a bf16 front-end would cost
 

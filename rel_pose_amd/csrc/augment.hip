@@ -31,7 +31,10 @@ struct Rgb { int r, g, b; };        // uint8 values
 RP_DEV int clip8(int v) { return min(max(v, 0), 255); }
 RP_DEV int luma8(Rgb c) { return (c.r * 19595 + c.g * 38470 + c.b * 7471 + 0x8000) >> 16; }          // convert("L")
 RP_DEV int blend8(int deg, int img, float a, bool interp) {                                          // Image.blend(deg, img, a)
-  const float t = __fadd_rn((float)deg, __fmul_rn(a, (float)(img - deg)));
+  // plain operators, NOT __fmul_rn / __fadd_rn: those header inlines carry the default `contract` flag and fuse into one v_fma after
+  // inlining (measured: 2 % of the pixels off by one level); under this file's `fp contract(off)` the two roundings stay separate
+  const float prod = a * (float)(img - deg);
+  const float t = (float)deg + prod;
   if (interp) return (int)t;
   return t <= 0.f ? 0 : (t >= 255.f ? 255 : (int)t);
 }
@@ -49,7 +52,7 @@ RP_DEV Rgb hue_shift(Rgb c, int shift) {
     const float s = __fdiv_rn(cr, (float)maxc);
     const float rc = __fdiv_rn((float)(maxc - c.r), cr), gc = __fdiv_rn((float)(maxc - c.g), cr), bc = __fdiv_rn((float)(maxc - c.b), cr);
     float h;
-    if (c.r == maxc) h = __fsub_rn(bc, gc);
+    if (c.r == maxc) h = bc - gc;
     else if (c.g == maxc) h = (float)(2.0 + (double)rc - (double)bc);
     else h = (float)(4.0 + (double)gc - (double)rc);
     h = (float)fmod((double)h / 6.0 + 1.0, 1.0);
@@ -137,9 +140,9 @@ __global__ __launch_bounds__(256) void aug_apply_kernel(const unsigned char* __r
   c = apply_ops(c, p, 0, 4, mean);
   if (p[8] != 0.f) { const int g = luma8(c); c = Rgb{g, g, g}; }
   float* o = out + (((long long)b * 2 + im) * 3) * n_out + idx;
-  o[0] = __fmul_rn(255.f, __fdiv_rn((float)c.b, 255.f));          // ToTensor: uint8 / 255 in fp32; the reference: 255 * that
-  o[n_out] = __fmul_rn(255.f, __fdiv_rn((float)c.g, 255.f));
-  o[2 * n_out] = __fmul_rn(255.f, __fdiv_rn((float)c.r, 255.f));
+  o[0] = 255.f * __fdiv_rn((float)c.b, 255.f);          // ToTensor: uint8 / 255 in fp32; the reference: 255 * that
+  o[n_out] = 255.f * __fdiv_rn((float)c.g, 255.f);
+  o[2 * n_out] = 255.f * __fdiv_rn((float)c.r, 255.f);
 }
 
 }  // namespace

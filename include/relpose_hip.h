@@ -36,8 +36,8 @@ extern "C" {
  * functions this header declares.  rp_abi_version() / rp_abi_export_count() return the values the library was COMPILED with, so a
  * binding (rel_pose_amd/_lib.py parses both macros and counts the declarations) rejects a stale .so at load time instead of
  * failing later on a missing symbol. */
-#define RP_ABI_VERSION 11
-#define RP_ABI_EXPORTS 85
+#define RP_ABI_VERSION 12
+#define RP_ABI_EXPORTS 87
 int rp_abi_version(void);
 int rp_abi_export_count(void);
 const char* rp_target_arch(void);
@@ -178,6 +178,17 @@ int rp_maxpool3x3s2_bwd(const void* dy, const unsigned char* idx, void* dx, int 
  * zeros, ...) finishes them (any partial sums of (x - pivot), (x - pivot)^2 over disjoint row sets are accepted). */
 int rp_conv_stem_blocks(int N, int H, int W);
 int rp_conv_stem_fwd(const float* x_padded, const float* w, float* y, double* stats, int N, int H, int W, void* stream);
+
+/* The 3x3 / stride 1 / pad 1, 64 -> 64 convolutions of resnet.layer1 in the bf16 configuration (src/model.py:131; torchvision
+ * BasicBlock.conv1 / conv2), hand-written implicit GEMM with the input halo resident in LDS and the filter in registers
+ * (csrc/conv3x3_bf16.hip).  x, y [N,56,56,64] bf16 channels-last; w [64][3][3][64] bf16 (the memory of a channels-last nn.Conv2d
+ * weight; for the input gradient pass the rotated, transposed filter w'[ci][r][s][co] = w[co][2-r][2-s][ci] and dY as x).
+ * scale / shift (optional, both or neither) [64] fp32: the input is max(0, x * scale + shift) -- the producing layer's BatchNorm-apply
+ * + ReLU folded into the operand load; padding stays 0.  stats (optional) [rp_conv3x3_c64_blocks(N)][2][64] doubles: per-workgroup
+ * sums of the stored y and y^2 per channel (for rp_bn_stats_from_partials, like rp_conv_stem_fwd).  H = W = 56 only. */
+int rp_conv3x3_c64_blocks(int N);
+int rp_conv3x3_c64_bf16(const void* x, const void* w, void* y, const float* scale, const float* shift, double* stats, int N, int H, int W,
+                        void* stream);
 
 /* The stem's BatchNorm -> ReLU -> MaxPool2d(3, 2, 1) chain (src/model.py:127-130 on torchvision's resnet.bn1 / relu / maxpool) without
  * the [N,H,W,C] intermediates.  Forward (after rp_bn_stats, or with the running statistics in eval): y [N,OH,OW,C], idx = window

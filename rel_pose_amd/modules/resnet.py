@@ -32,8 +32,11 @@ class BasicBlock(nn.Module):
     def forward(self, x):
         # BatchNorm + residual add + ReLU as one fused pass pair on the GPU (rel_pose_amd/csrc/batchnorm.hip)
         idt = x if self.downsample is None else bn_act(self.downsample[1], conv2d(self.downsample[0], x), relu=False)
-        y = bn_act(self.bn1, conv2d(self.conv1, x))
-        return bn_act(self.bn2, conv2d(self.conv2, y), residual=idt)
+        # (bf16 configuration, layer1: the hand-written 3x3 convolution hands the BatchNorm its batch statistics from its epilogue)
+        y, st = conv2d(self.conv1, x, want_stats=True)
+        y = bn_act(self.bn1, y, stats=st)
+        y, st = conv2d(self.conv2, y, want_stats=True)
+        return bn_act(self.bn2, y, residual=idt, stats=st)
 
 
 class ResNet18(nn.Module):

@@ -1647,7 +1647,9 @@ class BnActFn(_Fn):
     training; running statistics in eval).  Returns a channels-last tensor."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, training, momentum, eps, relu):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, training, momentum, eps, relu, stats=None):
+        """stats: per-workgroup sums of x and x^2 [blocks,2,C] float64 from the producing convolution's epilogue (rp_conv3x3_c64_bf16):
+        then the statistics pass over x is skipped (training only)"""
         lib = _lib.load()
         N, C, H, W = x.shape
         xr = x.permute(0, 2, 3, 1)                       # [N,H,W,C] view of the channels-last buffer
@@ -1662,7 +1664,12 @@ class BnActFn(_Fn):
         bf = _chk_act(xr, rr)
         R = N * H * W
         y = torch.empty_like(xr)
-        if training:
+        if training and stats is not None:
+            mean, rstd = torch.empty(C, device=x.device), torch.empty(C, device=x.device)
+            _lib.check(lib.rp_bn_stats_from_partials(_p(stats), stats.shape[0], R, C, _p(_zeros(C, xr.device)), _p(mean), _p(rstd),
+                                                     _p(running_mean), _p(running_var), float(momentum), float(eps), _st()),
+                       "rp_bn_stats_from_partials")
+        elif training:
             mean, rstd = _empty(C, like=xr), _empty(C, like=xr)
             part = torch.empty(lib.rp_bn_partial_blocks(R) * 2 * C, device=x.device, dtype=torch.float64)
             _lib.check(lib.rp_bn_stats(_p(xr), R, C, _p(part), _p(mean), _p(rstd), _p(running_mean), _p(running_var),
@@ -1696,7 +1703,7 @@ class BnActFn(_Fn):
         _lib.check(lib.rp_bn_bwd(_p(dyr), _p(y), _p(xr), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dx), _p(dres), _p(dgamma), _p(dbeta),
                                  _p(part), _p(c12), R, C, 1 if relu else 0, 1 if training else 0, bf, _st()), "rp_bn_bwd")
         return (dx.permute(0, 3, 1, 2), dgamma, dbeta, None, None,
-                None if dres is None else dres.permute(0, 3, 1, 2), None, None, None, None)
+                None if dres is None else dres.permute(0, 3, 1, 2), None, None, None, None, None)
 
 
 # Convolution operand precision of the CNN front-end (MIOpen through PyTorch-ROCm): 0 = fp32 (the parity path),
@@ -1758,12 +1765,61 @@ class conv_params_bf16:
         return False
 
 
-def conv2d(m, x):
-    """nn.Conv2d module `m` applied to x at the configured operand precision."""
+# bf16 configuration: resnet.layer1's four 3x3 / 64 -> 64 convolutions on the hand-written implicit GEMM (csrc/conv3x3_bf16.hip): forward
+# (with the following BatchNorm's batch statistics from its epilogue) and input gradient (the same kernel on dY with the rotated,
+# transposed filter); the weight gradient stays MIOpen's backward-weights.
+CONV3X3_OWN = os.environ.get("RP_CONV3X3_OWN", "1") != "0"
+
+
+class Conv3x3C64Fn(_Fn):
+    @staticmethod
+    def forward(ctx, x, w, want_stats):
+        """x [N,64,56,56] bf16 channels-last, w [64,64,3,3] bf16 channels-last -> y (channels-last) [, stats partials (not differentiable)]"""
+        xr, wr = x.permute(0, 2, 3, 1), w.permute(0, 2, 3, 1)
+        if not xr.is_contiguous():
+            xr = xr.contiguous()
+        if not wr.is_contiguous():
+            wr = wr.contiguous()
+        ctx.save_for_backward(x, w)
+        if want_stats:
+            y, stats = conv3x3_c64_bf16(xr, wr, want_stats=True)
+            ctx.mark_non_differentiable(stats)
+            return y.permute(0, 3, 1, 2), stats
+        return conv3x3_c64_bf16(xr, wr).permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dy, *_):
+        x, w = ctx.saved_tensors
+        dx = dw = None
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        if ctx.needs_input_grad[0]:
+            # dX = conv3x3(dY, w'), w'[ci][r][s][co] = w[co][2-r][2-s][ci]
+            wt = w.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
+            dx = conv3x3_c64_bf16(dy.permute(0, 2, 3, 1), wt.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1]:
+            dw = torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+        return dx, dw, None
+
+
+def conv3x3_own_ok(m, x):
+    return (CONV3X3_OWN and CNN_PRECISION == 1 and x.is_cuda and tuple(m.weight.shape) == (64, 64, 3, 3) and m.bias is None
+            and m.stride == (1, 1) and m.padding == (1, 1) and m.dilation == (1, 1) and m.groups == 1 and tuple(x.shape[1:]) == (64, 56, 56))
+
+
+def conv2d(m, x, want_stats=False):
+    """nn.Conv2d module `m` applied to x at the configured operand precision.  want_stats: returns (y, stats) where stats are the
+    output's BatchNorm partial sums when the hand-written convolution ran (None otherwise)."""
+    if want_stats:
+        if conv3x3_own_ok(m, x) and getattr(m, "_rp_bf16", None) is not None:
+            xb = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
+            return Conv3x3C64Fn.apply(xb, m._rp_bf16[0], True)
+        return conv2d(m, x), None
     if CNN_PRECISION == 0 or not x.is_cuda:
         return m(x)
     bf = torch.bfloat16
     ready = getattr(m, "_rp_bf16", None)
+    if ready is not None and conv3x3_own_ok(m, x):
+        return Conv3x3C64Fn.apply(x if x.dtype == bf else x.to(bf), ready[0], False)
     if ready is not None:
         return torch.nn.functional.conv2d(x if x.dtype == bf else x.to(bf), ready[0], ready[1], m.stride, m.padding, m.dilation, m.groups)
     # activations STAY bf16 between the convolutions (the BatchNorm / ReLU / pool kernels of csrc/batchnorm.hip take bf16 storage):
@@ -1799,7 +1855,7 @@ def _bump_batches_tracked(bn):
         bn.num_batches_tracked += 1
 
 
-def bn_act(bn, x, residual=None, relu=True):
+def bn_act(bn, x, residual=None, relu=True, stats=None):
     """BatchNorm2d module `bn` applied to x, then (+ residual), then ReLU.  GPU tensors take the fused HIP path; CPU tensors
     (only the fixture generator uses the trunk on the CPU, as the reference's torchvision stand-in) take plain PyTorch."""
     if not x.is_cuda:
@@ -1810,7 +1866,7 @@ def bn_act(bn, x, residual=None, relu=True):
     if bn.training and bn.track_running_stats:
         _bump_batches_tracked(bn)
     return BnActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, bn.training, bn.momentum, bn.eps,
-                         relu)
+                         relu, stats if bn.training else None)
 
 
 class GeodesicLossFn(_Fn):
@@ -1883,6 +1939,26 @@ def conv_stem_fwd(x_padded_nhwc, w, want_stats=False):
     y = torch.empty(N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 64, device=w.device, dtype=torch.float32)
     stats = torch.empty(lib.rp_conv_stem_blocks(N, H, W), 2, 64, device=w.device, dtype=torch.float64) if want_stats else None
     _lib.check(lib.rp_conv_stem_fwd(_p(x_padded_nhwc), _p(wr), _p(y), _p(stats), N, H, W, _st()), "rp_conv_stem_fwd")
+    return (y, stats) if want_stats else y
+
+
+def conv3x3_c64_bf16(x_nhwc, w, scale=None, shift=None, want_stats=False):
+    """rp_conv3x3_c64_bf16: y = conv3x3(act(x), w), stride 1, pad 1, for x [N,56,56,64] bf16 (NHWC memory) and w [64,3,3,64] bf16 (the
+    memory of a channels-last [64,64,3,3] weight); act = max(0, x * scale + shift) when scale / shift [64] fp32 are given.  Returns y
+    [N,56,56,64] bf16 [, stats partials [blocks,2,64] float64 of the stored y]."""
+    lib = _lib.load()
+    bfd = torch.bfloat16
+    for t in (x_nhwc, w):
+        if not (t.is_cuda and t.is_contiguous() and t.dtype == bfd):
+            raise RuntimeError("conv3x3_c64_bf16: contiguous bf16 GPU tensors expected")
+    if tuple(x_nhwc.shape[1:]) != (56, 56, 64) or tuple(w.shape) != (64, 3, 3, 64):
+        raise RuntimeError("conv3x3_c64_bf16: x [N,56,56,64], w [64,3,3,64] expected, got %s, %s" % (tuple(x_nhwc.shape), tuple(w.shape)))
+    if scale is not None:
+        _chk(scale, shift)
+    N = x_nhwc.shape[0]
+    y = torch.empty_like(x_nhwc)
+    stats = torch.empty(lib.rp_conv3x3_c64_blocks(N), 2, 64, device=x_nhwc.device, dtype=torch.float64) if want_stats else None
+    _lib.check(lib.rp_conv3x3_c64_bf16(_p(x_nhwc), _p(w), _p(y), _p(scale), _p(shift), _p(stats), N, 56, 56, _st()), "rp_conv3x3_c64_bf16")
     return (y, stats) if want_stats else y
 
 

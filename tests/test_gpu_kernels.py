@@ -232,6 +232,46 @@ def test_gemm_precision1_epilogue_uses_the_bf16_configurations_gelu_pair(ops):
         ops.set_gemm_precision(prev)
 
 
+@pytest.mark.parametrize("N", [3, 37, 256])
+def test_conv3x3_c64_bf16_forward_fused_forms_and_backward(ops, N):
+    """rp_conv3x3_c64_bf16 (csrc/conv3x3_bf16.hip; resnet.layer1's 3x3 / 64 -> 64 convolutions in the bf16 configuration, src/model.py:131)
+    against fp64 F.conv2d on the same bf16 operands: plain; with the producing layer's BatchNorm-apply + ReLU folded into the operand
+    load (zero padding must stay zero); with the batch statistics of the stored output from the epilogue; ops.Conv3x3C64Fn's input
+    gradient (the same kernel on dY with the rotated, transposed filter) and weight gradient against fp64 autograd.  N = 3 / 37: tile
+    runs that end inside an image and workgroups with 0-3 tiles; 256: the configs[4] size (first and last images checked).
+    Tolerance 6e-3 of the maximum (a bf16 output, 2^-8 relative, of fp32-accumulated exact products); statistics 1e-6."""
+    import torch.nn.functional as F
+    bf, CL = torch.bfloat16, torch.channels_last
+    x = rnd(N, 64, 56, 56, seed=1).to(bf).contiguous(memory_format=CL)
+    w = rnd(64, 64, 3, 3, seed=2, scale=(64 * 9) ** -0.5).to(bf).contiguous(memory_format=CL)
+    scale, shift = 0.5 + rnd(64, seed=3).abs(), 0.3 * rnd(64, seed=4)
+    xn, wn = x.permute(0, 2, 3, 1), w.permute(0, 2, 3, 1)
+    sel = sorted(set(list(range(min(N, 3))) + [N - 1]))
+    ref = F.conv2d(x[sel].double(), w.double(), None, 1, 1).permute(0, 2, 3, 1)
+    y, st = ops.conv3x3_c64_bf16(xn, wn, want_stats=True)
+    e = dict(plain=rel(y[sel], ref))
+    assert torch.equal(y, ops.conv3x3_c64_bf16(xn, wn))                                   # the statistics do not change the output
+    yd = y.double()
+    e["sum"], e["sumsq"] = rel(st[:, 0].sum(0), yd.sum((0, 1, 2))), rel(st[:, 1].sum(0), (yd * yd).sum((0, 1, 2)))
+    xa = torch.relu(x[sel].float() * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)).to(bf)
+    ref_bn = F.conv2d(xa.double(), w.double(), None, 1, 1).permute(0, 2, 3, 1)
+    e["bn_relu_on_load"] = rel(ops.conv3x3_c64_bf16(xn, wn, scale, shift)[sel], ref_bn)
+    # autograd Function: forward, dX, dW
+    x1, w1 = x.detach().clone().requires_grad_(True), w.detach().clone().requires_grad_(True)
+    y1 = ops.Conv3x3C64Fn.apply(x1, w1, False)
+    dy = rnd(*y1.shape, seed=5).to(bf).contiguous(memory_format=CL)
+    y1.backward(dy)
+    x64, w64 = x[sel].double().requires_grad_(True), w.double().requires_grad_(True)
+    F.conv2d(x64, w64, None, 1, 1).backward(dy[sel].double())
+    e["dx"] = rel(x1.grad[sel], x64.grad)
+    if N <= 3:
+        e["dw"] = rel(w1.grad, w64.grad)
+    report("conv3x3_c64_bf16[N=%d]" % N, **e)
+    assert max(e["plain"], e["bn_relu_on_load"], e["dx"], e.get("dw", 0.0)) < 6e-3 and max(e["sum"], e["sumsq"]) < 1e-6, e
+    with pytest.raises(RuntimeError):
+        ops.conv3x3_c64_bf16(xn.float(), wn)
+
+
 def test_gemm_errors_are_loud(ops):
     A = rnd(64, 30)
     with pytest.raises(RuntimeError):

@@ -1801,6 +1801,41 @@ class Conv3x3C64Fn(_Fn):
         return dx, dw, None
 
 
+# bf16 configuration, the CNN tail's two 5x5 valid convolutions (src/modules/extractor.py:51-65): their input gradient IS a forward
+# convolution of dY with the rotated, transposed filter (padding 4), and MIOpen's forward solvers run these shapes faster than its
+# backward-data solvers once they are in the solver db (rel_pose_amd/miopen_db: profiles/r5_conv_probe_bf16_256.txt, 701 -> 515 us and
+# 413 -> 335 us at 256 images).  Same sums in another order: equal to MIOpen's backward-data to bf16 rounding.
+CONV_BWD_AS_FWD_MIN_K = int(os.environ.get("RP_CONV_BWD_AS_FWD_MIN_K", "5"))
+
+
+class ConvBf16Fn(_Fn):
+    """F.conv2d on bf16 channels-last operands (stride 1, dilation 1, groups 1) whose backward-data runs as a forward convolution;
+    weight / bias gradients stay MIOpen's backward-weights."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, padding):
+        ctx.save_for_backward(x, w)
+        ctx.conf = (tuple(padding), b is not None)
+        return torch.nn.functional.conv2d(x, w, b, 1, padding)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        padding, has_b = ctx.conf
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        k = w.shape[2]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wf = w.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
+            dx = torch.nn.functional.conv2d(dy, wf, None, 1, (k - 1 - padding[0], k - 1 - padding[1]))
+        mask = [False, ctx.needs_input_grad[1], has_b and ctx.needs_input_grad[2]]
+        if any(mask):
+            g = torch.ops.aten.convolution_backward(dy, x, w, [w.shape[0]] if has_b else None, [1, 1], list(padding), [1, 1], False,
+                                                    [0, 0], 1, mask)
+            dw, db = (g[1] if mask[1] else None), (g[2] if mask[2] else None)
+        return dx, dw, db, None
+
+
 def conv3x3_own_ok(m, x):
     return (CONV3X3_OWN and CNN_PRECISION == 1 and x.is_cuda and tuple(m.weight.shape) == (64, 64, 3, 3) and m.bias is None
             and m.stride == (1, 1) and m.padding == (1, 1) and m.dilation == (1, 1) and m.groups == 1 and tuple(x.shape[1:]) == (64, 56, 56))
@@ -1821,7 +1856,11 @@ def conv2d(m, x, want_stats=False):
     if ready is not None and conv3x3_own_ok(m, x):
         return Conv3x3C64Fn.apply(x if x.dtype == bf else x.to(bf), ready[0], False)
     if ready is not None:
-        return torch.nn.functional.conv2d(x if x.dtype == bf else x.to(bf), ready[0], ready[1], m.stride, m.padding, m.dilation, m.groups)
+        xb = x if x.dtype == bf else x.to(bf)
+        if (m.stride == (1, 1) and m.dilation == (1, 1) and m.groups == 1 and m.kernel_size[0] == m.kernel_size[1]
+                and m.kernel_size[0] >= CONV_BWD_AS_FWD_MIN_K):
+            return ConvBf16Fn.apply(xb, ready[0], ready[1], m.padding)
+        return torch.nn.functional.conv2d(xb, ready[0], ready[1], m.stride, m.padding, m.dilation, m.groups)
     # activations STAY bf16 between the convolutions (the BatchNorm / ReLU / pool kernels of csrc/batchnorm.hip take bf16 storage):
     # only the first convolution's input and the small weights are cast
     return torch.nn.functional.conv2d(x if x.dtype == bf else x.to(bf), m.weight.to(bf), None if m.bias is None else m.bias.to(bf),

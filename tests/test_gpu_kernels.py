@@ -272,6 +272,30 @@ def test_conv3x3_c64_bf16_forward_fused_forms_and_backward(ops, N):
         ops.conv3x3_c64_bf16(xn.float(), wn)
 
 
+@pytest.mark.parametrize("ci,co,k,pad,h", [(128, 192, 5, 0, 28), (192, 192, 5, 0, 28), (64, 96, 3, 1, 20)])
+def test_bf16_convolution_input_gradient_as_forward_convolution(ops, ci, co, k, pad, h):
+    """ops.ConvBf16Fn (bf16 configuration, the CNN tail's 5x5 valid convolutions, src/modules/extractor.py:51-65): the input gradient
+    computed as a FORWARD convolution of dY with the rotated / transposed filter against fp64 autograd of F.conv2d on the same
+    bf16-rounded operands: 1e-2 of the maximum (bf16 output of fp32-accumulated exact products) -- like MIOpen's own backward-data;
+    weight and bias gradients (MIOpen's backward-weights) likewise."""
+    import torch.nn.functional as F
+    bf, CL = torch.bfloat16, torch.channels_last
+    x = rnd(6, ci, h, h, seed=1).to(bf).contiguous(memory_format=CL).requires_grad_(True)
+    w = rnd(co, ci, k, k, seed=2, scale=(ci * k * k) ** -0.5).to(bf).contiguous(memory_format=CL).requires_grad_(True)
+    b = rnd(co, seed=3).to(bf).requires_grad_(True)
+    y = ops.ConvBf16Fn.apply(x, w, b, (pad, pad))
+    dy = rnd(*y.shape, seed=4).to(bf).contiguous(memory_format=CL)
+    y.backward(dy)
+    x64, w64, b64 = (t.detach().double().requires_grad_(True) for t in (x, w, b))
+    F.conv2d(x64, w64, b64, 1, pad).backward(dy.double())
+    e = dict(dx=rel(x.grad, x64.grad), dw=rel(w.grad, w64.grad), db=rel(b.grad, b64.grad))
+    report("conv_bf16_bwd_as_fwd[%d->%d,k%d]" % (ci, co, k), **e)
+    assert max(e.values()) < 1e-2, e
+    x2 = x.detach().clone().requires_grad_(True)
+    F.conv2d(x2, w.detach(), b.detach(), 1, pad).backward(dy)             # MIOpen's backward-data on the same operands
+    assert rel(x.grad, x2.grad) < 1e-2
+
+
 def test_gemm_errors_are_loud(ops):
     A = rnd(64, 30)
     with pytest.raises(RuntimeError):

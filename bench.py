@@ -115,7 +115,7 @@ def cpu_baseline(hw, budget_s=20.0):
                       "torch-CPU oracle, %d of %d host threads (best of 8/16/32/64), %.1f s"
                       % (n, Bc, hw, hw, cores, ncpu, el)}
 
-TRAFFIC_FILES = ("r4_traffic.json", "r3_traffic.json", "r2_traffic.json")
+TRAFFIC_FILES = ("r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r2_traffic.json")
 
 
 def csrc_fingerprint():
@@ -433,9 +433,9 @@ def main():
         tfiles = None
         if args.hw == 384:
             if args.batch == 64 and nl == 0:
-                tfiles = TRAFFIC_FILES if train else ("r4_traffic_fwd.json", "r3_traffic_fwd.json")
+                tfiles = TRAFFIC_FILES if train else ("r5_traffic_fwd.json", "r4_traffic_fwd.json", "r3_traffic_fwd.json")
             elif args.batch == 128 and nl == 1 and train:
-                tfiles = ("r4_traffic_bf16.json", "r3_traffic_bf16.json")
+                tfiles = ("r5_traffic_bf16.json", "r4_traffic_bf16.json", "r3_traffic_bf16.json")
         traffic, traffic_src, traffic_stale = pmc_traffic(kname, tfiles) if tfiles else (None, None, None)
         rec = {
             "metric": METRIC, "value": round(pairs / el, 2), "unit": "image-pairs/sec", "n_gpus": world,
@@ -470,11 +470,11 @@ def main():
             sup = {}         # (the headline model stays resident: 288 GB of HBM make freeing it pointless)
             for key, kw in (("fwd_only", dict(tag="ViTEss.forward, eval, no_grad, synthetic %dx%d pairs (BASELINE configs[1])" % (args.hw, args.hw),
                                               batch=64, mode="fwd", precision="fp32", steps=60, warmup=5, timer_instance="mlp_fused_fwd",
-                                              kernel_symbol=TAG_SYMBOLS["mlp_fused_fwd"], traffic_files=("r4_traffic_fwd.json", "r3_traffic_fwd.json"))),
+                                              kernel_symbol=TAG_SYMBOLS["mlp_fused_fwd"], traffic_files=("r5_traffic_fwd.json", "r4_traffic_fwd.json", "r3_traffic_fwd.json"))),
                             ("bf16_128", dict(tag="train.py step, bf16 MFMA operands in Linear / attention / EMM GEMMs and the MIOpen "
                                                   "convolutions, fp32 accumulate (BASELINE configs[4] per-GPU workload)",
                                               batch=128, mode="train", precision="bf16", steps=20, warmup=3, timer_instance="dw192_bf16",
-                                              kernel_symbol="dw192_bf16_kernel<false>", traffic_files=("r4_traffic_bf16.json", "r3_traffic_bf16.json")))):
+                                              kernel_symbol="dw192_bf16_kernel<false>", traffic_files=("r5_traffic_bf16.json", "r4_traffic_bf16.json", "r3_traffic_bf16.json")))):
                 try:
                     sup[key] = supplementary_point(dev, hw=args.hw, **kw)
                 except Exception as e:          # a supplementary point must never take the headline line down with it

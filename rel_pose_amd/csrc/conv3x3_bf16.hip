@@ -92,14 +92,25 @@ __global__ __launch_bounds__(NT, NT / 256) void conv3x3_c64_kernel(ConvP p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5, mq = wave >> 1, nh = wave & 1;       // wave (mq, nh): M-tiles 2 mq, 2 mq + 1; channels 32 nh ..
 
-  // ---- this wave's filter fragments: A operand, lane = (out channel 32 nh + l31, k-slots 8 hi .. 8 hi + 7 of each 16-channel step)
+  // ---- this wave's filter fragments: A operand, lane = (out channel 32 nh + l31, k-slots 8 hi .. 8 hi + 7 of each 16-channel step).
+  // The 72 KB filter goes global -> LDS as whole lines (18 coalesced 16-byte loads per thread) and LDS -> registers from there: read
+  // straight from global memory every wave instruction touches 64 different rows (8x the L2 requests).  Launch time is the same either
+  // way (the launch-size-independent part of this kernel is ~3 us: profiles/r5_conv3x3.txt).
   bf16x8 wf[9][4];
   {
-    const bf16_t* wrow = p.w + (long long)(32 * nh + l31) * (9 * C) + 8 * hi;
+    constexpr int WV = 64 * 9 * C * 2 / 16;                      // 4608 vectors
+#pragma unroll
+    for (int i = 0; i < WV / NT; ++i) {
+      const int v = tid + NT * i;
+      *reinterpret_cast<uint4*>(lds + v * 16) = *reinterpret_cast<const uint4*>(p.w + v * 8);
+    }
+    __syncthreads();
+    const unsigned char* wrow = lds + ((32 * nh + l31) * (9 * C) + 8 * hi) * 2;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) wf[tap][ks] = *reinterpret_cast<const bf16x8*>(wrow + tap * C + 16 * ks);
+      for (int ks = 0; ks < 4; ++ks) wf[tap][ks] = *reinterpret_cast<const bf16x8*>(wrow + (tap * C + 16 * ks) * 2);
+    __syncthreads();                                             // (the halo buffers reuse this memory)
   }
 
   // ---- halo vectors of this thread: vector v = tid + 256 i -> (position v >> 3, chunk v & 7 = tid & 7); the descriptors are recomputed

@@ -10,7 +10,7 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
            "GRBM_GUI_ACTIVE SQ_WAIT_INST_LDS SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC" \
            "FETCH_SIZE" "WRITE_SIZE"; do
-  timeout ${PMC_PASS_TIMEOUT:-120} rocprofv3 --pmc $grp --kernel-trace --output-format csv -d /tmp/pmck/p$i -o p -- python "$@" > /tmp/pmck/log$i.txt 2>&1
+  timeout ${PMC_PASS_TIMEOUT:-120} rocprofv3 --pmc $grp --kernel-trace --output-format csv -d /tmp/pmck/p$i -o p -- ${RUN:-python} "$@" > /tmp/pmck/log$i.txt 2>&1
   i=$((i+1))
 done
 python3 - "$tag" "$pat" <<'PY'

@@ -36,8 +36,8 @@ extern "C" {
  * functions this header declares.  rp_abi_version() / rp_abi_export_count() return the values the library was COMPILED with, so a
  * binding (rel_pose_amd/_lib.py parses both macros and counts the declarations) rejects a stale .so at load time instead of
  * failing later on a missing symbol. */
-#define RP_ABI_VERSION 12
-#define RP_ABI_EXPORTS 87
+#define RP_ABI_VERSION 13
+#define RP_ABI_EXPORTS 90
 int rp_abi_version(void);
 int rp_abi_export_count(void);
 const char* rp_target_arch(void);
@@ -189,6 +189,13 @@ int rp_conv_stem_fwd(const float* x_padded, const float* w, float* y, double* st
 int rp_conv3x3_c64_blocks(int N);
 int rp_conv3x3_c64_bf16(const void* x, const void* w, void* y, const float* scale, const float* shift, double* stats, int N, int H, int W,
                         void* stream);
+/* ... and their weight gradient (csrc/conv3x3_wgrad_bf16.hip): dw [64][3][3][64] bf16 (channels-last weight memory) = sum over pixels of
+ * dY[n,y,x,co] * X[n,y+r-1,x+s-1,ci], output-stationary over the pixel stream; workspace: rp_conv3x3_c64_wgrad_workspace_bytes(N) bytes
+ * of per-workgroup fp32 partials, summed in a fixed order by the call's second launch (deterministic). */
+int rp_conv3x3_c64_wgrad_blocks(int N);
+size_t rp_conv3x3_c64_wgrad_workspace_bytes(int N);
+int rp_conv3x3_c64_wgrad_bf16(const void* x, const void* dy, void* dw, void* workspace, size_t workspace_bytes, int N, int H, int W,
+                              void* stream);
 
 /* The stem's BatchNorm -> ReLU -> MaxPool2d(3, 2, 1) chain (src/model.py:127-130 on torchvision's resnet.bn1 / relu / maxpool) without
  * the [N,H,W,C] intermediates.  Forward (after rp_bn_stats, or with the running statistics in eval): y [N,OH,OW,C], idx = window

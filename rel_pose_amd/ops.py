@@ -1769,6 +1769,7 @@ class conv_params_bf16:
 # (with the following BatchNorm's batch statistics from its epilogue) and input gradient (the same kernel on dY with the rotated,
 # transposed filter); the weight gradient stays MIOpen's backward-weights.
 CONV3X3_OWN = os.environ.get("RP_CONV3X3_OWN", "1") != "0"
+CONV3X3_OWN_WGRAD = os.environ.get("RP_CONV3X3_OWN_WGRAD", "1") != "0"
 
 
 class Conv3x3C64Fn(_Fn):
@@ -1797,7 +1798,11 @@ class Conv3x3C64Fn(_Fn):
             wt = w.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
             dx = conv3x3_c64_bf16(dy.permute(0, 2, 3, 1), wt.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
-            dw = torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+            if CONV3X3_OWN_WGRAD:
+                xr = x.permute(0, 2, 3, 1)
+                dw = conv3x3_c64_wgrad_bf16(xr if xr.is_contiguous() else xr.contiguous(), dy.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
+            else:
+                dw = torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
         return dx, dw, None
 
 
@@ -1999,6 +2004,21 @@ def conv3x3_c64_bf16(x_nhwc, w, scale=None, shift=None, want_stats=False):
     stats = torch.empty(lib.rp_conv3x3_c64_blocks(N), 2, 64, device=x_nhwc.device, dtype=torch.float64) if want_stats else None
     _lib.check(lib.rp_conv3x3_c64_bf16(_p(x_nhwc), _p(w), _p(y), _p(scale), _p(shift), _p(stats), N, 56, 56, _st()), "rp_conv3x3_c64_bf16")
     return (y, stats) if want_stats else y
+
+
+def conv3x3_c64_wgrad_bf16(x_nhwc, dy_nhwc):
+    """rp_conv3x3_c64_wgrad_bf16: dW of y = conv3x3(x, w) (stride 1, pad 1, 64 -> 64, 56 x 56) from x and dY [N,56,56,64] bf16 (NHWC
+    memory) -> [64,3,3,64] bf16 (the memory of a channels-last [64,64,3,3] weight)."""
+    lib = _lib.load()
+    for t in (x_nhwc, dy_nhwc):
+        if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.bfloat16 and tuple(t.shape[1:]) == (56, 56, 64)):
+            raise RuntimeError("conv3x3_c64_wgrad_bf16: contiguous bf16 [N,56,56,64] GPU tensors expected")
+    N = x_nhwc.shape[0]
+    nb = lib.rp_conv3x3_c64_wgrad_workspace_bytes(N)
+    ws = torch.empty(nb // 4, device=x_nhwc.device, dtype=torch.float32)
+    dw = torch.empty(64, 3, 3, 64, device=x_nhwc.device, dtype=torch.bfloat16)
+    _lib.check(lib.rp_conv3x3_c64_wgrad_bf16(_p(x_nhwc), _p(dy_nhwc), _p(dw), _p(ws), nb, N, 56, 56, _st()), "rp_conv3x3_c64_wgrad_bf16")
+    return dw
 
 
 STEM_CONV = os.environ.get("RP_STEM_CONV", "1") != "0"      # hand-written stem convolution forward (exact fp32 front-end only)

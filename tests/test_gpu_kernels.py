@@ -239,7 +239,9 @@ def test_conv3x3_c64_bf16_forward_fused_forms_and_backward(ops, N):
     load (zero padding must stay zero); with the batch statistics of the stored output from the epilogue; ops.Conv3x3C64Fn's input
     gradient (the same kernel on dY with the rotated, transposed filter) and weight gradient against fp64 autograd.  N = 3 / 37: tile
     runs that end inside an image and workgroups with 0-3 tiles; 256: the configs[4] size (first and last images checked).
-    Tolerance 6e-3 of the maximum (a bf16 output, 2^-8 relative, of fp32-accumulated exact products); statistics 1e-6."""
+    Tolerance 6e-3 of the maximum (a bf16 output, 2^-8 relative, of fp32-accumulated exact products); statistics 1e-6.  The weight
+    gradient (rp_conv3x3_c64_wgrad_bf16: output-stationary over the pixel stream, transpose reads, fixed-order partial sums) is a bf16
+    output of up to 800 k fp32-accumulated products per element: 6e-3 against fp64 (N <= 37) / 1e-2 against MIOpen's bf16 result (256)."""
     import torch.nn.functional as F
     bf, CL = torch.bfloat16, torch.channels_last
     x = rnd(N, 64, 56, 56, seed=1).to(bf).contiguous(memory_format=CL)
@@ -264,10 +266,16 @@ def test_conv3x3_c64_bf16_forward_fused_forms_and_backward(ops, N):
     x64, w64 = x[sel].double().requires_grad_(True), w.double().requires_grad_(True)
     F.conv2d(x64, w64, None, 1, 1).backward(dy[sel].double())
     e["dx"] = rel(x1.grad[sel], x64.grad)
-    if N <= 3:
-        e["dw"] = rel(w1.grad, w64.grad)
+    if N <= 37:                                           # weight gradient (csrc/conv3x3_wgrad_bf16.hip) against fp64 over ALL images
+        xa64, wa64 = x.double(), w.double().requires_grad_(True)
+        F.conv2d(xa64, wa64, None, 1, 1).backward(dy.double())
+        e["dw"] = rel(w1.grad, wa64.grad)
+    else:                                                 # N = 256: against MIOpen's backward-weights on the same operands, and twice
+        dw_mi = torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+        e["dw"] = rel(w1.grad, dw_mi.double())
+        assert torch.equal(ops.conv3x3_c64_wgrad_bf16(xn, dy.permute(0, 2, 3, 1)), w1.grad.permute(0, 2, 3, 1))      # deterministic
     report("conv3x3_c64_bf16[N=%d]" % N, **e)
-    assert max(e["plain"], e["bn_relu_on_load"], e["dx"], e.get("dw", 0.0)) < 6e-3 and max(e["sum"], e["sumsq"]) < 1e-6, e
+    assert max(e["plain"], e["bn_relu_on_load"], e["dx"]) < 6e-3 and e["dw"] < (6e-3 if N <= 37 else 1e-2) and max(e["sum"], e["sumsq"]) < 1e-6, e
     with pytest.raises(RuntimeError):
         ops.conv3x3_c64_bf16(xn.float(), wn)
 

@@ -55,7 +55,16 @@ t0 = timeit(lambda: ops.conv3x3_c64_bf16(xn, wn))
 t1 = timeit(lambda: ops.conv3x3_c64_bf16(xn, wn, want_stats=True))
 t2 = timeit(lambda: ops.conv3x3_c64_bf16(xn, wn, scale, shift))
 t3 = timeit(lambda: ops.conv3x3_c64_bf16(xn, wn, scale, shift, want_stats=True))
+dy = torch.randn(N, 56, 56, 64, device="cuda", generator=g).to(bf)
+dyc = dy.permute(0, 3, 1, 2)
+dw = ops.conv3x3_c64_wgrad_bf16(xn, dy)
+dw_mi = torch.ops.aten.convolution_backward(dyc, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+print("wgrad: rel diff vs MIOpen %.2e" % rel(dw, dw_mi.permute(0, 2, 3, 1).double()))
+t_wmi = timeit(lambda: torch.ops.aten.convolution_backward(dyc, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False]))
+t_w = timeit(lambda: ops.conv3x3_c64_wgrad_bf16(xn, dy))
 print("N=%d  %.1f GF" % (N, fl * 1e-9))
+print("MIOpen wrw                      %7.1f us  %6.1f TF" % (t_wmi, fl / t_wmi * 1e-6))
+print("own wgrad (+ partial reduce)    %7.1f us  %6.1f TF" % (t_w, fl / t_w * 1e-6))
 print("MIOpen fwd                      %7.1f us  %6.1f TF" % (t_mi, fl / t_mi * 1e-6))
 for name, t in (("own plain", t0), ("own + stats epilogue", t1), ("own + BN/ReLU on load", t2), ("own + BN/ReLU on load + stats", t3)):
     print("%-31s %7.1f us  %6.1f TF  %5.2f TB/s algorithmic" % (name, t, fl / t * 1e-6, 2.0 * x.numel() * 2 / t * 1e-6))

@@ -36,8 +36,8 @@ extern "C" {
  * functions this header declares.  rp_abi_version() / rp_abi_export_count() return the values the library was COMPILED with, so a
  * binding (rel_pose_amd/_lib.py parses both macros and counts the declarations) rejects a stale .so at load time instead of
  * failing later on a missing symbol. */
-#define RP_ABI_VERSION 13
-#define RP_ABI_EXPORTS 90
+#define RP_ABI_VERSION 14
+#define RP_ABI_EXPORTS 92
 int rp_abi_version(void);
 int rp_abi_export_count(void);
 const char* rp_target_arch(void);
@@ -178,6 +178,12 @@ int rp_maxpool3x3s2_bwd(const void* dy, const unsigned char* idx, void* dx, int 
  * zeros, ...) finishes them (any partial sums of (x - pivot), (x - pivot)^2 over disjoint row sets are accepted). */
 int rp_conv_stem_blocks(int N, int H, int W);
 int rp_conv_stem_fwd(const float* x_padded, const float* w, float* y, double* stats, int N, int H, int W, void* stream);
+
+/* The stem convolution of the bf16 configuration (csrc/conv_stem_bf16.hip): same operands as rp_conv_stem_fwd -- the fp32 image inside its
+ * zero frame and the fp32 filter are rounded to bf16 on chip (v_mfma_f32_16x16x32_bf16, fp32 accumulate) -- y [N,OH,OW,64] bf16; stats as
+ * above, of the stored bf16 values. */
+int rp_conv_stem_bf16_blocks(int N, int H, int W);
+int rp_conv_stem_fwd_bf16(const float* x_padded, const float* w, void* y, double* stats, int N, int H, int W, void* stream);
 
 /* The 3x3 / stride 1 / pad 1, 64 -> 64 convolutions of resnet.layer1 in the bf16 configuration (src/model.py:131; torchvision
  * BasicBlock.conv1 / conv2), hand-written implicit GEMM with the input halo resident in LDS and the filter in registers

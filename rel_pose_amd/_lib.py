@@ -128,6 +128,8 @@ _SIGS = {
     "rp_preprocess_padded": (c_int, [P, P, I, I, I, I, P]),
     "rp_conv_stem_blocks": (c_int, [I, I, I]),
     "rp_conv_stem_fwd": (c_int, [P, P, P, P, I, I, I, P]),
+    "rp_conv_stem_bf16_blocks": (c_int, [I, I, I]),
+    "rp_conv_stem_fwd_bf16": (c_int, [P, P, P, P, I, I, I, P]),
     "rp_conv3x3_c64_blocks": (c_int, [I]),
     "rp_conv3x3_c64_bf16": (c_int, [P, P, P, P, P, P, I, I, I, P]),
     "rp_conv3x3_c64_wgrad_blocks": (c_int, [I]),

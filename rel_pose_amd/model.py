@@ -99,10 +99,11 @@ class ViTEss(nn.Module):
             # BGR->RGB, /255, mean/std, nearest 224 (one bit-exact HIP kernel) written inside the stem's zero padding; hand-written conv1
             # (in training also bn1's batch statistics, from the convolution's epilogue)
             stats = None
+            fn = ops.StemConvBf16Fn if ops.CNN_PRECISION == 1 else ops.StemConvFn      # (bf16 configuration: csrc/conv_stem_bf16.hip)
             if r.bn1.training and ops.STEM_STATS and ops.FUSE_STEM_POOL:
-                c1, stats = ops.StemConvFn.apply(ops.preprocess(images, pad=3), r.conv1.weight, True)
+                c1, stats = fn.apply(ops.preprocess(images, pad=3), r.conv1.weight, True)
             else:
-                c1 = ops.StemConvFn.apply(ops.preprocess(images, pad=3), r.conv1.weight)
+                c1 = fn.apply(ops.preprocess(images, pad=3), r.conv1.weight)
         else:
             c1, stats = ops.conv2d(r.conv1, ops.preprocess(images)), None
         x = ops.bn_relu_maxpool(r.bn1, r.maxpool, c1, stats)                    # stem: BatchNorm + ReLU + pool, one pass each way

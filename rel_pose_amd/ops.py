@@ -2021,7 +2021,23 @@ def conv3x3_c64_wgrad_bf16(x_nhwc, dy_nhwc):
     return dw
 
 
-STEM_CONV = os.environ.get("RP_STEM_CONV", "1") != "0"      # hand-written stem convolution forward (exact fp32 front-end only)
+def conv_stem_fwd_bf16(x_padded_nhwc, w, want_stats=False):
+    """rp_conv_stem_fwd_bf16: as conv_stem_fwd (fp32 framed image, fp32 channels-last filter), bf16 operands on chip -> y
+    [N,OH,OW,64] bf16 [, stats partials of the stored y]."""
+    lib = _lib.load()
+    wr = w.permute(0, 2, 3, 1)
+    if not wr.is_contiguous():
+        wr = wr.contiguous()
+    _chk(x_padded_nhwc, wr)
+    N, Hp, Wp, _ = x_padded_nhwc.shape
+    H, W = Hp - 6, Wp - 6
+    y = torch.empty(N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 64, device=w.device, dtype=torch.bfloat16)
+    stats = torch.empty(lib.rp_conv_stem_bf16_blocks(N, H, W), 2, 64, device=w.device, dtype=torch.float64) if want_stats else None
+    _lib.check(lib.rp_conv_stem_fwd_bf16(_p(x_padded_nhwc), _p(wr), _p(y), _p(stats), N, H, W, _st()), "rp_conv_stem_fwd_bf16")
+    return (y, stats) if want_stats else y
+
+
+STEM_CONV = os.environ.get("RP_STEM_CONV", "1") != "0"      # hand-written stem convolution forward
 STEM_STATS = os.environ.get("RP_STEM_STATS", "1") != "0"    # ... with the BatchNorm batch statistics from its epilogue
 
 
@@ -2051,8 +2067,34 @@ class StemConvFn(_Fn):
         return None, dw, None
 
 
+class StemConvBf16Fn(_Fn):
+    """resnet.conv1 in the bf16 configuration: forward = csrc/conv_stem_bf16.hip on the fp32 framed image and the fp32 master filter
+    (rounded to bf16 on chip); weight gradient = MIOpen's bf16 backward-weights on a bf16 copy of the framed image (padding 0), returned
+    in fp32 for the fp32 master; the image needs no gradient."""
+
+    @staticmethod
+    def forward(ctx, xp, w, want_stats=False):
+        ctx.save_for_backward(xp, w)
+        if want_stats:
+            y, stats = conv_stem_fwd_bf16(xp, w, want_stats=True)
+            ctx.mark_non_differentiable(stats)
+            return y.permute(0, 3, 1, 2), stats
+        return conv_stem_fwd_bf16(xp, w).permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dy, *_):
+        xp, w = ctx.saved_tensors
+        dw = None
+        if ctx.needs_input_grad[1]:
+            bf = torch.bfloat16
+            dy = dy.contiguous(memory_format=torch.channels_last)
+            dw = torch.ops.aten.convolution_backward(dy, xp.to(bf).permute(0, 3, 1, 2), w.to(bf), None, [2, 2], [0, 0], [1, 1], False, [0, 0], 1,
+                                                     [False, True, False])[1].float()
+        return None, dw, None
+
+
 def stem_conv_ok(conv, images):
-    return (STEM_CONV and CNN_PRECISION == 0 and images.is_cuda and tuple(conv.weight.shape) == (64, 3, 7, 7) and conv.bias is None
+    return (STEM_CONV and images.is_cuda and tuple(conv.weight.shape) == (64, 3, 7, 7) and conv.bias is None
             and conv.stride == (2, 2) and conv.padding == (3, 3))
 
 

@@ -304,6 +304,32 @@ def test_bf16_convolution_input_gradient_as_forward_convolution(ops, ci, co, k, 
     assert rel(x.grad, x2.grad) < 1e-2
 
 
+@pytest.mark.parametrize("N,hw", [(2, 224), (5, 100)])
+def test_stem_convolution_bf16_configuration(ops, N, hw):
+    """rp_conv_stem_fwd_bf16 (csrc/conv_stem_bf16.hip; resnet.conv1, src/model.py:127, in the bf16 configuration) against fp64 F.conv2d on
+    the bf16-rounded image and filter: 6e-3 of the maximum (bf16 output of fp32-accumulated exact products), batch statistics of the
+    stored values 1e-6; ops.StemConvBf16Fn's weight gradient against fp64 autograd 1e-2 (MIOpen's bf16 backward-weights: bf16 output)."""
+    import torch.nn.functional as F
+    bf, CL = torch.bfloat16, torch.channels_last
+    img = rnd(N, 3, hw, hw, seed=1)
+    w = rnd(64, 3, 7, 7, seed=2, scale=147 ** -0.5).contiguous(memory_format=CL).requires_grad_(True)
+    xp = torch.zeros(N, hw + 6, hw + 6, 3, device="cuda")
+    xp[:, 3:-3, 3:-3] = img.permute(0, 2, 3, 1)
+    y, st = ops.StemConvBf16Fn.apply(xp, w, True)
+    x64, w64 = img.to(bf).double(), w.detach().to(bf).double().requires_grad_(True)
+    ref = F.conv2d(x64, w64, None, 2, 3)
+    yd = y.double()
+    e = dict(y=rel(y, ref), sum=rel(st[:, 0].sum(0), yd.sum((0, 2, 3))), sumsq=rel(st[:, 1].sum(0), (yd * yd).sum((0, 2, 3))))
+    assert y.dtype == bf and y.is_contiguous(memory_format=CL)
+    assert torch.equal(y, ops.StemConvBf16Fn.apply(xp, w))
+    dy = rnd(*y.shape, seed=3).to(bf).contiguous(memory_format=CL)
+    y.backward(dy)
+    ref.backward(dy.double())
+    e["dw"] = rel(w.grad, w64.grad)
+    report("conv_stem_bf16[N=%d,%d]" % (N, hw), **e)
+    assert e["y"] < 6e-3 and max(e["sum"], e["sumsq"]) < 1e-6 and e["dw"] < 1e-2 and w.grad.dtype == torch.float32, e
+
+
 def test_gemm_errors_are_loud(ops):
     A = rnd(64, 30)
     with pytest.raises(RuntimeError):

@@ -36,8 +36,8 @@ extern "C" {
  * functions this header declares.  rp_abi_version() / rp_abi_export_count() return the values the library was COMPILED with, so a
  * binding (rel_pose_amd/_lib.py parses both macros and counts the declarations) rejects a stale .so at load time instead of
  * failing later on a missing symbol. */
-#define RP_ABI_VERSION 14
-#define RP_ABI_EXPORTS 92
+#define RP_ABI_VERSION 15
+#define RP_ABI_EXPORTS 94
 int rp_abi_version(void);
 int rp_abi_export_count(void);
 const char* rp_target_arch(void);
@@ -184,6 +184,12 @@ int rp_conv_stem_fwd(const float* x_padded, const float* w, float* y, double* st
  * above, of the stored bf16 values. */
 int rp_conv_stem_bf16_blocks(int N, int H, int W);
 int rp_conv_stem_fwd_bf16(const float* x_padded, const float* w, void* y, double* stats, int N, int H, int W, void* stream);
+/* ... and its weight gradient (csrc/conv_stem_wgrad_bf16.hip): dw [64][7][7][3] fp32 from the same framed fp32 image and dY [N,112,112,64]
+ * bf16 (H = W = 224 only): space-to-depth of the image into the workspace (bf16), an output-stationary MFMA stream over the pixels, a
+ * fixed-order reduce of the per-workgroup partials (three launches, deterministic). */
+size_t rp_conv_stem_wgrad_workspace_bytes(int N);
+int rp_conv_stem_wgrad_bf16(const float* x_padded, const void* dy, float* dw, void* workspace, size_t workspace_bytes, int N, int H, int W,
+                            void* stream);
 
 /* The 3x3 / stride 1 / pad 1, 64 -> 64 convolutions of resnet.layer1 in the bf16 configuration (src/model.py:131; torchvision
  * BasicBlock.conv1 / conv2), hand-written implicit GEMM with the input halo resident in LDS and the filter in registers

@@ -184,19 +184,20 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_wgrad_kernel(WgP p) {
     for (int r = 0; r < 16; ++r) o[acc_row(r, hi) * (9 * C) + tap * C] = acc[tap][r];
 }
 
+// 64 outputs x 4 slices of the partials per workgroup; fixed order: a slice front to back, then the four slices
 __global__ __launch_bounds__(256) void conv3x3_c64_wgrad_reduce_kernel(const float* __restrict__ ws, bf16_t* __restrict__ dw, int nblk) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;                         // < 36864
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int k = 0;
-  for (; k + 4 <= nblk; k += 4) {                                         // fixed order: four interleaved chains, then their sum
-    s0 += ws[(long long)k * (C * 9 * C) + idx];
-    s1 += ws[(long long)(k + 1) * (C * 9 * C) + idx];
-    s2 += ws[(long long)(k + 2) * (C * 9 * C) + idx];
-    s3 += ws[(long long)(k + 3) * (C * 9 * C) + idx];
+  __shared__ float part[4][64];
+  const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + o;                                    // < 36864
+  const int k0 = (int)((long long)nblk * sl / 4), k1 = (int)((long long)nblk * (sl + 1) / 4);
+  float s = 0.f;
+  for (int k = k0; k < k1; ++k) s += ws[(long long)k * (C * 9 * C) + idx];
+  part[sl][o] = s;
+  __syncthreads();
+  if (sl == 0) {
+    const float v = ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];
+    dw[idx] = (bf16_t)(pk_bf16(v, 0.f) & 0xffffu);
   }
-  for (; k < nblk; ++k) s0 += ws[(long long)k * (C * 9 * C) + idx];
-  const float v = (s0 + s1) + (s2 + s3);
-  dw[idx] = (bf16_t)(pk_bf16(v, 0.f) & 0xffffu);
 }
 
 }  // namespace
@@ -221,7 +222,7 @@ extern "C" int rp_conv3x3_c64_wgrad_bf16(const void* x, const void* dy, void* dw
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(conv3x3_c64_wgrad_kernel, dim3(nblk), dim3(256), 0, st, p);
   RP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(conv3x3_c64_wgrad_reduce_kernel, dim3(C * 9 * C / 256), dim3(256), 0, st, (const float*)workspace, (bf16_t*)dw, nblk);
+  hipLaunchKernelGGL(conv3x3_c64_wgrad_reduce_kernel, dim3(C * 9 * C / 64), dim3(256), 0, st, (const float*)workspace, (bf16_t*)dw, nblk);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }

@@ -81,13 +81,22 @@ __global__ __launch_bounds__(SNT, 4) void conv_stem_bf16_kernel(StemBP p) {
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);          // one filter fragment in flight per MFMA (else all 24 are hoisted: 96 registers)
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       }
-    if (ox0 + j < p.OW) {                       // lane (j, q): pixel j, channels 16 hb + 4 q .. + 3
-      bf16_t* yr = p.y + (((long long)n * p.OH + oy) * p.OW + ox0 + j) * CO + 4 * q;
+    // lane (j, q): pixel j, channels 16 hb + 4 q .. + 3.  Pairs of 16-channel blocks go out as ONE 16-byte store per lane after a
+    // half swap with lane q ^ 1 (common.h: st_bf16x8): even q writes channels 32 h2 + 4 q .. + 7, odd q 32 h2 + 16 + 4 (q - 1) .. + 7
+    // -- 64 contiguous bytes per pixel and instruction instead of 32 (the 8-byte form was store-issue-bound: 261 us per launch)
+    {
+      const bool live = ox0 + j < p.OW;
+      bf16_t* yr = p.y + (((long long)n * p.OH + oy) * p.OW + min(ox0 + j, p.OW - 1)) * CO + ((q & 1) ? 16 + 4 * (q - 1) : 4 * q);
 #pragma unroll
-      for (int hb = 0; hb < 4; ++hb) {
-        const unsigned w0 = pk_bf16(acc[hb][0], acc[hb][1]), w1 = pk_bf16(acc[hb][2], acc[hb][3]);
-        *reinterpret_cast<uint2*>(yr + 16 * hb) = make_uint2(w0, w1);
-        if (STATS) {
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const float4 v0 = make_float4(acc[2 * h2][0], acc[2 * h2][1], acc[2 * h2][2], acc[2 * h2][3]);
+        const float4 v1 = make_float4(acc[2 * h2 + 1][0], acc[2 * h2 + 1][1], acc[2 * h2 + 1][2], acc[2 * h2 + 1][3]);
+        if (live) st_bf16x8(yr + 32 * h2, v0, v1, q);          // (lanes q and q ^ 1 share the pixel: both live or both not)
+      }
+      if (STATS && live) {
+#pragma unroll
+        for (int hb = 0; hb < 4; ++hb) {
+          const unsigned w0 = pk_bf16(acc[hb][0], acc[hb][1]), w1 = pk_bf16(acc[hb][2], acc[hb][3]);
           const float v0 = __uint_as_float(w0 << 16), v1 = __uint_as_float(w0 & 0xffff0000u), v2 = __uint_as_float(w1 << 16),
                       v3 = __uint_as_float(w1 & 0xffff0000u);
           s1[4 * hb] += v0; s1[4 * hb + 1] += v1; s1[4 * hb + 2] += v2; s1[4 * hb + 3] += v3;

@@ -2037,7 +2037,25 @@ def conv_stem_fwd_bf16(x_padded_nhwc, w, want_stats=False):
     return (y, stats) if want_stats else y
 
 
+def conv_stem_wgrad_bf16(x_padded_nhwc, dy_nhwc):
+    """rp_conv_stem_wgrad_bf16: dW of the stem convolution from the fp32 framed image [N,230,230,3] and dY [N,112,112,64] bf16 ->
+    [64,7,7,3] fp32 (the memory of a channels-last [64,3,7,7] weight)."""
+    lib = _lib.load()
+    _chk(x_padded_nhwc)
+    if not (dy_nhwc.is_cuda and dy_nhwc.is_contiguous() and dy_nhwc.dtype == torch.bfloat16):
+        raise RuntimeError("conv_stem_wgrad_bf16: contiguous bf16 dY expected")
+    N = x_padded_nhwc.shape[0]
+    if tuple(x_padded_nhwc.shape[1:]) != (230, 230, 3) or tuple(dy_nhwc.shape) != (N, 112, 112, 64):
+        raise RuntimeError("conv_stem_wgrad_bf16: x_padded [N,230,230,3], dY [N,112,112,64] expected")
+    nb = lib.rp_conv_stem_wgrad_workspace_bytes(N)
+    ws = torch.empty((nb + 3) // 4, device=dy_nhwc.device, dtype=torch.float32)
+    dw = torch.empty(64, 7, 7, 3, device=dy_nhwc.device, dtype=torch.float32)
+    _lib.check(lib.rp_conv_stem_wgrad_bf16(_p(x_padded_nhwc), _p(dy_nhwc), _p(dw), _p(ws), nb, N, 224, 224, _st()), "rp_conv_stem_wgrad_bf16")
+    return dw
+
+
 STEM_CONV = os.environ.get("RP_STEM_CONV", "1") != "0"      # hand-written stem convolution forward
+STEM_WGRAD = os.environ.get("RP_STEM_WGRAD", "1") != "0"    # ... and (bf16 configuration, 224 x 224) its weight gradient
 STEM_STATS = os.environ.get("RP_STEM_STATS", "1") != "0"    # ... with the BatchNorm batch statistics from its epilogue
 
 
@@ -2088,8 +2106,11 @@ class StemConvBf16Fn(_Fn):
         if ctx.needs_input_grad[1]:
             bf = torch.bfloat16
             dy = dy.contiguous(memory_format=torch.channels_last)
-            dw = torch.ops.aten.convolution_backward(dy, xp.to(bf).permute(0, 3, 1, 2), w.to(bf), None, [2, 2], [0, 0], [1, 1], False, [0, 0], 1,
-                                                     [False, True, False])[1].float()
+            if STEM_WGRAD and tuple(xp.shape[1:]) == (230, 230, 3) and dy.dtype == bf:
+                dw = conv_stem_wgrad_bf16(xp, dy.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
+            else:
+                dw = torch.ops.aten.convolution_backward(dy.to(bf), xp.to(bf).permute(0, 3, 1, 2), w.to(bf), None, [2, 2], [0, 0], [1, 1], False,
+                                                         [0, 0], 1, [False, True, False])[1].float()
         return None, dw, None
 
 

@@ -304,11 +304,13 @@ def test_bf16_convolution_input_gradient_as_forward_convolution(ops, ci, co, k, 
     assert rel(x.grad, x2.grad) < 1e-2
 
 
-@pytest.mark.parametrize("N,hw", [(2, 224), (5, 100)])
+@pytest.mark.parametrize("N,hw", [(2, 224), (5, 100), (37, 224)])
 def test_stem_convolution_bf16_configuration(ops, N, hw):
     """rp_conv_stem_fwd_bf16 (csrc/conv_stem_bf16.hip; resnet.conv1, src/model.py:127, in the bf16 configuration) against fp64 F.conv2d on
     the bf16-rounded image and filter: 6e-3 of the maximum (bf16 output of fp32-accumulated exact products), batch statistics of the
-    stored values 1e-6; ops.StemConvBf16Fn's weight gradient against fp64 autograd 1e-2 (MIOpen's bf16 backward-weights: bf16 output)."""
+    stored values 1e-6; ops.StemConvBf16Fn's weight gradient against fp64 autograd: at 224 x 224 the hand-written stream
+    (csrc/conv_stem_wgrad_bf16.hip: fp32 output of fp32-accumulated exact bf16 products) 1e-4, else MIOpen's bf16 backward-weights 1e-2;
+    the hand-written gradient is deterministic and agrees with MIOpen's."""
     import torch.nn.functional as F
     bf, CL = torch.bfloat16, torch.channels_last
     img = rnd(N, 3, hw, hw, seed=1)
@@ -327,7 +329,13 @@ def test_stem_convolution_bf16_configuration(ops, N, hw):
     ref.backward(dy.double())
     e["dw"] = rel(w.grad, w64.grad)
     report("conv_stem_bf16[N=%d,%d]" % (N, hw), **e)
-    assert e["y"] < 6e-3 and max(e["sum"], e["sumsq"]) < 1e-6 and e["dw"] < 1e-2 and w.grad.dtype == torch.float32, e
+    assert e["y"] < 6e-3 and max(e["sum"], e["sumsq"]) < 1e-6 and e["dw"] < (1e-4 if hw == 224 else 1e-2) and w.grad.dtype == torch.float32, e
+    if hw == 224:
+        d1 = ops.conv_stem_wgrad_bf16(xp, dy.permute(0, 2, 3, 1))
+        assert torch.equal(d1, ops.conv_stem_wgrad_bf16(xp, dy.permute(0, 2, 3, 1))) and torch.equal(d1.permute(0, 3, 1, 2), w.grad)
+        mi = torch.ops.aten.convolution_backward(dy, xp.to(bf).permute(0, 3, 1, 2), w.detach().to(bf), None, [2, 2], [0, 0], [1, 1], False, [0, 0], 1,
+                                                 [False, True, False])[1]
+        assert rel(d1.permute(0, 3, 1, 2), mi.double()) < 1e-2
 
 
 def test_gemm_errors_are_loud(ops):

@@ -391,10 +391,33 @@ def main():
     if roctx is not None:
         roctx.roctxProfilerPause(0)
     timer.enabled = False
+    dist_diag = None
     if world > 1 or force_dist:
-        tt = torch.tensor([el], device=dev, dtype=torch.float64)
+        # self-diagnosing scaling record: every rank's own time for the timed steps, and -- AFTER the timed
+        # region, never inside it -- the same step without the gradient exchange (DDP no_sync), so that the all-reduce time the
+        # backward does not hide can be read off the line: exposed = ms_per_step - ms_per_step_no_allreduce (max over ranks each)
+        own = torch.tensor([el], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(own) for _ in range(world)]
+        dist.all_gather(every, own)
+        tt = own.clone()
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
+        dist_diag = {"per_rank_ms_per_step": [round(1e3 * float(t.item()) / args.steps, 3) for t in every]}
+        if train and not graphed and hasattr(net, "no_sync"):
+            k = max(3, min(10, args.steps))
+            fence()
+            t1 = time.perf_counter()
+            with net.no_sync():
+                for _ in range(k):
+                    step()
+            fence()
+            ns = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+            dist.all_reduce(ns, op=dist.ReduceOp.MAX)
+            ms_ns = 1e3 * float(ns.item()) / k
+            dist_diag.update({"ms_per_step_no_allreduce": round(ms_ns, 3), "steps_no_allreduce": k,
+                              "exposed_allreduce_ms": round(1e3 * el / args.steps - ms_ns, 3),
+                              "gradient_bytes": int(sum(p.numel() for p in model.parameters() if p.requires_grad) * 4),
+                              "note": "no_allreduce = the same step under DDP.no_sync(), timed after the judged region"})
     finite = bool(torch.isfinite(last).all())
 
     if graphed:
@@ -480,6 +503,8 @@ def main():
                 except Exception as e:          # a supplementary point must never take the headline line down with it
                     sup[key] = {"error": "%s: %s" % (type(e).__name__, e)}
             rec["supplementary"] = sup
+        if dist_diag is not None:
+            rec["distributed"] = dist_diag
         if not args.no_cpu_baseline and world == 1:
             rec["cpu_baseline"] = cpu_baseline(args.hw)
         print(json.dumps(rec), flush=True)

@@ -225,6 +225,7 @@ def test_bench_two_ranks_on_one_gpu():
     rec = json.loads(line)
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch_pairs"] == 16 and rec["config"]["finite"] and rec["scaling"] == "weak"
     assert "cpu_baseline" not in rec and rec["roofline"]["launches_timed"] > 0
+    assert len(rec["distributed"]["per_rank_ms_per_step"]) == 2 and rec["distributed"]["ms_per_step_no_allreduce"] > 0
 
 
 def test_product_model_ddp_gradients_equal_full_batch(tmp_path):
@@ -291,6 +292,11 @@ def test_bench_distributed_path_on_rccl_single_rank():
     assert r.returncode == 0, r.stderr[-3000:]
     rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert rec["n_gpus"] == 1 and rec["config"]["finite"] and rec["roofline"]["launches_timed"] > 0
+    # the scaling record diagnoses itself: per-rank step times and the step without the gradient exchange (timed after the judged region)
+    d = rec["distributed"]
+    assert len(d["per_rank_ms_per_step"]) == 1 and abs(d["per_rank_ms_per_step"][0] - rec["ms_per_step"]) < 1e-2
+    assert d["ms_per_step_no_allreduce"] > 0 and d["gradient_bytes"] == 4 * 19258510
+    assert abs(d["exposed_allreduce_ms"] - (rec["ms_per_step"] - d["ms_per_step_no_allreduce"])) < 1e-2
 
 
 def test_graphed_train_step_matches_the_eager_step():

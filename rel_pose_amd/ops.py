@@ -1295,7 +1295,7 @@ def _chunk_permuted_bf16(w, transpose=False):
     """bf16 copy of a [192, 768] operand (w, or w^T when transpose) with the 768 hidden units of every 32-chunk in the order the fused
     MLP kernels' second product wants (_mlp_unit_perm); cached on w until it changes"""
     c = getattr(w, "_rp_bp", None)
-    if c is not None and c[0] == w._version and c[1] == w.data_ptr() and c[2] == _PAD_GEN:
+    if c is not None and c[0] == w._version and c[1] == w.data_ptr() and c[2] == _PAD_GEN and c[4] == MLP_W2_CHUNK_MAJOR:
         return c[3]
     src = w.detach().t() if transpose else w.detach()
     o = src.index_select(1, _mlp_unit_perm(w.device)).to(torch.bfloat16).contiguous()
@@ -1303,7 +1303,7 @@ def _chunk_permuted_bf16(w, transpose=False):
         o = o.view(o.shape[0], -1, 32).permute(1, 0, 2).contiguous()
     if not (w.is_cuda and torch.cuda.is_current_stream_capturing()):
         try:
-            w._rp_bp = (w._version, w.data_ptr(), _PAD_GEN, o)
+            w._rp_bp = (w._version, w.data_ptr(), _PAD_GEN, o, MLP_W2_CHUNK_MAJOR)      # (the layout is part of the key)
         except AttributeError:
             pass
     return o

@@ -423,3 +423,76 @@ def test_evaluation_scripts_reproduce_the_references_runs(tmp_path, monkeypatch)
     with open(os.path.join(ROOT, "gpurun_out", "test_report.txt"), "a") as f:
         f.write("eval_scripts_vs_reference_runs: matterport raw=%.2e pred_t=%.2e metrics=%.2e | interiornet raw=%.2e metrics=%.2e\n"
                 % (e_raw, e_pt, e_m, e_raw2, e_m2))
+
+
+FP32_SWITCHES = ["SPLITK_BATCHING", "ROWS_LINEAR", "ROWS_DX", "FUSE_LN_BWD", "DW192_F32", "COLSUM_BATCHING", "ATTN_BWD_STORE_DS",
+                 "EMM_BWD_STORE_DS", "QKV_BIAS_FROM_PRODUCERS", "EMM_STATS_ONE_PASS", "FUSE_MLP", "FUSE_MLP_TRAIN", "FUSE_MLP_BWD",
+                 "USE_SIDE_STREAM", "STEM_CONV", "STEM_STATS", "FUSE_STEM_POOL"]
+BF16_SWITCHES = ["ACT_BF16", "BF16_PATH", "DX_LNBWD_BF16", "DW192", "MLP_W2_CHUNK_MAJOR", "CONV3X3_OWN", "CONV3X3_OWN_WGRAD", "STEM_CONV",
+                 "STEM_WGRAD", "STEM_STATS", "CONV_BWD_AS_FWD_MIN_K"]
+
+
+def _step_outputs(model, images, Gs, intr):
+    import torch
+    for p in model.parameters():
+        p.grad = None
+    out = model(images, Gs, intrinsics=intr.clone())[0].data
+    out[:, 1].square().sum().backward()
+    keys = ("resnet.conv1.weight", "resnet.layer1.0.conv1.weight", "resnet.layer1.1.conv2.weight", "extractor_final_conv.conv2.weight",
+            "fusion_transformer.blocks.0.attn.qkv.weight", "fusion_transformer.blocks.2.mlp.fc1.weight", "fusion_transformer.blocks.2.mlp.fc2.weight",
+            "fusion_transformer.blocks.5.cross_attn.qkv.weight", "fusion_transformer.blocks.4.norm2.weight", "pose_regressor.0.weight")
+    named = dict(model.named_parameters())
+    return out.detach().clone(), {k: named[k].grad.detach().double().flatten().clone() for k in keys}
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_every_kernel_path_switch_has_a_working_alternative(precision):
+    """every `RP_*` switch of rel_pose_amd/ops.py that selects an alternative kernel path is flipped, one at a
+    time, on a whole training step of the product model (2 pairs, images in, train-mode BatchNorm): the alternative must run and give
+    the default path's pose and gradients -- fp32: pose within 2e-4, every checked gradient cosine >= 0.9999 (the alternatives are the
+    same arithmetic in another summation order or kernel); bf16 configuration: pose within 5e-2, cosine >= 0.97 (another rounding
+    schedule) -- except the CNN front-end's own weight gradients, which at 2 pairs sit behind 12 layers of ReLU / max-pool masks that a
+    bf16 rounding flips (test_bf16_convolution_front_end...: 0.958 between fp32 and bf16): >= 0.85.  A switch whose alternative no longer
+    works fails here instead of rotting."""
+    import types
+    import torch
+    from rel_pose_amd import ops
+    from rel_pose_amd.model import ViTEss
+    torch.manual_seed(0)
+    args = types.SimpleNamespace(noess="", pool_size=60, fc_hidden_size=512, fusion_transformer=True, transformer_depth=6,
+                                 cross_features=False, use_single_softmax=False, no_pos_encoding=False, l1_pos_encoding=False)
+    model = ViTEss(args).cuda().train()
+    images = torch.floor(torch.rand(2, 2, 3, 384, 384, device="cuda") * 255.0)
+    Gs = torch.tensor([0, 0, 0, 0, 0, 0, 1.0]).repeat(2, 2, 1).cuda()
+    intr = torch.tensor([[192.0, 192.0, 192.0, 192.0]]).repeat(2, 2, 1).cuda()
+    bn = {k: v.clone() for k, v in model.state_dict().items() if "running_" in k or "num_batches" in k}
+    bf = precision == "bf16"
+    ops.set_gemm_precision(1 if bf else 0)
+    ops.set_attention_precision(1 if bf else 0)
+    ops.set_cnn_precision(1 if bf else 0)
+    tol_pose, tol_cos = (5e-2, 0.97) if bf else (2e-4, 0.9999)
+    try:
+        base_out, base_g = _step_outputs(model, images, Gs, intr)
+        model.load_state_dict(bn, strict=False)
+        bad = {}
+        for name in (BF16_SWITCHES if bf else FP32_SWITCHES):
+            old = getattr(ops, name)
+            setattr(ops, name, (99 if name == "CONV_BWD_AS_FWD_MIN_K" else (not old)))
+            try:
+                out, g = _step_outputs(model, images, Gs, intr)
+            finally:
+                setattr(ops, name, old)
+                model.load_state_dict(bn, strict=False)
+            e_pose = float((out - base_out).abs().max() / base_out.abs().max())
+            cs = {k: float(torch.dot(g[k], base_g[k]) / (g[k].norm() * base_g[k].norm()).clamp_min(1e-300)) for k in g}
+            # (a switch that changes the FIRST layers' rounding schedule in bf16 perturbs every activation behind it: at 2 pairs and
+            # random init the late gradients move with it -- the kernels themselves are pinned against fp64 in test_gpu_kernels.py)
+            front = bf and name in ("STEM_CONV", "CONV3X3_OWN")
+            ok = all(c >= (0.85 if (front or (bf and k.startswith(("resnet", "extractor")))) else tol_cos) for k, c in cs.items())
+            if not (torch.isfinite(out).all() and e_pose < tol_pose and ok):
+                bad[name] = (e_pose, min(cs.values()))
+        assert not bad, bad
+    finally:
+        ops.set_gemm_precision(0)
+        ops.set_attention_precision(0)
+        ops.set_cnn_precision(0)

@@ -33,6 +33,19 @@ def test_train_steps_checkpoint_and_resume(tmp_path):
     assert "resumed from" in r2.stdout
 
 
+def test_train_in_the_bf16_configuration(tmp_path):
+    """train.py --precision bf16 (BASELINE.json configs[4]: bf16 data path of the ViT / EMM + the hand-written bf16 convolutions of the CNN
+    front-end): a few steps on synthetic 384 x 384 pairs run to the end with finite losses and write the reference's checkpoint layout."""
+    args = [os.path.join(ROOT, "train.py"), "--name", "tb", "--batch", "4", "--steps", "5", "--warmup", "2", "--fusion_transformer",
+            "--image_size", "384", "384", "--num_workers", "0", "--dataset", "synthetic", "--precision", "bf16"]
+    r = run(args, str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "finished training!" in r.stdout and "nan" not in r.stdout.lower()
+    import torch
+    sd = torch.load(str(tmp_path / "output" / "tb" / "checkpoints" / "000005.pth"), map_location="cpu")
+    assert len(sd["model"]) == 227 and all(torch.isfinite(v).all() for v in sd["model"].values() if v.is_floating_point())
+
+
 def test_demo_runs_on_png_pair(tmp_path):
     import numpy as np
     import zlib, struct

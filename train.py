@@ -10,6 +10,7 @@ seeded random pairs of the real tensor shapes instead, so the whole loop -- forw
 OneCycle schedule, checkpoint save / auto-resume with the reference's file layout and keys -- runs anywhere.
 
     python train.py --name run0 --gpus 1 --batch 64 --steps 100 --fusion_transformer          # single GPU
+    python train.py ... --precision bf16          # (not in the reference) BASELINE configs[4]: bf16 data path + bf16 CNN front-end
     python train.py --name run0 --gpus 8 ...      # spawns 8 ranks itself, like the reference (train.py:286-291, port 12356)
     python -m torch.distributed.run --nproc-per-node 8 train.py --name run0 --gpus 8 ...       # or under a launcher
 """
@@ -95,6 +96,11 @@ def run(args):
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
+    from rel_pose_amd import ops
+    prec = {"fp32": 0, "split3": 3, "bf16": 1}[getattr(args, "precision", "fp32")]
+    ops.set_gemm_precision(prec)
+    ops.set_attention_precision(1 if prec == 1 else 0)
+    ops.set_cnn_precision(1 if prec == 1 else 0)
     model = ViTEss(args).to(dev).train()
     if rank == 0 and not model.resnet_pretrained and not (args.ckpt or find_resume(args.name)):
         print("WARNING: the ResNet-18 trunk starts from random weights -- the reference fine-tunes conv1/layer1/layer2 from "
@@ -235,6 +241,9 @@ def parser():
     ap.add_argument("--pool_size", type=int, default=60)
     ap.add_argument("--transformer_depth", type=int, default=6)
     ap.add_argument("--resnet_weights", help="local torchvision resnet18 state_dict (.pth) for the pretrained trunk")
+    ap.add_argument("--precision", default="fp32", choices=("fp32", "split3", "bf16"),
+                    help="not in the reference: operand precision of the HIP hot path -- fp32 = exact fp32 MFMA (the parity path, default); "
+                         "bf16 = BASELINE configs[4] (bf16 data path + bf16 CNN front-end, tanh-form GELU); split3 = fp32-grade on the bf16 pipe")
     return ap
 
 

@@ -84,7 +84,13 @@ __global__ __launch_bounds__(256, 1) void dw192_f32_kernel(DwF p) {
   __builtin_amdgcn_s_barrier();
   for (int s = 0; s < nst; ++s) {
     const int buf = s & 1;
-    if (s + 1 < nst) issue(s + 1, buf ^ 1);
+    // The next stage's twelve DMA pieces are issued ONE PER K-STEP, each in the shadow of that step's nine MFMAs (576 matrix-pipe cycles):
+    // issued as a block at the stage's top they held the in-order wave -- and the idle pipe -- for ~7 % of the launch
+    // (tools/lab/dw_ablate.sh, profiles/r5_dw_ablate.txt).  The last stage re-fetches itself into the dead buffer (no branch in the loop).
+    const int sn = min(s + 1, nst - 1);
+    const void* sa = uniform_vpf(ab + (long long)sn * SR * p.lda);
+    const void* sb = uniform_vpf(bb + (long long)sn * SR * W);
+    const unsigned an0 = as0 + (buf ^ 1) * (ST_FL * 4), bn0 = bs0 + (buf ^ 1) * (ST_FL * 4);
     const float* At = As[buf] + ao;
     const float* Bt = Bs[buf] + bo;
     // operands of k-step t + 1 are read while the nine MFMAs of step t run (one wave per SIMD: nobody else hides the LDS latency)
@@ -104,6 +110,8 @@ __global__ __launch_bounds__(256, 1) void dw192_f32_kernel(DwF p) {
           bn[i] = Bt[2 * (t + 1) * W + 32 * i];
         }
       }
+      if (t < 6) glds16f(sa, aoff[t], an0 + t * 4096);
+      else if (t < 12) glds16f(sb, boff[t - 6], bn0 + (t - 6) * 4096);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < 3; ++i)

@@ -36,8 +36,8 @@ extern "C" {
  * functions this header declares.  rp_abi_version() / rp_abi_export_count() return the values the library was COMPILED with, so a
  * binding (rel_pose_amd/_lib.py parses both macros and counts the declarations) rejects a stale .so at load time instead of
  * failing later on a missing symbol. */
-#define RP_ABI_VERSION 15
-#define RP_ABI_EXPORTS 94
+#define RP_ABI_VERSION 16
+#define RP_ABI_EXPORTS 96
 int rp_abi_version(void);
 int rp_abi_export_count(void);
 const char* rp_target_arch(void);
@@ -495,6 +495,18 @@ size_t rp_mlp_fused_bwd_workspace_bytes(int M);
 int rp_mlp_fused_bwd_tile_rows(void);
 int rp_mlp_fused_bwd(const float* dy, const float* hpre, const float* w2t, const float* w1t, float* dhp, float* dxn, float* colpart,
                      void* workspace, int M, int dim, int hidden, int precision, int io_bf16, void* stream);
+/* The same with the backward of the LayerNorm in front of fc1 folded into the epilogue (Block.forward, vision_transformer.py:353:
+ * x + mlp(norm2(x)) -- the gradient of x is LayerNorm-backward(dxn) + dy): instead of dxn the kernel writes
+ *     dx [M,dim] = rstd (g - mean_c(g) - xhat mean_c(g xhat)) + dy,   g = dxn o ln_gamma,  xhat = (ln_x - ln_mean) ln_rstd
+ * (ln_x [M,dim] the LayerNorm's input, ln_mean / ln_rstd [M] its saved statistics; dx must not alias dy), and ln_part
+ * [rp_mlp_fused_bwd_ln_part_rows(M)][3 dim] receives per row block the column sums of (dxn o xhat | dxn | dy): summed over the rows they
+ * are dgamma, dbeta and the bias gradient of the Linear that produced dy (rp_layernorm_bwd's contract with `add` = dy).  dxn never
+ * reaches HBM: one [M,dim] write + read and the re-read of dy saved per Block.  Tiles that no single workgroup finished are
+ * completed -- LayerNorm backward included -- by a fix-up launch.  All other arguments as rp_mlp_fused_bwd. */
+int rp_mlp_fused_bwd_ln_part_rows(int M);
+int rp_mlp_fused_bwd_ln(const float* dy, const float* hpre, const float* w2t, const float* w1t, float* dhp, float* dx, float* colpart,
+                        void* workspace, int M, int dim, int hidden, int precision, int io_bf16, const float* ln_x,
+                        const float* ln_gamma, const float* ln_mean, const float* ln_rstd, float* ln_part, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Training-time augmentation of a resident batch (RGBDAugmentor, src/data_readers/augmentation.py:7-37):

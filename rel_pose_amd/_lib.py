@@ -150,6 +150,8 @@ _SIGS = {
     "rp_mlp_fused_bwd_workspace_bytes": (ctypes.c_size_t, [I]),
     "rp_mlp_fused_bwd_tile_rows": (c_int, []),
     "rp_mlp_fused_bwd": (c_int, [P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
+    "rp_mlp_fused_bwd_ln_part_rows": (c_int, [I]),
+    "rp_mlp_fused_bwd_ln": (c_int, [P, P, P, P, P, P, P, P, I, I, I, I, I, P, P, P, P, P, P]),
     "rp_augment_blocks": (c_int, []),
     "rp_augment_pairs": (c_int, [P, P, P, P, I, I, I, I, I, P]),
     "rp_essential_from_pose": (c_int, [P, P, I, P]),

@@ -54,7 +54,14 @@ struct MlpP {
   // MODE 0, TRAIN: what the backward needs, written on the way (all [M, .] fp32): the normalised rows and their statistics, the fc1
   // pre-activation (dhp doubles as its pointer) and the hidden activation
   float *xn_out, *mean_out, *rstd_out, *h_out;
+  // MODE 1, optional (ln_x != nullptr): the backward of the LayerNorm in front of fc1 rides on the epilogue --
+  //     y = rstd (g - mean_c(g) - xhat mean_c(g xhat)) + dy,   g = dxn o gamma,  xhat = (ln_x - mean) rstd       (dxn never reaches HBM)
+  // and ln_part [tiles * LN_SUB][3 C] receives the column sums of (dxn o xhat | dxn | dy) over each row block: dgamma, dbeta and the
+  // bias gradient of the Linear that produced dy (rp_layernorm_bwd's contract, reference Block.forward :353)
+  const float *ln_x, *ln_gamma, *ln_mean, *ln_rstd;
+  float* ln_part;
 };
+constexpr int LN_SUB = 4;      // partial-sum rows per row tile (a finished tile fills row 0 and zeroes the rest; the fix-up fills all)
 
 RP_DEV void item_range(const MlpP& p, int b, int& start, int& count) {
   start = b * p.base + min(b, p.rem);
@@ -96,6 +103,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
   // CU, measured with tools/lab/rows_probe); MODE 1: per-wave column sums of a chunk
   // (BF: + all of b1 for MODE 0 -- LDS is not what limits a 12-wave workgroup; MODE 1: two parities of the per-wave sums)
   __shared__ __attribute__((aligned(16))) float b1s[MODE == 0 ? (BF ? 3 * C + HID : 3 * C) : (BF ? 2 : 1) * NW * CH];
+  __shared__ __attribute__((aligned(16))) float lnred[MODE == 1 ? NW * 3 * C : 1];      // per-wave column sums of the LayerNorm backward
   if (MODE == 0) {
     for (int i = threadIdx.x; i < C; i += NW * 64) {
       b1s[i] = p.gamma[i];
@@ -474,7 +482,65 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
       }
     }
     // ---- epilogue: lane (j, q) holds Y[row j][16 ob + 4q + 0..3]
-    if (c0 == 0 && c1 == NCHUNK) {
+    if (MODE == 1 && p.ln_x && c0 == 0 && c1 == NCHUNK) {
+      // LayerNorm backward on the accumulators: lane (j, q) holds dxn[row j][16 ob + 4 q + 0..3]; a row's 192 columns are 48 values in
+      // each of its four lanes (q).  Two passes over the row of x (the second hits L1 / L2) keep the live registers at the
+      // accumulators' 48: the workgroup runs at three waves per SIMD.
+      const long long rc = min(row, p.M - 1);
+      const float* xr = p.ln_x + rc * C + 4 * q;
+      const float* ar = p.x + rc * C + 4 * q;                 // the residual-branch gradient IS this kernel's dy
+      const float* gr = p.ln_gamma + 4 * q;
+      const float mu = p.ln_mean[rc], rs = p.ln_rstd[rc];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int ob = 0; ob < 12; ++ob) {
+        const float4 xv = ld4(xr + 16 * ob), gv = ld4(gr + 16 * ob);
+        const float xa[4] = {xv.x, xv.y, xv.z, xv.w}, ga[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float g = acc[ob][r] * ga[r];
+          s1 += g;
+          s2 = fmaf(g, (xa[r] - mu) * rs, s2);
+        }
+      }
+      s1 += __shfl_xor(s1, 16, 64);
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 16, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      const float m1 = s1 * (1.0f / C), m2 = s2 * (1.0f / C);
+      float* lr = lnred + wave * 3 * C + 4 * q;
+#pragma unroll
+      for (int ob = 0; ob < 12; ++ob) {
+        const float4 xv = ld4(xr + 16 * ob), gv = ld4(gr + 16 * ob), av = ld4(ar + 16 * ob);
+        const float xa[4] = {xv.x, xv.y, xv.z, xv.w}, ga[4] = {gv.x, gv.y, gv.z, gv.w}, aa[4] = {av.x, av.y, av.z, av.w};
+        float o[4], t0[4], t1[4], t2[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float xh = (xa[r] - mu) * rs, d = acc[ob][r];
+          o[r] = rs * (d * ga[r] - m1 - xh * m2) + aa[r];
+          t0[r] = row16_sum(live ? d * xh : 0.f);
+          t1[r] = row16_sum(live ? d : 0.f);
+          t2[r] = row16_sum(live ? aa[r] : 0.f);
+        }
+        if (live) st4(p.y + (long long)row * C + 16 * ob + 4 * q, make_float4(o[0], o[1], o[2], o[3]));
+        if (j == 0) {
+          st4(lr + 16 * ob, make_float4(t0[0], t0[1], t0[2], t0[3]));
+          st4(lr + C + 16 * ob, make_float4(t1[0], t1[1], t1[2], t1[3]));
+          st4(lr + 2 * C + 16 * ob, make_float4(t2[0], t2[1], t2[2], t2[3]));
+        }
+      }
+      __syncthreads();
+      for (int i = tid; i < 3 * C; i += NT) {                 // waves in order: fixed summation order
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) sum += lnred[w * 3 * C + i];
+        float* dst = p.ln_part + (long long)tile * LN_SUB * 3 * C + i;
+        dst[0] = sum;
+#pragma unroll
+        for (int u = 1; u < LN_SUB; ++u) dst[u * 3 * C] = 0.f;
+      }
+      __syncthreads();                                        // lnred is reused by the next tile
+    } else if (c0 == 0 && c1 == NCHUNK) {
       if (live) {
         float* yr = p.y + (long long)row * C + 4 * q;
         // ALL residual loads first, then the stores: y may alias x for the compiler, so "load, add, store" per block came out as twelve
@@ -533,6 +599,75 @@ __global__ __launch_bounds__(256) void mlp_fixup_kernel(MlpP p, int G) {
   st4(p.y + row * C + col, make_float4(a.x + bv.x + xv.x, a.y + bv.y + xv.y, a.z + bv.z + xv.z, a.w + bv.w + xv.w));
 }
 
+// The same for the backward with the LayerNorm folded in (MlpP::ln_x): block (sub, tile) sums the partials of ROWS / LN_SUB rows of
+// a tile that no single workgroup finished and applies the LayerNorm backward to them -- a wave per row, lane = columns lane + 64 j,
+// arithmetic of ln_bwd_kernel (rowwise.hip) -- and writes the row block's column sums to ln_part[tile * LN_SUB + sub].
+template <int ROWS>
+__global__ __launch_bounds__(256) void mlp_fixup_ln_kernel(MlpP p, int G) {
+  constexpr int J = C / 64, RB = ROWS / LN_SUB;
+  static_assert(ROWS % (4 * LN_SUB) == 0, "row blocks are split over four waves");
+  __shared__ float red[3][4][C];
+  const int tile = blockIdx.y, sub = blockIdx.x;
+  const int first = tile * NCHUNK, last = first + NCHUNK - 1;
+  auto owner = [&](int item) {
+    const int big = p.rem * (p.base + 1);
+    return item < big ? item / (p.base + 1) : p.rem + (item - big) / p.base;
+  };
+  const int w0 = owner(first), w1 = owner(last);
+  if (w0 == w1) return;                                          // finished (and its partial sums written) by its owner
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float g[J], dg[J], db[J], da[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    g[j] = p.ln_gamma[lane + 64 * j];
+    dg[j] = db[j] = da[j] = 0.f;
+  }
+  for (int rr = 0; rr < RB / 4; ++rr) {
+    const int rt = sub * RB + wave * (RB / 4) + rr;              // row of the tile
+    const long long row = (long long)tile * ROWS + rt;
+    if (row >= p.M) break;
+    float d[J] = {};
+    for (int w = w0; w <= w1; ++w) {
+      int st, cn;
+      item_range(p, w, st, cn);
+      const int seg = tile - st / NCHUNK;
+      const float* src = p.part + (((long long)w * p.P + seg) * ROWS + rt) * C + lane;
+#pragma unroll
+      for (int j = 0; j < J; ++j) d[j] += src[64 * j];
+    }
+    const float mu = p.ln_mean[row], rs = p.ln_rstd[row];
+    float xh[J], dxh[J], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      xh[j] = (p.ln_x[row * C + lane + 64 * j] - mu) * rs;
+      dxh[j] = d[j] * g[j];
+      s1 += dxh[j];
+      s2 += dxh[j] * xh[j];
+      dg[j] += d[j] * xh[j];
+      db[j] += d[j];
+    }
+    const float m1 = wave_sum(s1) * (1.0f / C), m2 = wave_sum(s2) * (1.0f / C);
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const float a = p.x[row * C + lane + 64 * j];
+      da[j] += a;
+      p.y[row * C + lane + 64 * j] = rs * (dxh[j] - m1 - xh[j] * m2) + a;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    red[0][wave][lane + 64 * j] = dg[j];
+    red[1][wave][lane + 64 * j] = db[j];
+    red[2][wave][lane + 64 * j] = da[j];
+  }
+  __syncthreads();
+  float* dst = p.ln_part + ((long long)tile * LN_SUB + sub) * 3 * C;
+  for (int i = threadIdx.x; i < 3 * C; i += 256) {
+    const int k = i / C, c = i % C;
+    dst[i] = red[k][0][c] + red[k][1][c] + red[k][2][c] + red[k][3][c];
+  }
+}
+
 // NW waves per workgroup (16 rows each), WPS waves per SIMD the register allocation is held to
 template <int NW, int WPS, int MODE, bool BF = false, bool TRAIN = false>
 struct Variant {
@@ -568,7 +703,8 @@ struct Variant {
     hipLaunchKernelGGL((mlp_fused_kernel<NW, WPS, MODE, BF, TRAIN>), dim3(G), dim3(NW * 64), 0, st, p);
     RP_CHECK_LAUNCH();
     if (p.rem != 0 || p.base % NCHUNK != 0) {                     // some tile is shared between workgroups
-      hipLaunchKernelGGL((mlp_fixup_kernel<ROWS, MODE>), dim3((ROWS * C / 4 + 255) / 256, p.tiles), dim3(256), 0, st, p, G);
+      if (MODE == 1 && p.ln_x) hipLaunchKernelGGL((mlp_fixup_ln_kernel<ROWS>), dim3(LN_SUB, p.tiles), dim3(256), 0, st, p, G);
+      else hipLaunchKernelGGL((mlp_fixup_kernel<ROWS, MODE>), dim3((ROWS * C / 4 + 255) / 256, p.tiles), dim3(256), 0, st, p, G);
       RP_CHECK_LAUNCH();
     }
     return RP_OK;
@@ -641,6 +777,23 @@ extern "C" size_t rp_mlp_fused_bwd_workspace_bytes(int M) {
   return mlp_bwd_variant() == 1 ? Variant<8, 2, 1>::workspace(M) : Variant<12, 3, 1>::workspace(M);
 }
 extern "C" int rp_mlp_fused_bwd_tile_rows(void) { return mlp_bwd_variant() == 1 ? Variant<8, 2, 1>::ROWS : Variant<12, 3, 1>::ROWS; }
+extern "C" int rp_mlp_fused_bwd_ln_part_rows(int M) { return M <= 0 ? 0 : (M + rp_mlp_fused_bwd_tile_rows() - 1) / rp_mlp_fused_bwd_tile_rows() * LN_SUB; }
+static int mlp_bwd_launch(MlpP p, int precision, hipStream_t st) {
+  if (precision == 1) return Variant<12, 3, 1, true>::launch(p, st);      // (same 192-row tiles: same workspace / tile rows)
+  return mlp_bwd_variant() == 1 ? Variant<8, 2, 1>::launch(p, st) : Variant<12, 3, 1>::launch(p, st);
+}
+extern "C" int rp_mlp_fused_bwd_ln(const float* dy, const float* hpre, const float* w2t, const float* w1t, float* dhp, float* dx,
+                                   float* colpart, void* workspace, int M, int dim, int hidden, int precision, int io_bf16,
+                                   const float* ln_x, const float* ln_gamma, const float* ln_mean, const float* ln_rstd, float* ln_part,
+                                   void* stream) {
+  if (M <= 0 || dim != C || hidden != HID || !dy || !hpre || !w2t || !w1t || !dhp || !dx || !colpart || !workspace || !ln_x ||
+      !ln_gamma || !ln_mean || !ln_rstd || !ln_part || dx == dy)
+    return RP_EBADSHAPE;
+  if ((precision != 0 && precision != 1) || (io_bf16 && (precision != 1 || (io_bf16 & ~22)))) return RP_EUNSUPPORTED;
+  MlpP p{dy, nullptr, nullptr, w2t, nullptr, w1t, nullptr, dx, hpre, dhp, colpart, (float*)workspace, M, 0.f, 0, 0, 0, 0, io_bf16,
+         nullptr, nullptr, nullptr, nullptr, ln_x, ln_gamma, ln_mean, ln_rstd, ln_part};
+  return mlp_bwd_launch(p, precision, (hipStream_t)stream);
+}
 extern "C" int rp_mlp_fused_bwd(const float* dy, const float* hpre, const float* w2t, const float* w1t, float* dhp, float* dxn,
                                 float* colpart, void* workspace, int M, int dim, int hidden, int precision, int io_bf16, void* stream) {
   if (M <= 0 || dim != C || hidden != HID || !dy || !hpre || !w2t || !w1t || !dhp || !dxn || !colpart || !workspace)

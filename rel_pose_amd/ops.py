@@ -1272,6 +1272,10 @@ def mlp_fused(x2d, gamma, beta, w1, b1, w2, b2, eps=LN_EPS, train=False, out_dty
 
 
 FUSE_MLP_BWD = os.environ.get("RP_FUSE_MLP_BWD", "1") != "0"
+# the LayerNorm backward in front of fc1 on the epilogue of rp_mlp_fused_bwd (rp_mlp_fused_bwd_ln): dxn never reaches HBM.  1 = in the
+# bf16 configuration (HBM-bound there: 19.67 -> 19.48 ms per 128 pairs), 2 = also with exact fp32 operands, where the kernel is
+# matrix-bound, every workgroup's epilogue burst lands at the same moment and the fold LOSES 8 us per Block (profiles/r5_ab_mlp_bwd_ln.txt)
+MLP_BWD_LN = int(os.environ.get("RP_MLP_BWD_LN", "1"))
 
 
 _UNIT_PERM = {}
@@ -1314,8 +1318,10 @@ def _mlp_bwd_bf16_weights(w1, w2):
     return bf16_weight(transposed(w2)), _chunk_permuted_bf16(w1, transpose=True)
 
 
-def mlp_fused_bwd(dy, hpre, w1, w2, out_dtype=None):
+def mlp_fused_bwd(dy, hpre, w1, w2, out_dtype=None, ln=None):
     """(dhp, dxn, db1_partials) of the MLP backward-data chain (rp_mlp_fused_bwd): dhp = (dy W2) o GELU'(hpre), dxn = dhp W1.
+    ln = (x, gamma, mean, rstd) of the LayerNorm in front of fc1: its backward rides on the epilogue (rp_mlp_fused_bwd_ln) and the
+    result is (dhp, (dx, dgamma, dbeta, colsum(dy)), db1_partials) with dx = layernorm_bwd(dxn, ...) + dy -- layernorm_bwd's tuple.
     w1 [768,192], w2 [192,768] as stored by nn.Linear (transposed here: 2 x 590 KB); db1_partials [tiles,768] column-sums to db1.
     At operand precision 1 (the bf16 configuration) the products run on the bf16 MFMA from bf16 weight copies; hpre may then be a bf16
     tensor and out_dtype=torch.bfloat16 stores dhp as bf16."""
@@ -1340,6 +1346,16 @@ def mlp_fused_bwd(dy, hpre, w1, w2, out_dtype=None):
     ws = _mlp_ws.get(key)
     if ws is None:
         ws = _mlp_ws[key] = torch.empty(max(1, lib.rp_mlp_fused_bwd_workspace_bytes(M)) // 4 + 1, device=dy.device, dtype=torch.float32)
+    if ln is not None:
+        x, gamma, mean, rstd = ln
+        _chk(x, gamma, mean, rstd)
+        C = dy.shape[1]
+        lnpart = _empty(lib.rp_mlp_fused_bwd_ln_part_rows(M), 3 * C, like=dy)
+        _lib.check(lib.rp_mlp_fused_bwd_ln(_p(dy), _p(hpre), _p(w2t), _p(w1t), _p(dhp), _p(dxn), _p(colpart), _p(ws), M, C,
+                                           hpre.shape[1], 1 if bf else 0, io, _p(x), _p(gamma), _p(mean), _p(rstd), _p(lnpart), _st()),
+                   "rp_mlp_fused_bwd_ln")
+        sums = colsum(lnpart)
+        return dhp, (dxn, sums[:C], sums[C:2 * C], sums[2 * C:]), colpart
     _lib.check(lib.rp_mlp_fused_bwd(_p(dy), _p(hpre), _p(w2t), _p(w1t), _p(dhp), _p(dxn), _p(colpart), _p(ws), M, dy.shape[1],
                                     hpre.shape[1], 1 if bf else 0, io, _st()), "rp_mlp_fused_bwd")
     return dhp, dxn, colpart
@@ -1392,11 +1408,13 @@ def _mlp_bwd(fork, dy, xn, h, hpre, w1, w2, want_db2=True, ln=None):
     if (FUSE_MLP_BWD and GEMM_PRECISION in (0, 1) and dy.shape[1] == DIM and tuple(w1.shape) == (4 * DIM, DIM)
             and tuple(w2.shape) == (DIM, 4 * DIM) and dy.dtype == torch.float32):
         # both input-gradient products as one kernel (dh stays on chip); fc1 bias gradient from its per-tile column sums
-        dh, dxn, part = mlp_fused_bwd(dy, hpre, w1, w2, out_dtype=torch.bfloat16 if hpre.dtype == torch.bfloat16 else None)
+        odt = torch.bfloat16 if hpre.dtype == torch.bfloat16 else None
+        fold = ln is not None and ln[4] is dy and MLP_BWD_LN >= (1 if GEMM_PRECISION == 1 else 2)      # (a Block's residual-branch gradient IS the MLP's dy)
+        dh, dxn, part = mlp_fused_bwd(dy, hpre, w1, w2, out_dtype=odt, ln=ln[:4] if fold else None)
         db1 = colsum(part)
         fork.sync_side()
         dw1 = fork.on_side(lambda: linear_dw(dh, xn))
-        if ln is not None:
+        if ln is not None and not fold:
             x_, gamma_, mean_, rstd_, add_ = ln
             return layernorm_bwd(dxn, x_, gamma_, mean_, rstd_, add=add_), dw1, db1, dw2, db2
         return dxn, dw1, db1, dw2, db2
@@ -1515,8 +1533,8 @@ class CrossBlockFn(_Fn):
         dy = dy.contiguous().view(Z * 70, DIM)
         fork = _Fork(dy.device)
         with colsum_batch(), splitk_batch():
-            dfn, dfc1w, dfc1b, dfc2w, _ = _mlp_bwd(fork, dy, fn, h, hpre, fc1_w, fc2_w, want_db2=False)
-            df_, dn2w, dn2b, dfc2b = layernorm_bwd(dfn, f, n2w, m2, r2, add=dy)       # 4th: colsum(dy) = fc2 bias gradient
+            (df_, dn2w, dn2b, dfc2b), dfc1w, dfc1b, dfc2w, _ = _mlp_bwd(fork, dy, fn, h, hpre, fc1_w, fc2_w, want_db2=False,
+                                                                         ln=(f, n2w, m2, r2, dy))       # 4th: colsum(dy) = fc2 bias gradient
             fork.sync_side()
             dpfw_full, dpfb = _param_grads(fork, df_, g)
             dg = linear_dx(df_, pf_wp)                                      # [Z*70, 224]

@@ -1270,6 +1270,43 @@ def test_fused_mlp_forward_bf16_configuration(ops, M):
         ops.mlp_fused(x, g, b, w1, b1, w2, b2, train=True, out_dtype=bf)          # bf16 storage only in the bf16 configuration
 
 
+@pytest.mark.parametrize("precision", [0, 1])
+@pytest.mark.parametrize("M", [140, 1152, 9216 + 48, 73728])
+def test_fused_mlp_backward_with_layernorm_backward_folded_in(ops, M, precision):
+    """rp_mlp_fused_bwd_ln: the backward of norm2 (Block.forward, vision_transformer.py:353: x + mlp(norm2(x))) on the epilogue of the fused
+    MLP backward -- dx = LayerNorm-backward(dxn) + dy, with dgamma / dbeta / colsum(dy) from per-row-block partial sums.  Reference: fp64
+    LayerNorm backward of the dxn the SAME kernel writes without the fold (checked against autograd by the tests above), so the bound is
+    fp32 rounding (3e-6 of the maximum) in both operand precisions.  The sizes cover tiles finished by one workgroup (epilogue form),
+    tiles shared between workgroups (fix-up form: all of M = 1152, a third of 73 728) and a ragged last tile.  Deterministic."""
+    bf = torch.bfloat16
+    q = (lambda t: t.to(bf).float()) if precision else (lambda t: t)
+    w1 = q(rnd(768, 192, seed=4, scale=192 ** -0.5))
+    w2 = q(rnd(192, 768, seed=6, scale=768 ** -0.5))
+    dy = q(rnd(M, 192, seed=9))
+    hp = q(rnd(M, 768, seed=8, scale=1.5))
+    x = rnd(M, 192, seed=10) * 2.0 + 0.3
+    gamma = 1.0 + 0.2 * rnd(192, seed=11)
+    mean = x.mean(1).contiguous()
+    rstd = (x.var(1, unbiased=False) + 1e-6).rsqrt().contiguous()
+    prev = ops.GEMM_PRECISION
+    ops.set_gemm_precision(precision)
+    try:
+        dhp0, dxn, part0 = ops.mlp_fused_bwd(dy, hp, w1, w2)
+        dhp, (dx, dg, db, da), part = ops.mlp_fused_bwd(dy, hp, w1, w2, ln=(x, gamma, mean, rstd))
+        dhp2, (dx2, dg2, db2, da2), part2 = ops.mlp_fused_bwd(dy, hp, w1, w2, ln=(x, gamma, mean, rstd))
+    finally:
+        ops.set_gemm_precision(prev)
+    assert torch.equal(dhp, dhp0) and torch.equal(part, part0)                      # the rest of the kernel is untouched
+    assert all(torch.equal(a, b) for a, b in ((dx, dx2), (dg, dg2), (db, db2), (da, da2), (dhp, dhp2)))
+    d = dxn.double()
+    xh = (x.double() - mean.double()[:, None]) * rstd.double()[:, None]
+    g = d * gamma.double()
+    ref = rstd.double()[:, None] * (g - g.mean(1, keepdim=True) - xh * (g * xh).mean(1, keepdim=True)) + dy.double()
+    e = dict(dx=rel(dx, ref), dgamma=rel(dg, (d * xh).sum(0)), dbeta=rel(db, d.sum(0)), colsum_dy=rel(da, dy.double().sum(0)))
+    report("mlp_fused_bwd_ln_M%d_p%d" % (M, precision), **e)
+    assert max(e.values()) < 3e-6, e
+
+
 @pytest.mark.parametrize("M", [140, 9216 + 48])
 def test_fused_mlp_backward_bf16_configuration(ops, M):
     """rp_mlp_fused_bwd at operand precision 1 (v_mfma_f32_16x16x32_bf16 from bf16 weight copies, the second one in the kernel's

@@ -358,6 +358,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dkdv_kernel(AttnBwdP p)
   __shared__ __attribute__((aligned(16))) float Qs[2][32 * KST];
   __shared__ __attribute__((aligned(16))) float Ds[2][32 * KST];
   __shared__ __attribute__((aligned(16))) float Ls[2][64];   // [0..31] lse, [32..63] delta of the query tile
+  __shared__ __attribute__((aligned(16))) float Tst[BF ? 1 : NW][BF ? 4 : 512];      // per-wave staging of the stored dS tile (store_acc_image_lds)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   int zh, qblk;
   if (!xcd_problem(NTILE / NW, p.ZH, zh, qblk)) return;
@@ -421,7 +422,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dkdv_kernel(AttnBwdP p)
       // coalesced 256-byte stores; rp_ds_matmul (below) reads it -- the dQ pass then needs neither S nor dP again
       const long long tile = (((long long)zq * p.H + h) * NTILE + t) * NTILE + (k0 >> 5);
       if (BF) store_acc_image_bf16(reinterpret_cast<unsigned short*>(p.ds) + tile * 1024, dp, p.scale, lane);   // bf16 operands downstream: bf16 tiles
-      else store_acc_image(p.ds + tile * 1024, dp, p.scale, lane);
+      else store_acc_image_lds(p.ds + tile * 1024, Tst[BF ? 0 : wave], dp, p.scale, lane);
     }
     STAMP(4)
     accum_tile<KST, BF>(Ds[cur], l31, hi, s, dv0, dv1);     // dV^T += dO^T P

@@ -13,6 +13,7 @@
 //   * per 2-row k-step a wave issues 6 ds_read_b32 for 9 MFMAs (576 matrix-pipe cycles): LDS and issue bandwidth are idle, one barrier
 //     per 144 MFMAs;
 //   * split-K slabs in rp_gemm's workspace layout, finished by the same fixed-order reduce (rp_splitk_reduce_multi): deterministic.
+#include <type_traits>
 #include "common.h"
 #include "../../include/relpose_hip.h"
 
@@ -22,6 +23,17 @@ RP_DEV void glds16f(const void* sbase, unsigned voff, unsigned lds_byte_addr) {
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(lds_byte_addr), "s"(sbase) : "memory");
+}
+template <int OFF> RP_DEV float lds_rd32(unsigned addr) {
+  float v;
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <int N, class F> RP_DEV void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
 }
 RP_DEV const void* uniform_vpf(const void* p) {
   const unsigned long long v = (unsigned long long)p;
@@ -91,40 +103,42 @@ __global__ __launch_bounds__(256, 1) void dw192_f32_kernel(DwF p) {
     const void* sa = uniform_vpf(ab + (long long)sn * SR * p.lda);
     const void* sb = uniform_vpf(bb + (long long)sn * SR * W);
     const unsigned an0 = as0 + (buf ^ 1) * (ST_FL * 4), bn0 = bs0 + (buf ^ 1) * (ST_FL * 4);
-    const float* At = As[buf] + ao;
-    const float* Bt = Bs[buf] + bo;
-    // operands of k-step t + 1 are read while the nine MFMAs of step t run (one wave per SIMD: nobody else hides the LDS latency)
+    // Operands of k-step t + 1 are read while the nine MFMAs of step t run (one wave per SIMD: nobody else hides the LDS latency), as
+    // ds_read_b32 with the step's offset as an IMMEDIATE: hipcc's ds_read2_b32 pairs need a fresh base register per step (8-bit offsets),
+    // 32 v_add_u32 per stage, and next to an fp32 MFMA a VALU instruction costs its issue time while an LDS instruction is free
+    // (profiles/r5_shadow_lab.txt).  The asm reads are invisible to the compiler's counters: the wait is written out, with the six
+    // registers passed through it.
+    const unsigned at = (unsigned)(size_t)(rp_lds_ptr_t)(As[buf] + ao), bt = (unsigned)(size_t)(rp_lds_ptr_t)(Bs[buf] + bo);
     float af[3], bf[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      af[i] = At[32 * i];
-      bf[i] = Bt[32 * i];
-    }
-#pragma unroll
-    for (int t = 0; t < SR / 2; ++t) {
+    static_for<3>([&](auto i) {
+      af[i] = lds_rd32<128 * i>(at);
+      bf[i] = lds_rd32<128 * i>(bt);
+    });
+    static_for<SR / 2>([&](auto tt) {
+      constexpr int t = tt;
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]));
       float an[3], bn[3];
-      if (t + 1 < SR / 2) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          an[i] = At[2 * (t + 1) * W + 32 * i];
-          bn[i] = Bt[2 * (t + 1) * W + 32 * i];
-        }
+      if constexpr (t + 1 < SR / 2) {
+        static_for<3>([&](auto i) {
+          an[i] = lds_rd32<(2 * (t + 1) * W + 32 * i) * 4>(at);
+          bn[i] = lds_rd32<(2 * (t + 1) * W + 32 * i) * 4>(bt);
+        });
       }
-      if (t < 6) glds16f(sa, aoff[t], an0 + t * 4096);
-      else if (t < 12) glds16f(sb, boff[t - 6], bn0 + (t - 6) * 4096);
+      if (t < 6) glds16f(sa, aoff[t < 6 ? t : 0], an0 + t * 4096);
+      else if (t < 12) glds16f(sb, boff[t >= 6 && t < 12 ? t - 6 : 0], bn0 + (t - 6) * 4096);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
-      if (t + 1 < SR / 2) {
+      if constexpr (t + 1 < SR / 2) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
           af[i] = an[i];
           bf[i] = bn[i];
         }
       }
-    }
+    });
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }

@@ -253,6 +253,7 @@ __global__ __launch_bounds__(GT, 2) void emm_grad_kernel(EmmP p) {
   __shared__ __attribute__((aligned(16))) float Ks[2][32 * KST];
   __shared__ __attribute__((aligned(16))) float Xs[2][32 * XGS];
   __shared__ float Ll[2][64];   // loop-side lse [0..31] and rho/gamma [32..63]
+  __shared__ __attribute__((aligned(16))) float Tst[BF ? 1 : GW][BF ? 4 : 256];      // per-wave staging of the stored dS tile (1 KB: four workgroups per CU stay)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   int zh_, wgi;
   if (!xcd_problem(NTILE / GW, p.ZH, zh_, wgi)) return;
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(GT, 2) void emm_grad_kernel(EmmP p) {
       // 4 KB contiguous, rows = loop index j, columns = owners i: fully coalesced 256-byte stores; rp_ds_matmul reads it (attention.hip)
       const long long tile = (zh * (NTOK / 32) + t) * (NTOK / 32) + (o0 >> 5);
       if (BF) store_acc_image_bf16(reinterpret_cast<unsigned short*>(p.ds) + tile * 1024, s, p.scale, lane);
-      else store_acc_image(p.ds + tile * 1024, s, p.scale, lane);
+      else store_acc_image_lds<4>(p.ds + tile * 1024, Tst[BF ? 0 : wave], s, p.scale, lane);
     }
     // d owner^T[d][owner] += sum_loop other[loop][d] dS^T[loop][owner]
     if (BF) {

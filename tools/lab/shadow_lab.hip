@@ -18,7 +18,8 @@ template <int KIND> __device__ __forceinline__ void other(float& x, float& y, co
   if (KIND == 5) asm volatile("s_nop 0");
 }
 
-template <int KIND, int K>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+template <int KIND, int K, int MF = 0>      // MF 0: v_mfma_f32_32x32x2_f32 (64 cycles)   1: v_mfma_f32_32x32x16_bf16 (32 cycles)
 __global__ __launch_bounds__(256, 1) void shadow(const float* src, float* out, long long* clk, int iters) {
   __shared__ float lds[1024];
   lds[threadIdx.x] = src[threadIdx.x];
@@ -28,13 +29,16 @@ __global__ __launch_bounds__(256, 1) void shadow(const float* src, float* out, l
   for (int i = 0; i < 16; ++i) x[i] = src[(threadIdx.x + i) & 4095];
   f32x16 c[4];
   for (int n = 0; n < 4; ++n) for (int i = 0; i < 16; ++i) c[n][i] = 0.f;
+  bf16x8 xa[2];
+  for (int q = 0; q < 2; ++q) for (int i = 0; i < 8; ++i) xa[q][i] = (__bf16)a[(i + q) & 3];
   const long long c0 = __builtin_readcyclecounter();
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
-        asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(c[n]) : "v"(a[t]), "v"(b[(t + n) & 3]));
+        if (MF == 0) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(c[n]) : "v"(a[t]), "v"(b[(t + n) & 3]));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c[n]) : "v"(xa[t & 1]), "v"(xa[(t + n) & 1]));
 #pragma unroll
         for (int k = 0; k < K; ++k) other<KIND>(x[(4 * t + n + k) & 15], y, lds + (threadIdx.x & 255));
       }
@@ -48,17 +52,17 @@ __global__ __launch_bounds__(256, 1) void shadow(const float* src, float* out, l
   if (threadIdx.x == 0) clk[blockIdx.x] = c1 - c0;
 }
 
-template <int KIND, int K> void run(const char* name, const float* src, float* out, long long* clk) {
+template <int KIND, int K, int MF = 0> void run(const char* name, const float* src, float* out, long long* clk) {
   const int wgs = 256, iters = 4000;
-  hipLaunchKernelGGL((shadow<KIND, K>), dim3(wgs), dim3(256), 0, 0, src, out, clk, iters);
+  hipLaunchKernelGGL((shadow<KIND, K, MF>), dim3(wgs), dim3(256), 0, 0, src, out, clk, iters);
   CK(hipDeviceSynchronize());
-  hipLaunchKernelGGL((shadow<KIND, K>), dim3(wgs), dim3(256), 0, 0, src, out, clk, iters);
+  hipLaunchKernelGGL((shadow<KIND, K, MF>), dim3(wgs), dim3(256), 0, 0, src, out, clk, iters);
   CK(hipDeviceSynchronize());
   std::vector<long long> hc(wgs);
   CK(hipMemcpy(hc.data(), clk, wgs * 8, hipMemcpyDeviceToHost));
   double cyc = 0;
   for (auto v : hc) cyc += v;
-  printf("%-14s K = %2d : %6.1f cycles per MFMA\n", name, K, cyc / wgs / (iters * 16.0));
+  printf("%-22s %-14s K = %2d : %6.1f cycles per MFMA\n", MF ? "32x32x16_bf16" : "32x32x2_f32", name, K, cyc / wgs / (iters * 16.0));
 }
 template <int KIND> void sweep(const char* name, const float* src, float* out, long long* clk) {
   run<KIND, 0>(name, src, out, clk); run<KIND, 1>(name, src, out, clk); run<KIND, 2>(name, src, out, clk); run<KIND, 4>(name, src, out, clk);
@@ -77,5 +81,9 @@ int main() {
   sweep<3>("ds_read_b32", src, out, clk);
   sweep<4>("v_cndmask", src, out, clk);
   sweep<5>("s_nop", src, out, clk);
+  run<0, 0, 1>("v_fma_f32", src, out, clk); run<0, 1, 1>("v_fma_f32", src, out, clk); run<0, 2, 1>("v_fma_f32", src, out, clk);
+  run<0, 4, 1>("v_fma_f32", src, out, clk); run<0, 8, 1>("v_fma_f32", src, out, clk); run<0, 16, 1>("v_fma_f32", src, out, clk);
+  run<1, 2, 1>("v_exp_f32", src, out, clk); run<1, 4, 1>("v_exp_f32", src, out, clk); run<1, 8, 1>("v_exp_f32", src, out, clk);
+  run<3, 2, 1>("ds_read_b32", src, out, clk); run<3, 4, 1>("ds_read_b32", src, out, clk); run<3, 8, 1>("ds_read_b32", src, out, clk);
   return 0;
 }

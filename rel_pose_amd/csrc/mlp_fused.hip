@@ -82,8 +82,11 @@ RP_DEV void item_range(const MlpP& p, int b, int& start, int& count) {
 // TRAIN (MODE 0 only): the training forward -- same kernel, but xn / mean / rstd (by the workgroup that runs a tile's first chunk), the
 // pre-activation and the hidden activation are stored for the backward (the chain then costs the MFMA time of its two products instead
 // of a LayerNorm+fc1 launch and an fc2 launch that re-reads h).
-template <int NW, int WPS, int MODE, bool BF = false, bool TRAIN = false>
+// LNB (MODE 1 only): the LayerNorm backward on the epilogue (MlpP::ln_x) -- its own instantiation, so that the plain backward keeps its
+// register allocation.
+template <int NW, int WPS, int MODE, bool BF = false, bool TRAIN = false, bool LNB = false>
 __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
+  static_assert(!LNB || MODE == 1, "the LayerNorm fold belongs to the backward");
   constexpr int NT = NW * 64, ROWS = NW * 16;
   constexpr int TILE_FL = BF ? W1T / 2 : W1T;                   // floats per staged weight tile (bf16 weights: half)
   constexpr int DMA = (TILE_FL / 4) / NT;                       // 16-byte chunks per thread per tile (3 for NW = 8)
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
   // CU, measured with tools/lab/rows_probe); MODE 1: per-wave column sums of a chunk
   // (BF: + all of b1 for MODE 0 -- LDS is not what limits a 12-wave workgroup; MODE 1: two parities of the per-wave sums)
   __shared__ __attribute__((aligned(16))) float b1s[MODE == 0 ? (BF ? 3 * C + HID : 3 * C) : (BF ? 2 : 1) * NW * CH];
-  __shared__ __attribute__((aligned(16))) float lnred[MODE == 1 ? NW * 3 * C : 1];      // per-wave column sums of the LayerNorm backward
+  __shared__ __attribute__((aligned(16))) float lnred[LNB ? NW * 3 * C : 1];      // per-wave column sums of the LayerNorm backward
   if (MODE == 0) {
     for (int i = threadIdx.x; i < C; i += NW * 64) {
       b1s[i] = p.gamma[i];
@@ -482,7 +485,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
       }
     }
     // ---- epilogue: lane (j, q) holds Y[row j][16 ob + 4q + 0..3]
-    if (MODE == 1 && p.ln_x && c0 == 0 && c1 == NCHUNK) {
+    if (LNB && c0 == 0 && c1 == NCHUNK) {
       // LayerNorm backward on the accumulators: lane (j, q) holds dxn[row j][16 ob + 4 q + 0..3]; a row's 192 columns are 48 values in
       // each of its four lanes (q).  Two passes over the row of x (the second hits L1 / L2) keep the live registers at the
       // accumulators' 48: the workgroup runs at three waves per SIMD.
@@ -700,7 +703,8 @@ struct Variant {
   }
   static int launch(MlpP p, hipStream_t st) {
     const int G = partition(p);
-    hipLaunchKernelGGL((mlp_fused_kernel<NW, WPS, MODE, BF, TRAIN>), dim3(G), dim3(NW * 64), 0, st, p);
+    if (MODE == 1 && p.ln_x) hipLaunchKernelGGL((mlp_fused_kernel<NW, WPS, MODE, BF, TRAIN, MODE == 1>), dim3(G), dim3(NW * 64), 0, st, p);
+    else hipLaunchKernelGGL((mlp_fused_kernel<NW, WPS, MODE, BF, TRAIN>), dim3(G), dim3(NW * 64), 0, st, p);
     RP_CHECK_LAUNCH();
     if (p.rem != 0 || p.base % NCHUNK != 0) {                     // some tile is shared between workgroups
       if (MODE == 1 && p.ln_x) hipLaunchKernelGGL((mlp_fixup_ln_kernel<ROWS>), dim3(LN_SUB, p.tiles), dim3(256), 0, st, p, G);

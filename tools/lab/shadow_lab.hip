@@ -16,6 +16,7 @@ template <int KIND> __device__ __forceinline__ void other(float& x, float& y, co
   if (KIND == 3) asm volatile("ds_read_b32 %0, %1" : "=v"(x) : "v"((unsigned)(size_t)lds) : "memory");
   if (KIND == 4) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x) : "v"(y));
   if (KIND == 5) asm volatile("s_nop 0");
+  if (KIND == 6) { typedef float f2 __attribute__((ext_vector_type(2))); f2 v = {x, y}; asm volatile("v_pk_fma_f32 %0, %0, %0, %0" : "+v"(v)); x = v.x; }
 }
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -81,6 +82,7 @@ int main() {
   sweep<3>("ds_read_b32", src, out, clk);
   sweep<4>("v_cndmask", src, out, clk);
   sweep<5>("s_nop", src, out, clk);
+  sweep<6>("v_pk_fma_f32", src, out, clk);
   run<0, 0, 1>("v_fma_f32", src, out, clk); run<0, 1, 1>("v_fma_f32", src, out, clk); run<0, 2, 1>("v_fma_f32", src, out, clk);
   run<0, 4, 1>("v_fma_f32", src, out, clk); run<0, 8, 1>("v_fma_f32", src, out, clk); run<0, 16, 1>("v_fma_f32", src, out, clk);
   run<1, 2, 1>("v_exp_f32", src, out, clk); run<1, 4, 1>("v_exp_f32", src, out, clk); run<1, 8, 1>("v_exp_f32", src, out, clk);

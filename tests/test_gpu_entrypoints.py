@@ -315,7 +315,7 @@ def test_bench_distributed_path_on_rccl_single_rank():
 def test_graphed_train_step_matches_the_eager_step():
     """rel_pose_amd/graph.py (bench.py --graph): the HIP-graph replay of forward + loss + backward | clip + Adam takes the same
     optimisation steps as the same functions run eagerly from the same initial state -- the losses of 4 consecutive steps agree to
-    2e-3 (measured 5e-6, 5e-6, 2e-5, 1.2e-4: the kernels are the same and deterministic, Adam on a random-init net amplifies the
+    2e-4 / 1e-3 / 5e-3 / 1e-2 (measured 5e-6, 5e-6, 2e-5, 1.2e-4: the kernels are the same and deterministic, Adam on a random-init net amplifies the
     last-bit differences of MIOpen's solver choice under capture from step to step)."""
     import copy
     import types
@@ -368,8 +368,11 @@ def test_graphed_train_step_matches_the_eager_step():
         losses[mode] = out
     assert all(l == l and l > 0 for l in losses["graph"])
     assert losses["graph"][-1] != losses["graph"][0]                      # the replayed optimiser really moves the weights
-    for a, b in zip(losses["eager"][2:], losses["graph"]):
-        assert abs(a - b) <= 2e-3 * abs(a), losses
+    # Adam's first updates are ~lr * sign(g): a gradient whose sign flips with the rounding noise of MIOpen's atomically accumulated
+    # weight gradients moves its parameter by 2 lr, and the difference compounds step by step (one full-suite run in ~17 exceeded a flat
+    # 2e-3 on a later step).  The first replayed step is the check on the capture itself; the later ones bound the drift.
+    for k, (a, b) in enumerate(zip(losses["eager"][2:], losses["graph"])):
+        assert abs(a - b) <= (2e-4, 1e-3, 5e-3, 1e-2)[k] * abs(a), (k, losses)
 
 
 def _closed_form_checkpoint(path):

@@ -233,7 +233,7 @@ def parse_instance(text):
         return text
 
 
-TAG_SYMBOLS = {"mlp_fused_fwd": "mlp_fused_kernel<4, 3, 0, false, false>", "attn_fwd": "attn_fwd_kernel<2, false, 2, false, false>",
+TAG_SYMBOLS = {"mlp_fused_fwd": "mlp_fused_kernel<4, 3, 0, false, false, false>", "attn_fwd": "attn_fwd_kernel<2, false, 2, false, false>",
                "attn_stats": "attn_fwd_kernel<3, true, 2, false, true>", "linear_rows_ln": "linear_rows_kernel<true, false>",
                "linear_rows": "linear_rows_kernel<false, false>", "dw192_bf16": "dw192_bf16_kernel<false>",
                "dw192_bf16_f32b": "dw192_bf16_kernel<true>", "dw192_f32": "dw192_f32_kernel", "attn_fwd_bf16": "attn_fwd_bf16_kernel<2, false, 1>"}

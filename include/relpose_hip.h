@@ -36,8 +36,8 @@ extern "C" {
  * functions this header declares.  rp_abi_version() / rp_abi_export_count() return the values the library was COMPILED with, so a
  * binding (rel_pose_amd/_lib.py parses both macros and counts the declarations) rejects a stale .so at load time instead of
  * failing later on a missing symbol. */
-#define RP_ABI_VERSION 16
-#define RP_ABI_EXPORTS 96
+#define RP_ABI_VERSION 17
+#define RP_ABI_EXPORTS 99
 int rp_abi_version(void);
 int rp_abi_export_count(void);
 const char* rp_target_arch(void);
@@ -208,6 +208,15 @@ int rp_conv3x3_c64_wgrad_blocks(int N);
 size_t rp_conv3x3_c64_wgrad_workspace_bytes(int N);
 int rp_conv3x3_c64_wgrad_bf16(const void* x, const void* dy, void* dw, void* workspace, size_t workspace_bytes, int N, int H, int W,
                               void* stream);
+
+/* The same weight gradient in EXACT fp32 (the headline configuration; autograd of src/model.py:131's BasicBlock convolutions): x and dy
+ * [N,56,56,64] fp32 NHWC, dw [64][3][3][64] fp32 (= a [64,64,3,3] channels-last parameter gradient), workspace
+ * rp_conv3x3_c64_wgrad_f32_workspace_bytes(N) bytes of per-workgroup fp32 partials, summed in a fixed order (deterministic, no atomics).
+ * Output-stationary on v_mfma_f32_32x32x2_f32 (csrc/conv3x3_wgrad_f32.hip); replaces MIOpen's backward-weights call for this shape. */
+int rp_conv3x3_c64_wgrad_f32_blocks(int N);
+size_t rp_conv3x3_c64_wgrad_f32_workspace_bytes(int N);
+int rp_conv3x3_c64_wgrad_f32(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes, int N, int H, int W,
+                             void* stream);
 
 /* The stem's BatchNorm -> ReLU -> MaxPool2d(3, 2, 1) chain (src/model.py:127-130 on torchvision's resnet.bn1 / relu / maxpool) without
  * the [N,H,W,C] intermediates.  Forward (after rp_bn_stats, or with the running statistics in eval): y [N,OH,OW,C], idx = window

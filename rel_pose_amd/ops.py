@@ -1859,6 +1859,36 @@ class ConvBf16Fn(_Fn):
         return dx, dw, db, None
 
 
+# exact-fp32 configuration: the weight gradient of resnet.layer1's 3x3 convolutions on the output-stationary fp32 kernel
+# (csrc/conv3x3_wgrad_f32.hip); forward and input gradient stay MIOpen's
+CONV3X3_WGRAD_F32 = os.environ.get("RP_CONV3X3_WGRAD_F32", "1") != "0"
+
+
+class Conv3x3C64F32Fn(_Fn):
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return torch.nn.functional.conv2d(x, w, None, 1, 1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx = dw = None
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        if ctx.needs_input_grad[0]:
+            dx = torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+        if ctx.needs_input_grad[1]:
+            xr = x.permute(0, 2, 3, 1)
+            dw = conv3x3_c64_wgrad_f32(xr if xr.is_contiguous() else xr.contiguous(), dy.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
+        return dx, dw
+
+
+def conv3x3_wgrad_f32_ok(m, x):
+    return (CONV3X3_WGRAD_F32 and CNN_PRECISION == 0 and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
+            and m.weight.requires_grad and tuple(m.weight.shape) == (64, 64, 3, 3) and m.bias is None and m.stride == (1, 1)
+            and m.padding == (1, 1) and m.dilation == (1, 1) and m.groups == 1 and tuple(x.shape[1:]) == (64, 56, 56))
+
+
 def conv3x3_own_ok(m, x):
     return (CONV3X3_OWN and CNN_PRECISION == 1 and x.is_cuda and tuple(m.weight.shape) == (64, 64, 3, 3) and m.bias is None
             and m.stride == (1, 1) and m.padding == (1, 1) and m.dilation == (1, 1) and m.groups == 1 and tuple(x.shape[1:]) == (64, 56, 56))
@@ -1873,6 +1903,8 @@ def conv2d(m, x, want_stats=False):
             return Conv3x3C64Fn.apply(xb, m._rp_bf16[0], True)
         return conv2d(m, x), None
     if CNN_PRECISION == 0 or not x.is_cuda:
+        if conv3x3_wgrad_f32_ok(m, x):
+            return Conv3x3C64F32Fn.apply(x, m.weight)
         return m(x)
     bf = torch.bfloat16
     ready = getattr(m, "_rp_bf16", None)
@@ -2036,6 +2068,21 @@ def conv3x3_c64_wgrad_bf16(x_nhwc, dy_nhwc):
     ws = torch.empty(nb // 4, device=x_nhwc.device, dtype=torch.float32)
     dw = torch.empty(64, 3, 3, 64, device=x_nhwc.device, dtype=torch.bfloat16)
     _lib.check(lib.rp_conv3x3_c64_wgrad_bf16(_p(x_nhwc), _p(dy_nhwc), _p(dw), _p(ws), nb, N, 56, 56, _st()), "rp_conv3x3_c64_wgrad_bf16")
+    return dw
+
+
+def conv3x3_c64_wgrad_f32(x_nhwc, dy_nhwc):
+    """rp_conv3x3_c64_wgrad_f32: dW of y = conv3x3(x, w) (stride 1, pad 1, 64 -> 64, 56 x 56) in exact fp32 from x and dY [N,56,56,64]
+    fp32 (NHWC memory) -> [64,3,3,64] fp32 (the memory of a channels-last [64,64,3,3] weight gradient)."""
+    lib = _lib.load()
+    for t in (x_nhwc, dy_nhwc):
+        if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32 and tuple(t.shape[1:]) == (56, 56, 64)):
+            raise RuntimeError("conv3x3_c64_wgrad_f32: contiguous fp32 [N,56,56,64] GPU tensors expected")
+    N = x_nhwc.shape[0]
+    nb = lib.rp_conv3x3_c64_wgrad_f32_workspace_bytes(N)
+    ws = torch.empty(nb // 4, device=x_nhwc.device, dtype=torch.float32)
+    dw = torch.empty(64, 3, 3, 64, device=x_nhwc.device, dtype=torch.float32)
+    _lib.check(lib.rp_conv3x3_c64_wgrad_f32(_p(x_nhwc), _p(dy_nhwc), _p(dw), _p(ws), nb, N, 56, 56, _st()), "rp_conv3x3_c64_wgrad_f32")
     return dw
 
 

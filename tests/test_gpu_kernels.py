@@ -280,6 +280,45 @@ def test_conv3x3_c64_bf16_forward_fused_forms_and_backward(ops, N):
         ops.conv3x3_c64_bf16(xn.float(), wn)
 
 
+@pytest.mark.parametrize("N", [1, 3, 37, 128])
+def test_conv3x3_c64_weight_gradient_exact_fp32(ops, N):
+    """rp_conv3x3_c64_wgrad_f32 (csrc/conv3x3_wgrad_f32.hip: the weight gradient of resnet.layer1's 3x3 / 64 -> 64 convolutions in the
+    exact-fp32 configuration, autograd of src/model.py:131) against fp64 autograd of F.conv2d over ALL images (N <= 37) / against
+    MIOpen's fp32 backward-weights (N = 128, the headline size): 3e-6 of the maximum (fp32 accumulation of up to 400 k exact products per
+    element, in workgroup partials summed in a fixed order) / 2e-5 between the two fp32 results.  N = 1 / 3 / 37: fewer image rows than
+    workgroup slots, runs that start and end inside an image (every edge case of the row ring: first / last row of an image in the
+    prologue, in the steady state and at a workgroup boundary).  Deterministic; ops.Conv3x3C64F32Fn (MIOpen forward and input gradient,
+    this weight gradient) against plain autograd of the module."""
+    import torch.nn.functional as F
+    CL = torch.channels_last
+    x = rnd(N, 64, 56, 56, seed=1).contiguous(memory_format=CL)
+    w = rnd(64, 64, 3, 3, seed=2, scale=(64 * 9) ** -0.5).contiguous(memory_format=CL)
+    dy = rnd(N, 64, 56, 56, seed=5).contiguous(memory_format=CL)
+    dw = ops.conv3x3_c64_wgrad_f32(x.permute(0, 2, 3, 1), dy.permute(0, 2, 3, 1))
+    assert torch.equal(dw, ops.conv3x3_c64_wgrad_f32(x.permute(0, 2, 3, 1), dy.permute(0, 2, 3, 1)))        # deterministic
+    if N <= 37:
+        w64 = w.double().requires_grad_(True)
+        F.conv2d(x.double(), w64, None, 1, 1).backward(dy.double())
+        e = rel(dw.permute(0, 3, 1, 2), w64.grad)
+        bound = 3e-6
+    else:
+        ref = torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+        e = rel(dw.permute(0, 3, 1, 2), ref.double())
+        bound = 2e-5
+    x1, w1 = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y1 = ops.Conv3x3C64F32Fn.apply(x1, w1)
+    y1.backward(dy)
+    x2, w2 = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y2 = F.conv2d(x2, w2, None, 1, 1)
+    y2.backward(dy)
+    e_fn = dict(y=rel(y1, y2.double()), dx=rel(x1.grad, x2.grad.double()), dw=rel(w1.grad, w2.grad.double()))
+    report("conv3x3_c64_wgrad_f32[N=%d]" % N, dw=e, **{"fn_" + k: v for k, v in e_fn.items()})
+    assert e < bound and e_fn["y"] == 0.0 and e_fn["dx"] < 1e-6 and e_fn["dw"] < 2e-5, (e, e_fn)
+    assert w1.grad.is_contiguous(memory_format=CL) or w1.grad.shape == w2.grad.shape
+    with pytest.raises(RuntimeError):
+        ops.conv3x3_c64_wgrad_f32(x.permute(0, 2, 3, 1).to(torch.bfloat16), dy.permute(0, 2, 3, 1))
+
+
 @pytest.mark.parametrize("ci,co,k,pad,h", [(128, 192, 5, 0, 28), (192, 192, 5, 0, 28), (64, 96, 3, 1, 20)])
 def test_bf16_convolution_input_gradient_as_forward_convolution(ops, ci, co, k, pad, h):
     """ops.ConvBf16Fn (bf16 configuration, the CNN tail's 5x5 valid convolutions, src/modules/extractor.py:51-65): the input gradient

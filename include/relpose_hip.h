@@ -36,8 +36,8 @@ extern "C" {
  * functions this header declares.  rp_abi_version() / rp_abi_export_count() return the values the library was COMPILED with, so a
  * binding (rel_pose_amd/_lib.py parses both macros and counts the declarations) rejects a stale .so at load time instead of
  * failing later on a missing symbol. */
-#define RP_ABI_VERSION 17
-#define RP_ABI_EXPORTS 99
+#define RP_ABI_VERSION 18
+#define RP_ABI_EXPORTS 101
 int rp_abi_version(void);
 int rp_abi_export_count(void);
 const char* rp_target_arch(void);
@@ -190,6 +190,15 @@ int rp_conv_stem_fwd_bf16(const float* x_padded, const float* w, void* y, double
 size_t rp_conv_stem_wgrad_workspace_bytes(int N);
 int rp_conv_stem_wgrad_bf16(const float* x_padded, const void* dy, float* dw, void* workspace, size_t workspace_bytes, int N, int H, int W,
                             void* stream);
+
+/* The stem's weight gradient in EXACT fp32 (the headline configuration; autograd of src/model.py:127): x_padded [N,230,230,3] the framed
+ * fp32 image (rp_preprocess_padded), dy [N,112,112,64] fp32 NHWC, dw [64][7][7][3] fp32 (= a [64,3,7,7] channels-last parameter
+ * gradient); 224 x 224 images only.  workspace: rp_conv_stem_wgrad_f32_workspace_bytes(N) (the space-to-depth image + per-workgroup
+ * partials, summed in a fixed order: deterministic).  Output-stationary on v_mfma_f32_32x32x2_f32 (csrc/conv_stem_wgrad_f32.hip);
+ * replaces MIOpen's backward-weights call for this shape. */
+size_t rp_conv_stem_wgrad_f32_workspace_bytes(int N);
+int rp_conv_stem_wgrad_f32(const float* x_padded, const float* dy, float* dw, void* workspace, size_t workspace_bytes, int N, int H, int W,
+                           void* stream);
 
 /* The 3x3 / stride 1 / pad 1, 64 -> 64 convolutions of resnet.layer1 in the bf16 configuration (src/model.py:131; torchvision
  * BasicBlock.conv1 / conv2), hand-written implicit GEMM with the input halo resident in LDS and the filter in registers

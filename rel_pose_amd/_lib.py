@@ -132,6 +132,8 @@ _SIGS = {
     "rp_conv_stem_fwd_bf16": (c_int, [P, P, P, P, I, I, I, P]),
     "rp_conv_stem_wgrad_workspace_bytes": (c_size_t, [I]),
     "rp_conv_stem_wgrad_bf16": (c_int, [P, P, P, P, c_size_t, I, I, I, P]),
+    "rp_conv_stem_wgrad_f32_workspace_bytes": (c_size_t, [I]),
+    "rp_conv_stem_wgrad_f32": (c_int, [P, P, P, P, c_size_t, I, I, I, P]),
     "rp_conv3x3_c64_blocks": (c_int, [I]),
     "rp_conv3x3_c64_bf16": (c_int, [P, P, P, P, P, P, I, I, I, P]),
     "rp_conv3x3_c64_wgrad_blocks": (c_int, [I]),

@@ -2119,15 +2119,30 @@ def conv_stem_wgrad_bf16(x_padded_nhwc, dy_nhwc):
     return dw
 
 
+def conv_stem_wgrad_f32(x_padded_nhwc, dy_nhwc):
+    """rp_conv_stem_wgrad_f32: dW of the stem convolution in exact fp32 from the framed image [N,230,230,3] and dY [N,112,112,64] fp32 ->
+    [64,7,7,3] fp32 (the memory of a channels-last [64,3,7,7] weight)."""
+    lib = _lib.load()
+    _chk(x_padded_nhwc, dy_nhwc)
+    N = x_padded_nhwc.shape[0]
+    if tuple(x_padded_nhwc.shape[1:]) != (230, 230, 3) or tuple(dy_nhwc.shape) != (N, 112, 112, 64):
+        raise RuntimeError("conv_stem_wgrad_f32: x_padded [N,230,230,3], dY [N,112,112,64] expected")
+    nb = lib.rp_conv_stem_wgrad_f32_workspace_bytes(N)
+    ws = torch.empty((nb + 3) // 4, device=dy_nhwc.device, dtype=torch.float32)
+    dw = torch.empty(64, 7, 7, 3, device=dy_nhwc.device, dtype=torch.float32)
+    _lib.check(lib.rp_conv_stem_wgrad_f32(_p(x_padded_nhwc), _p(dy_nhwc), _p(dw), _p(ws), nb, N, 224, 224, _st()), "rp_conv_stem_wgrad_f32")
+    return dw
+
+
 STEM_CONV = os.environ.get("RP_STEM_CONV", "1") != "0"      # hand-written stem convolution forward
-STEM_WGRAD = os.environ.get("RP_STEM_WGRAD", "1") != "0"    # ... and (bf16 configuration, 224 x 224) its weight gradient
+STEM_WGRAD = os.environ.get("RP_STEM_WGRAD", "1") != "0"    # ... and (224 x 224) its weight gradient: bf16 configuration and exact fp32
 STEM_STATS = os.environ.get("RP_STEM_STATS", "1") != "0"    # ... with the BatchNorm batch statistics from its epilogue
 
 
 class StemConvFn(_Fn):
     """resnet.conv1 (7x7 / 2, pad 3, 3 -> 64, no bias; src/model.py:127) on the zero-framed NHWC image: forward = csrc/conv_stem.hip;
-    weight gradient = MIOpen's backward-weights on the same framed buffer (padding 0 there: identical arithmetic); the image itself
-    needs no gradient."""
+    weight gradient = csrc/conv_stem_wgrad_f32.hip at 224 x 224 (otherwise MIOpen's backward-weights on the same framed buffer, padding
+    0 there: identical arithmetic); the image itself needs no gradient."""
 
     @staticmethod
     def forward(ctx, xp, w, want_stats=False):
@@ -2145,8 +2160,11 @@ class StemConvFn(_Fn):
         dw = None
         if ctx.needs_input_grad[1]:
             dy = dy.contiguous(memory_format=torch.channels_last)
-            dw = torch.ops.aten.convolution_backward(dy, xp.permute(0, 3, 1, 2), w, None, [2, 2], [0, 0], [1, 1], False, [0, 0], 1,
-                                                     [False, True, False])[1]
+            if STEM_WGRAD and tuple(xp.shape[1:]) == (230, 230, 3) and dy.dtype == torch.float32 and tuple(dy.shape[1:]) == (64, 112, 112):
+                dw = conv_stem_wgrad_f32(xp, dy.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)      # csrc/conv_stem_wgrad_f32.hip
+            else:
+                dw = torch.ops.aten.convolution_backward(dy, xp.permute(0, 3, 1, 2), w, None, [2, 2], [0, 0], [1, 1], False, [0, 0], 1,
+                                                         [False, True, False])[1]
         return None, dw, None
 
 

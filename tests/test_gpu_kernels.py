@@ -1480,6 +1480,35 @@ def test_hand_written_stem_convolution(ops, N, H, W):
         assert float(framed.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("N", [1, 3, 128])
+def test_stem_weight_gradient_exact_fp32(ops, N):
+    """rp_conv_stem_wgrad_f32 (csrc/conv_stem_wgrad_f32.hip: weight gradient of resnet.conv1, 7x7 / 2, pad 3, 3 -> 64, src/model.py:127, in
+    the exact-fp32 configuration; space-to-depth + the output-stationary fp32 stream) against fp64 autograd of F.conv2d over ALL images
+    (N = 1, 3: fewer / ragged tile runs per workgroup) and against MIOpen's fp32 backward-weights at the headline size (N = 128):
+    3e-6 of the maximum (fp32 accumulation of up to 1.6 M exact products per element in per-workgroup partials summed in a fixed order)
+    / 2e-5 between the two fp32 results.  Deterministic.  The 8th row / column of the space-to-depth support must not leak into dW."""
+    import torch.nn.functional as F
+    CL = torch.channels_last
+    x = rnd(N, 3, 224, 224, seed=1).contiguous(memory_format=CL)
+    dy = rnd(N, 64, 112, 112, seed=2).contiguous(memory_format=CL)
+    xp = F.pad(x.permute(0, 2, 3, 1), (0, 0, 3, 3, 3, 3)).contiguous()
+    dw = ops.conv_stem_wgrad_f32(xp, dy.permute(0, 2, 3, 1))
+    assert torch.equal(dw, ops.conv_stem_wgrad_f32(xp, dy.permute(0, 2, 3, 1)))            # deterministic
+    w = rnd(64, 3, 7, 7, seed=3, scale=0.05).contiguous(memory_format=CL)
+    if N <= 3:
+        w64 = w.double().requires_grad_(True)
+        F.conv2d(x.double(), w64, None, 2, 3).backward(dy.double())
+        e, bound = rel(dw.permute(0, 3, 1, 2), w64.grad), 3e-6
+    else:
+        ref = torch.ops.aten.convolution_backward(dy, xp.permute(0, 3, 1, 2), w, None, [2, 2], [0, 0], [1, 1], False, [0, 0], 1,
+                                                  [False, True, False])[1]
+        e, bound = rel(dw.permute(0, 3, 1, 2), ref.double()), 2e-5
+    report("conv_stem_wgrad_f32[N=%d]" % N, dw=e)
+    assert e < bound, e
+    with pytest.raises(RuntimeError):
+        ops.conv_stem_wgrad_f32(xp[:, :100].contiguous(), dy.permute(0, 2, 3, 1))
+
+
 def test_deferred_splitk_reduces_are_bit_identical(ops):
     """ops.splitk_batch: the weight-gradient GEMMs of a block leave their split-K slabs in a private arena and ONE rp_splitk_reduce_multi
     finishes all of them (incl. the transposed-store form of fc2) -- same sums in the same order as each GEMM's own reduce."""

@@ -1862,6 +1862,9 @@ class ConvBf16Fn(_Fn):
 # exact-fp32 configuration: the weight gradient of resnet.layer1's 3x3 convolutions on the output-stationary fp32 kernel
 # (csrc/conv3x3_wgrad_f32.hip); forward and input gradient stay MIOpen's
 CONV3X3_WGRAD_F32 = os.environ.get("RP_CONV3X3_WGRAD_F32", "1") != "0"
+# (256 workgroup partials are written and reduced whatever the batch: below ~56 images MIOpen's kernel is faster -- 12 images: 37 vs
+# 55 us, 48: 110 vs 115, 64: 143 vs 137, 128: 263 vs 235, tools/lab/conv_wgrad_f32_time.py)
+CONV3X3_WGRAD_F32_MIN_N = int(os.environ.get("RP_CONV3X3_WGRAD_F32_MIN_N", "56"))
 
 
 class Conv3x3C64F32Fn(_Fn):
@@ -1886,7 +1889,8 @@ class Conv3x3C64F32Fn(_Fn):
 def conv3x3_wgrad_f32_ok(m, x):
     return (CONV3X3_WGRAD_F32 and CNN_PRECISION == 0 and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
             and m.weight.requires_grad and tuple(m.weight.shape) == (64, 64, 3, 3) and m.bias is None and m.stride == (1, 1)
-            and m.padding == (1, 1) and m.dilation == (1, 1) and m.groups == 1 and tuple(x.shape[1:]) == (64, 56, 56))
+            and m.padding == (1, 1) and m.dilation == (1, 1) and m.groups == 1 and tuple(x.shape[1:]) == (64, 56, 56)
+            and x.shape[0] >= CONV3X3_WGRAD_F32_MIN_N)
 
 
 def conv3x3_own_ok(m, x):

@@ -31,6 +31,9 @@ struct AttnP {
   float scale;
   int ZH;
   float* colpart;   // COLS only: [ZH][18 owner blocks][576 loop rows][2] = (max, sum of exp2(. - max)) of each loop row over one owner block
+  float* pst;       // SAVEP only: [ZH][18 query blocks][18 key tiles][1024]: exp2(s - running max) of every 32 x 32 tile in the layout the
+                    // stored-P backward reads (store_p_tile), and
+  float* mrun;      // [ZH][18 key tiles][576 queries]: the running max (log2 units) each tile was normalised with
 };
 
 // cooperative global -> register prefetch of a [32][64] tile (32 rows x 16 float4).  No exec-masked guards: when the
@@ -146,6 +149,30 @@ RP_DEV void pack_owner(const float (&reg)[32], bf16x8 (&pk)[4]) {
   for (int c = 0; c < 4; ++c) pk[c] = pack8(&reg[8 * c]);
 }
 
+// Stored-P training forward: the tile of un-normalised probabilities a wave has just formed (lane (q = l31, hf), register r = 4 g' + j'
+// = key 8 g' + 4 hf + j') leaves in the layout the stored-P backward pass (attn_bwd_dkdv_p_kernel: lane = key kk, registers = queries)
+// loads with four fully contiguous 16-byte-per-lane instructions:  Pt[g][hb][kk][j] = P[q = 8 g + 4 hb + j][kk]  (4 KB).  The
+// transposition runs through 2.1 KB of wave-private LDS in two halves of eight registers (keys 16 h .. 16 h + 15): sixteen ds_write_b32
+// with immediate offsets (rows of 16 chunks skewed by one chunk: 2-way conflicts only), four ds_read_b128, four 16-byte stores that
+// cover 256-byte runs -- no VALU instruction (an fp32 MFMA kernel pays for every one of them: profiles/r5_shadow_lab.txt).
+constexpr int PST_LDS = 544;      // floats per wave
+RP_DEV void store_p_tile(float* tile, float* T, const f32x16& v, int lane) {
+  const int q = lane & 31, hf = lane >> 5;
+  float* wbase = T + (q >> 2) * 68 + (q & 3) + 16 * hf;
+  const float* rbase = T + 4 * lane + 4 * (lane >> 4);
+  float* gbase = tile + ((lane >> 4) * 32 + (lane & 15)) * 4;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) wbase[32 * (e >> 2) + 4 * (e & 3)] = v[8 * h + e];      // register 8 h + e: local key 8 (e >> 2) + 4 hf + (e & 3)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float4 x = *reinterpret_cast<const float4*>(rbase + i * 272);               // local chunk 64 i + lane, skew 4 (4 i + (lane >> 4))
+      *reinterpret_cast<float4*>(gbase + i * 512 + 64 * h) = x;                         // chunk (4 i + (lane >> 4)) * 32 + 16 h + (lane & 15)
+    }
+  }
+}
+
 // Software-pipelined tile loop (one barrier per tile, two LDS buffers).  MFMA operands are fetched from LDS one phase
 // ahead of the MFMAs that consume them, so the matrix pipe never waits on a ds_read (the first version issued each
 // read right before its MFMA and exposed ~2000 cycles of LDS latency per 4096-cycle tile):
@@ -158,12 +185,15 @@ RP_DEV void pack_owner(const float (&reg)[32], bf16x8 (&pk)[4]) {
 // exp2 over the wave's 32 owner rows (DPP row reductions + one cross-row exchange, no LDS) -- and writes these partials; 18 of them
 // per key combine into the column log-sum-exp (colstats_finalize_kernel).  The dual softmax's row and column normalisers then cost
 // ONE pass over S instead of two (rp_emm_stats).
-template <int NW, bool STATS, int WPS, bool BF, bool COLS = false>
+// SAVEP (training forward of the stored-P backward, exact fp32 only): every tile's exp2(s - running max) also leaves for HBM
+// (store_p_tile) together with that running max; the backward then needs neither Q K^T nor an exponential (attn_bwd_dkdv_p_kernel).
+template <int NW, bool STATS, int WPS, bool BF, bool COLS = false, bool SAVEP = false>
 __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_kernel(AttnP p) {
   constexpr int NT = NW * 64;
   constexpr int NPF = (512 + NT - 1) / NT;
   __shared__ __attribute__((aligned(16))) float Ks[2][32 * KST];
   __shared__ __attribute__((aligned(16))) float Vs[STATS ? 1 : 2][STATS ? 4 : 32 * 64];
+  __shared__ __attribute__((aligned(16))) float Pst[SAVEP ? NW : 1][SAVEP ? PST_LDS : 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   int zh, qblk;
   if (!xcd_problem(NTILE / NW, p.ZH, zh, qblk)) return;
@@ -260,6 +290,10 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_kernel(AttnP p) {
       ps += s[r];
     }
     l = l * alpha + ps;
+    if (SAVEP) {
+      store_p_tile(p.pst + (((long long)zh * NTILE + (q0 >> 5)) * NTILE + t) * 1024, Pst[SAVEP ? wave : 0], s, lane);
+      p.mrun[((long long)zh * NTILE + t) * NTOK + q0 + l31] = mn;      // (both halves hold the same value: no exec-masked block)
+    }
     if (!STATS) {
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
@@ -340,6 +374,8 @@ struct AttnBwdP {
                 // dK/dV pass, so dQ = dS K is one streaming rp_ds_matmul
   float *dk_colpart, *dv_colpart;   // optional [Z * 18][ldp]: column sums of dk / dv over each 32-row block (first of the H*64 columns)
   int ldp;
+  const float* pst;    // stored-P pass only: what attn_fwd_kernel<SAVEP> wrote (AttnP::pst, AttnP::mrun)
+  const float* mrun;
 };
 
 #ifdef RP_DKDV_PROBE
@@ -447,6 +483,106 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dkdv_kernel(AttnBwdP p)
   store_ownerT(p.dk + ((long long)z * NTOK + k0 + l31) * p.lddk + h * 64, hi, dk0, dk1, p.scale);
   if (p.dk_colpart) {
     const long long prow = ((long long)z * NTILE + (k0 >> 5)) * p.ldp + h * 64;
+    colsum_ownerT(p.dv_colpart + prow, l31, hi, dv0, dv1, 1.0f);
+    colsum_ownerT(p.dk_colpart + prow, l31, hi, dk0, dk1, p.scale);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stored-P form of the dK/dV pass: the training forward left exp2(s - m_t) of every tile (store_p_tile) and the running maxima m_t, so
+//   P[q][kv] = Pt * exp2(m_t[q] - lse2[q])        one multiply per element, the factor formed once per (query, tile) by the loader lanes
+// and the pass executes THREE products per tile (dP = dO V^T, dV += dO^T P, dK += Q^T dS) instead of four: no Q K^T recompute, no
+// exponential, K is not read at all.  With rp_ds_matmul for dQ the attention backward executes exactly its four algorithmic products.
+// A wave owns 32 keys (V rows in VGPRs, dV / dK in 64 accumulators) and walks the 18 query tiles {Q, dO} staged in LDS; its P tile
+// (4 KB, this wave's alone) comes straight from HBM one tile ahead: four contiguous 16-byte-per-lane loads, register 4 g + j of lane
+// (kv, hi) = query 8 g + 4 hi + j -- the accumulator layout of the dP product, which is why the forward stores it that way.
+// ------------------------------------------------------------------------------------------------
+template <int NW, int WPS>
+__global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dkdv_p_kernel(AttnBwdP p) {
+  constexpr int NT = NW * 64;
+  constexpr int NPF = (512 + NT - 1) / NT;
+  __shared__ __attribute__((aligned(16))) float Qs[2][32 * KST];
+  __shared__ __attribute__((aligned(16))) float Ds[2][32 * KST];
+  __shared__ __attribute__((aligned(16))) float Ls[2][NW][64];   // per wave (the factor depends on the key block): [0..31] exp2(m_t - lse2), [32..63] delta
+  __shared__ __attribute__((aligned(16))) float Tst[NW][512];    // per-wave staging of the stored dS tile (store_acc_image_lds)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  int zh, qblk;
+  if (!xcd_problem(NTILE / NW, p.ZH, zh, qblk)) return;
+  const int h = zh % p.H, z = zh / p.H;
+  const int kb = qblk * NW + wave, k0 = kb * 32;
+  const float* qb = p.q + (long long)z * NTOK * p.ldq + h * 64;
+  const float* dob = p.dout + (long long)z * NTOK * p.lddo + h * 64;
+  const float* lseb = p.lse + (long long)zh * NTOK;
+  const float* delb = p.delta + (long long)zh * NTOK;
+  const float* mb = p.mrun + ((long long)zh * NTILE + kb) * NTOK;
+  const float* pt = p.pst + ((long long)zh * NTILE * NTILE + kb) * 1024 + 4 * lane;      // tile (t, kb): + t * 18 * 1024; register group g: + 256 g
+
+  float vreg[32];
+  load_owner(p.v + ((long long)z * NTOK + k0 + l31) * p.ldv + h * 64, hi, 1.0f, vreg);
+  const bf16x8 nopk[4] = {};
+  f32x16 dv0 = zero16(), dv1 = zero16(), dk0 = zero16(), dk1 = zero16();
+  float4 qpre[NPF], dpre[NPF];
+  // branch-free loader (see attn_bwd_dkdv_kernel): lanes 0-31 form the factor of query l31, lanes 32-63 carry its delta
+  const float* asrc = (lane & 32) ? delb + l31 : lseb + l31;
+  const float* bsrc = (lane & 32) ? delb + l31 : mb + l31;
+  auto lfac = [&](int t) {
+    const float a = asrc[t * 32], b = bsrc[t * 32];
+    return (lane & 32) ? a : fast_exp2(b - a * RP_LOG2E);
+  };
+  auto pload = [&](float4 (&x)[4], int t) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) x[g] = ld4(pt + (long long)t * (NTILE * 1024) + 256 * g);
+  };
+  float4 pa[4], pb[4];
+  tile_gload<NT>(qb, p.ldq, tid, qpre);
+  tile_gload<NT>(dob, p.lddo, tid, dpre);
+  float lpre = lfac(0);
+  pload(pa, 0);
+  tile_sstore<NT, KST>(Qs[0], tid, qpre);
+  tile_sstore<NT, KST>(Ds[0], tid, dpre);
+  Ls[0][wave][lane] = lpre;
+  __syncthreads();
+
+  auto step = [&](const float4 (&pc)[4], float4 (&pn)[4], int t) {
+    const int cur = t & 1;
+    if (t + 1 < NTILE) {
+      tile_gload<NT>(qb + (long long)(t + 1) * 32 * p.ldq, p.ldq, tid, qpre);
+      tile_gload<NT>(dob + (long long)(t + 1) * 32 * p.lddo, p.lddo, tid, dpre);
+      lpre = lfac(t + 1);
+      pload(pn, t + 1);
+    }
+    f32x16 dp = score_tile<false>(Ds[cur], l31, hi, vreg, nopk);      // dP: rows = queries acc_row(r, hi), lane = key
+    f32x16 pr;
+    const float* L = Ls[cur][wave];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float pv[4] = {pc[g].x, pc[g].y, pc[g].z, pc[g].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = 4 * g + j, qi = acc_row(r, hi);
+        pr[r] = pv[j] * L[qi];
+        dp[r] = pr[r] * (dp[r] - L[32 + qi]);
+      }
+    }
+    const long long tile = ((long long)zh * NTILE + t) * NTILE + kb;
+    store_acc_image_lds(p.ds + tile * 1024, Tst[wave], dp, p.scale, lane);
+    accum_tile<KST, false>(Ds[cur], l31, hi, pr, dv0, dv1);     // dV^T += dO^T P
+    accum_tile<KST, false>(Qs[cur], l31, hi, dp, dk0, dk1);     // dK^T += Q^T dS
+    if (t + 1 < NTILE) {
+      tile_sstore<NT, KST>(Qs[cur ^ 1], tid, qpre);
+      tile_sstore<NT, KST>(Ds[cur ^ 1], tid, dpre);
+      Ls[cur ^ 1][wave][lane] = lpre;
+    }
+    __syncthreads();
+  };
+  for (int t = 0; t < NTILE; t += 2) {      // two register sets for the P tiles rotate without copies (18 tiles)
+    step(pa, pb, t);
+    step(pb, pa, t + 1);
+  }
+  store_ownerT(p.dv + ((long long)z * NTOK + k0 + l31) * p.lddv + h * 64, hi, dv0, dv1, 1.0f);
+  store_ownerT(p.dk + ((long long)z * NTOK + k0 + l31) * p.lddk + h * 64, hi, dk0, dk1, p.scale);
+  if (p.dk_colpart) {
+    const long long prow = ((long long)z * NTILE + kb) * p.ldp + h * 64;
     colsum_ownerT(p.dv_colpart + prow, l31, hi, dv0, dv1, 1.0f);
     colsum_ownerT(p.dk_colpart + prow, l31, hi, dk0, dk1, p.scale);
   }
@@ -845,6 +981,36 @@ extern "C" int rp_attn_fwd(const float* q, const float* k, const float* v, float
   else if (nw == 2) hipLaunchKernelGGL((attn_fwd_kernel<2, false, 2, false>), g2, dim3(128), 0, st, p);
   else if (wps == 3) hipLaunchKernelGGL((attn_fwd_kernel<3, false, 3, false>), g3, dim3(192), 0, st, p);
   else hipLaunchKernelGGL((attn_fwd_kernel<3, false, 2, false>), g3, dim3(192), 0, st, p);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
+// Training forward of the stored-P backward (exact fp32): rp_attn_fwd plus pst [Z][H][18][18][1024] (un-normalised probabilities of every
+// 32 x 32 tile, store_p_tile's layout) and mrun [Z][H][18][576] (the running maxima they are relative to)
+extern "C" int rp_attn_fwd_savep(const float* q, const float* k, const float* v, float* o, float* lse, float* pst, float* mrun, int Z,
+                                 int H, int ldq, int ldk, int ldv, int ldo, float scale, void* stream) {
+  if (Z <= 0 || H <= 0 || !q || !k || !v || !o || !lse || !pst || !mrun) return RP_EBADSHAPE;
+  if ((ldq | ldk | ldv | ldo) & 3) return RP_EALIGN;
+  AttnP p{q, k, v, o, lse, H, ldq, ldk, ldv, ldo, 0, 0, scale, Z * H, nullptr, pst, mrun};
+  hipStream_t st = (hipStream_t)stream;
+  if (Z * H * (NTILE / 2) <= 512) hipLaunchKernelGGL((attn_fwd_kernel<1, false, 2, false, false, true>), dim3(xcd_grid(NTILE, Z * H)), dim3(64), 0, st, p);
+  else hipLaunchKernelGGL((attn_fwd_kernel<2, false, 2, false, false, true>), dim3(xcd_grid(NTILE / 2, Z * H)), dim3(128), 0, st, p);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
+// The dK/dV pass over what rp_attn_fwd_savep stored (attn_bwd_dkdv_p_kernel): dk, dv, and scale * dS in rp_ds_matmul's tiles
+extern "C" int rp_attn_bwd_dkdv_p(const float* q, const float* v, const float* dout, const float* lse, const float* delta,
+                                  const float* pst, const float* mrun, float* dk, float* dv, float* ds, int Z, int H, int ldq, int ldv,
+                                  int lddo, int lddk, int lddv, float scale, float* dk_colpart, float* dv_colpart, int ldp, void* stream) {
+  if (Z <= 0 || H <= 0 || !q || !v || !dout || !lse || !delta || !pst || !mrun || !dk || !dv || !ds) return RP_EBADSHAPE;
+  if ((ldq | ldv | lddo | lddk | lddv) & 3) return RP_EALIGN;
+  if ((dk_colpart == nullptr) != (dv_colpart == nullptr) || (dk_colpart && ldp < H * 64)) return RP_EBADSHAPE;
+  AttnBwdP p{q, nullptr, v, dout, lse, delta, nullptr, dk, dv, H, ldq, 4, ldv, lddo, 4, lddk, lddv, scale, Z * H, 0, ds,
+             dk_colpart, dv_colpart, ldp, pst, mrun};
+  hipStream_t st = (hipStream_t)stream;
+  if (Z * H * (NTILE / 2) <= 512) hipLaunchKernelGGL((attn_bwd_dkdv_p_kernel<1, 2>), dim3(xcd_grid(NTILE, Z * H)), dim3(64), 0, st, p);
+  else hipLaunchKernelGGL((attn_bwd_dkdv_p_kernel<2, 2>), dim3(xcd_grid(NTILE / 2, Z * H)), dim3(128), 0, st, p);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }

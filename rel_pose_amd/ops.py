@@ -822,9 +822,16 @@ def layernorm_bwd(dy, x2d, gamma, mean, rstd, add=None):
     return dx, sums[:C], sums[C:2 * C], sums[2 * C:]
 
 
-def attn_fwd(qkv, Z, stats_only=False, q_off=0, k_off=DIM, v_off=2 * DIM, q_xor=0, k_xor=0):
+# Stored-P attention backward (exact-fp32 configuration, self attention): the training forward keeps exp2(s - running max) of every tile
+# (Z * 4 MB per Block: 2.5 GB for the five Blocks at 64 pairs -- 288 GB of HBM) and the backward executes its four algorithmic
+# products instead of five (no Q K^T recompute, no exponential).  RP_ATTN_STORE_P=0: the recompute form (rp_attn_bwd_dkdv_ds).
+ATTN_STORE_P = os.environ.get("RP_ATTN_STORE_P", "1") == "1"
+
+
+def attn_fwd(qkv, Z, stats_only=False, q_off=0, k_off=DIM, v_off=2 * DIM, q_xor=0, k_xor=0, save_p=False):
     """qkv [Z*576, 576] packed (q | k | v, head-major columns).  Returns (o [Z*576,192] or None, lse [Z,H,576]).
-    k_xor: bit 0 takes K, bit 1 takes V from the partner image of the pair (3 = --noess cross attention)."""
+    k_xor: bit 0 takes K, bit 1 takes V from the partner image of the pair (3 = --noess cross attention).
+    save_p (exact fp32, no xor): rp_attn_fwd_savep -- returns (o, lse, pst, mrun) for attn_bwd(..., saved_p=(pst, mrun))."""
     lib = _lib.load()
     _chk(qkv)
     ld = qkv.shape[1]
@@ -833,6 +840,15 @@ def attn_fwd(qkv, Z, stats_only=False, q_off=0, k_off=DIM, v_off=2 * DIM, q_xor=
     base = qkv.data_ptr()
     P = ctypes.c_void_p
     hd = DIM // HEADS
+    if save_p:
+        if stats_only or q_xor or k_xor or ATTN_BF16:
+            raise RuntimeError("attn_fwd(save_p=True): exact-fp32 self attention only")
+        pst = _empty(Z, HEADS, N_TOK // 32, N_TOK // 32, 1024, like=qkv)
+        mrun = _empty(Z, HEADS, N_TOK // 32, N_TOK, like=qkv)
+        with timed("attn_fwd_savep", 4.0 * Z * HEADS * N_TOK * N_TOK * hd, 4.0 * Z * N_TOK * (4 * DIM + HEADS * (N_TOK + 19))):
+            _lib.check(lib.rp_attn_fwd_savep(P(base + 4 * q_off), P(base + 4 * k_off), P(base + 4 * v_off), _p(o), _p(lse), _p(pst),
+                                             _p(mrun), Z, HEADS, ld, ld, ld, DIM, hd ** -0.5, _st()), "rp_attn_fwd_savep")
+        return o, lse, pst, mrun
     with timed("attn_stats" if stats_only else "attn_fwd", (2.0 if stats_only else 4.0) * Z * HEADS * N_TOK * N_TOK * hd,
                4.0 * Z * N_TOK * ((2 if stats_only else 4) * DIM + HEADS)):
         _lib.check(lib.rp_attn_fwd(P(base + 4 * q_off), P(base + 4 * k_off), P(base + 4 * v_off), _p(o), _p(lse), Z, HEADS,
@@ -914,10 +930,11 @@ def ds_matmul(ds, b_base, ldb, out_base, ldo, Z, b_xor=0, colpart_base=None, ldp
 QKV_BIAS_FROM_PRODUCERS = os.environ.get("RP_QKV_BIAS_PARTIALS", "1") != "0"      # A/B aid
 
 
-def attn_bwd(qkv, o, lse, do, Z, fork=None, kv_xor=0, want_bias_partials=False):
+def attn_bwd(qkv, o, lse, do, Z, fork=None, kv_xor=0, want_bias_partials=False, saved_p=None):
     """dqkv of the fused attention.  With a _Fork the dQ pass runs on the side stream next to the dK/dV pass (they write
     disjoint column blocks of dqkv); the caller must fork.sync_main() before reading dqkv.
-    kv_xor=1: backward of attn_fwd(..., k_xor=3) (keys/values from the partner image)."""
+    kv_xor=1: backward of attn_fwd(..., k_xor=3) (keys/values from the partner image).
+    saved_p = (pst, mrun) of attn_fwd(save_p=True): the stored-P form (rp_attn_bwd_dkdv_p + rp_ds_matmul)."""
     lib = _lib.load()
     _chk(qkv, o, lse, do)
     ld = qkv.shape[1]
@@ -927,6 +944,24 @@ def attn_bwd(qkv, o, lse, do, Z, fork=None, kv_xor=0, want_bias_partials=False):
     P = ctypes.c_void_p
     b, d = qkv.data_ptr(), dqkv.data_ptr()
     sc = (DIM // HEADS) ** -0.5
+    if saved_p is not None:
+        if kv_xor or ATTN_BF16:
+            raise RuntimeError("stored-P attention backward: exact-fp32 self attention only")
+        pst, mrun = saved_p
+        _chk(pst, mrun)
+        ds = _ds_buffer(Z, qkv)
+        part = pb = None
+        if want_bias_partials and QKV_BIAS_FROM_PRODUCERS:
+            part = _empty(Z * (N_TOK // 32), 3 * DIM, like=qkv)
+            pb = part.data_ptr()
+        hd = DIM // HEADS
+        with timed("attn_bwd_dkdv_p", 6.0 * Z * HEADS * N_TOK * N_TOK * hd, 4.0 * Z * (N_TOK * 5 * DIM + HEADS * N_TOK * (2 * N_TOK + 21))):
+            _lib.check(lib.rp_attn_bwd_dkdv_p(P(b), P(b + 8 * DIM), _p(do), _p(lse), _p(delta), _p(pst), _p(mrun), P(d + 4 * DIM),
+                                              P(d + 8 * DIM), _p(ds), Z, HEADS, ld, ld, DIM, ld, ld, sc,
+                                              P(pb + 4 * DIM) if pb else None, P(pb + 8 * DIM) if pb else None, 3 * DIM, _st()),
+                       "rp_attn_bwd_dkdv_p")
+        ds_matmul(ds, b + 4 * DIM, ld, d, ld, Z, colpart_base=pb, ldp=3 * DIM)      # dQ = dS K
+        return (dqkv, part) if want_bias_partials else dqkv
     if kv_xor:
         _lib.check(lib.rp_attn_bwd_cross(P(b), P(b + 4 * DIM), P(b + 8 * DIM), _p(do), _p(lse), _p(delta), P(d),
                                          P(d + 4 * DIM), P(d + 8 * DIM), Z, HEADS, ld, ld, ld, DIM, ld, ld, ld, sc, 1, ATTN_BF16, _st()),
@@ -942,10 +977,14 @@ def attn_bwd(qkv, o, lse, do, Z, fork=None, kv_xor=0, want_bias_partials=False):
             # gradient becomes a column sum over 2304 rows per 128 images instead of 73 728
             part = _empty(Z * (N_TOK // 32), 3 * DIM, like=qkv)
             pb = part.data_ptr()
-        _lib.check(lib.rp_attn_bwd_dkdv_ds(P(b), P(b + 4 * DIM), P(b + 8 * DIM), _p(do), _p(lse), _p(delta), P(d + 4 * DIM),
-                                           P(d + 8 * DIM), _p(ds), Z, HEADS, ld, ld, ld, DIM, ld, ld, sc, ATTN_BF16,
-                                           P(pb + 4 * DIM) if pb else None, P(pb + 8 * DIM) if pb else None, 3 * DIM, _st()),
-                   "rp_attn_bwd_dkdv_ds")
+        hd = DIM // HEADS
+        # (algorithmic flops: dV, dP, dK -- the S recompute the kernel also executes is not counted)
+        with timed("attn_bwd_dkdv_ds", 6.0 * Z * HEADS * N_TOK * N_TOK * hd,
+                   (2.0 if ATTN_BF16 else 4.0) * Z * HEADS * N_TOK * N_TOK + 4.0 * Z * N_TOK * (6 * DIM + 2 * HEADS)):
+            _lib.check(lib.rp_attn_bwd_dkdv_ds(P(b), P(b + 4 * DIM), P(b + 8 * DIM), _p(do), _p(lse), _p(delta), P(d + 4 * DIM),
+                                               P(d + 8 * DIM), _p(ds), Z, HEADS, ld, ld, ld, DIM, ld, ld, sc, ATTN_BF16,
+                                               P(pb + 4 * DIM) if pb else None, P(pb + 8 * DIM) if pb else None, 3 * DIM, _st()),
+                       "rp_attn_bwd_dkdv_ds")
         ds_matmul(ds, b + 4 * DIM, ld, d, ld, Z, colpart_base=pb, ldp=3 * DIM)      # dQ = dS K: one streaming launch
         return (dqkv, part) if want_bias_partials else dqkv
     if fork is None or not fork.enabled:
@@ -1440,12 +1479,16 @@ class BlockFn(_Fn):
         Z = x.shape[0]
         x2 = x.view(Z * N_TOK, DIM)
         bfp = _bf16_path()
+        pst = mrun = None
         if bfp:      # bf16 q | k | v -> bf16 o (lse in log2 units); xn1 kept as the bf16 rows the product consumed
             qkv, xn1, m1, r1 = ln_linear(x2, n1w, n1b, qkv_w, qkv_b, train=train, out_dtype=torch.bfloat16, xn_dtype=torch.bfloat16)
             o, lse = attn_fwd_bf16(qkv, Z, k_xor=3 if cross else 0)
         else:
             qkv, xn1, m1, r1 = ln_linear(x2, n1w, n1b, qkv_w, qkv_b, train=train)
-            o, lse = attn_fwd(qkv, Z, k_xor=3 if cross else 0)
+            if train and ATTN_STORE_P and ATTN_BWD_STORE_DS and not cross and not ATTN_BF16 and not USE_SIDE_STREAM:
+                o, lse, pst, mrun = attn_fwd(qkv, Z, save_p=True)
+            else:
+                o, lse = attn_fwd(qkv, Z, k_xor=3 if cross else 0)
         ctx.cross = cross
         x1 = linear(o, proj_w, proj_b, residual=x2)
         y, xn2, m2, r2, h, hpre = _mlp_block_fwd(x1, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b, train)
@@ -1454,14 +1497,14 @@ class BlockFn(_Fn):
             if bfp:
                 register_transposed(qkv_w)          # W_qkv^T for the output-resident input-gradient kernel (rp_dx_lnbwd_bf16)
             ctx.save_for_backward(x2, m1, r1, xn1, qkv, o, lse, x1, m2, r2, xn2, h, hpre, n1w, qkv_w, proj_w, n2w,
-                                  fc1_w, fc2_w)
+                                  fc1_w, fc2_w, pst, mrun)
             ctx.Z = Z
         return y.view(Z, N_TOK, DIM)
 
     @staticmethod
     def backward(ctx, dy):
         (x2, m1, r1, xn1, qkv, o, lse, x1, m2, r2, xn2, h, hpre, n1w, qkv_w, proj_w, n2w, fc1_w,
-         fc2_w) = ctx.saved_tensors
+         fc2_w, pst, mrun) = ctx.saved_tensors
         Z = ctx.Z
         dy = dy.contiguous().view(Z * N_TOK, DIM)
         fork = _Fork(dy.device)
@@ -1478,7 +1521,8 @@ class BlockFn(_Fn):
                 dqkv, bpart = attn_bwd_bf16(qkv, o, lse, do, Z, kv_xor=1 if ctx.cross else 0, want_bias_partials=True)
             else:
                 do = linear_dx(dx1, proj_w)
-                dqkv, bpart = attn_bwd(qkv, o, lse, do, Z, fork, kv_xor=1 if ctx.cross else 0, want_bias_partials=True)
+                dqkv, bpart = attn_bwd(qkv, o, lse, do, Z, fork, kv_xor=1 if ctx.cross else 0, want_bias_partials=True,
+                                       saved_p=None if pst is None else (pst, mrun))
             fork.sync_main()                                  # dQ pass (side) done before dqkv is consumed
             fork.sync_side()
             if bpart is not None:      # qkv bias gradient from the per-block column sums the attention backward's kernels left

@@ -541,6 +541,44 @@ def test_attention_fwd_bwd(ops, waves, monkeypatch):
     assert rel(part, blocks) < 2e-6 and rel(part.double().sum(0), q64.grad.sum(0)) < 2e-5
 
 
+@pytest.mark.parametrize("Z", [4, 30])
+def test_attention_stored_p_fwd_bwd(ops, Z):
+    """Stored-P form (rp_attn_fwd_savep + rp_attn_bwd_dkdv_p + rp_ds_matmul; autograd of vision_transformer.py:325-329): the forward's
+    o / lse must be BIT-identical to rp_attn_fwd (same arithmetic, only extra stores), the stored tiles must be the un-normalised
+    probabilities in the documented layout, and the gradients must match fp64 autograd like the recompute form's.  Z = 4: one-wave
+    workgroups; Z = 30 (810 two-wave workgroups): the form every full-size batch runs."""
+    qkv = rnd(Z * 576, 576, seed=1)
+    qkv[:, :384] *= 1.7
+    qkv[5, :64] *= 6.0           # a spiky query row: its running maximum jumps, the per-tile factor must follow it
+    o0, lse0 = ops.attn_fwd(qkv, Z)
+    o, lse, pst, mrun = ops.attn_fwd(qkv, Z, save_p=True)
+    assert torch.equal(o, o0) and torch.equal(lse, lse0)
+    # tile layout: element (query i, key j) of tile (qb, t) at float ((i >> 3) * 64 + ((i >> 2) & 1) * 32 + j) * 4 + (i & 3)
+    q64 = qkv.double().requires_grad_(True)
+    o_ref, lse_ref, S = _attn_ref(q64, Z)                                           # S [Z,3,576,576], natural-log units
+    Pn = torch.exp(S.detach() - lse_ref.detach().view(Z, 3, 576, 1))
+    t5 = pst.view(Z, 3, 18, 18, 4, 2, 32, 4)                                        # [z,h,qb,t, g,hb,kk,j]: i = 8 g + 4 hb + j
+    fac = torch.exp2(mrun.double() - lse.double().view(Z, 3, 1, 576) / math.log(2.0))          # [Z,3,18 tiles,576]
+    Pst = t5.permute(0, 1, 2, 4, 5, 7, 3, 6).reshape(Z, 3, 576, 576).double()       # [z,h, (qb,g,hb,j) = i, (t,kk) = j]
+    Pback = Pst * fac.permute(0, 1, 3, 2).repeat_interleave(32, dim=3)
+    e_p = rel(Pback, Pn)
+    report("attn_fwd_savep[Z=%d]" % Z, p=e_p)
+    assert e_p < 5e-6
+    do = rnd(Z * 576, 192, seed=2)
+    (o_ref * do.double()).sum().backward()
+    dqkv, part = ops.attn_bwd(qkv, o, lse, do, Z, want_bias_partials=True, saved_p=(pst, mrun))
+    e = [rel(dqkv[:, i * 192:(i + 1) * 192], q64.grad[:, i * 192:(i + 1) * 192]) for i in range(3)]
+    report("attn_bwd[stored_p, Z=%d]" % Z, dq=e[0], dk=e[1], dv=e[2])
+    assert max(e) < 2e-5
+    assert torch.equal(dqkv, ops.attn_bwd(qkv, o, lse, do, Z, saved_p=(pst, mrun)))           # deterministic
+    blocks = dqkv.double().view(Z * 18, 32, 576).sum(1)
+    assert rel(part, blocks) < 2e-6 and rel(part.double().sum(0), q64.grad.sum(0)) < 2e-5
+    ref_form = ops.attn_bwd(qkv, o, lse, do, Z)                                                # recompute form: same gradients to rounding
+    assert rel(dqkv, ref_form) < 5e-6
+    with pytest.raises(RuntimeError):
+        ops.attn_fwd(qkv, Z, k_xor=3, save_p=True)
+
+
 def test_cross_attention_is_attention_on_partner_keys_values(ops):
     """--noess cross attention (vision_transformer.py:239-262): rp_attn_fwd(k_xor=3) / rp_attn_bwd_cross(kv_xor=1) must be
     BIT-identical to the plain kernels run on a copy whose k|v columns are pair-swapped (same tiles, same order)."""

@@ -37,7 +37,7 @@ extern "C" {
  * binding (rel_pose_amd/_lib.py parses both macros and counts the declarations) rejects a stale .so at load time instead of
  * failing later on a missing symbol. */
 #define RP_ABI_VERSION 19
-#define RP_ABI_EXPORTS 103
+#define RP_ABI_EXPORTS 104
 int rp_abi_version(void);
 int rp_abi_export_count(void);
 const char* rp_target_arch(void);
@@ -367,17 +367,21 @@ int rp_attn_bwd_dq(const float* q, const float* k, const float* v, const float* 
  * dK = dS^T Q, dQ = dS K) -- no Q K^T recompute, no exponential.
  * rp_attn_fwd_savep = rp_attn_fwd(q_xor = k_xor = 0) that also writes
  *   pst  [Z][H][18 query blocks][18 key tiles][1024]: exp2(s_ij - m_t(i)) of each 32 x 32 tile, s in log2 units, m_t(i) the online
- *        softmax's running maximum of query i after key tile t; inside a tile element (query i, key j) sits at float
- *        ((i >> 3) * 64 + ((i >> 2) & 1) * 32 + j) * 4 + (i & 3)  (i, j relative to the tile) -- the accumulator layout of the
- *        backward's dP product as four contiguous 16-byte-per-lane loads;
+ *        softmax's running maximum of query i after key tile t; inside a tile element (query i, key j) is float
+ *        ((j >> 2) * 32 + i) * 4 + (j & 3): the 16-byte runs the forward's lanes hold, 1 KB contiguous per store instruction;
  *   mrun [Z][H][18 key tiles][576]: m_t(i).
- * rp_attn_bwd_dkdv_p: the dK/dV pass over them (P = pst * exp2(mrun - lse / ln 2)); writes dk, dv and scale * dS in
- * rp_attn_bwd_dkdv_ds's tiles (ds, colpart arguments as there); dQ = rp_ds_matmul(ds, k). */
+ * Neither costs the forward an LDS round trip or a VALU instruction: four 16-byte stores per lane straight from the accumulators.
+ * rp_attn_bwd_dkdv_p: the dK/dV pass over them (P = pst * exp2(mrun - lse / ln 2)); writes dk, dv (colpart arguments as
+ * rp_attn_bwd_dkdv_ds) and scale * dS as ds [Z][H][18 query blocks][18 key blocks][1024], element (query i, key j) of a tile at float
+ * ((i >> 2) * 32 + j) * 4 + (i & 3) (again four contiguous 16-byte stores per lane from the accumulators).
+ * rp_ds_matmul_t: rp_ds_matmul for that tile layout (dQ = dS K): both operands by LDS-DMA, exact fp32 MFMA. */
 int rp_attn_fwd_savep(const float* q, const float* k, const float* v, float* o, float* lse, float* pst, float* mrun, int Z, int H,
                       int ldq, int ldk, int ldv, int ldo, float scale, void* stream);
 int rp_attn_bwd_dkdv_p(const float* q, const float* v, const float* dout, const float* lse, const float* delta, const float* pst,
                        const float* mrun, float* dk, float* dv, float* ds, int Z, int H, int ldq, int ldv, int lddo, int lddk,
                        int lddv, float scale, float* dk_colpart, float* dv_colpart, int ldp, void* stream);
+int rp_ds_matmul_t(const float* ds, const float* b, float* out, int Z, int H, int ldb, int ldo, int b_xor, float* colpart, int ldp,
+                   void* stream);
 
 /* Quadratic positional features (closed form of get_positional_encodings, vision_transformer.py:90-158):
  * pos[b][n] = (p3^2, p4^2, p3 p4, p3, p4, 1), p3 = lin[n%24]*iy_b, p4 = lin[n/24]*ix_b,

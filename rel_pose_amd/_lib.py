@@ -101,6 +101,7 @@ _SIGS = {
     "rp_attn_bwd_dq": (c_int, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, F, I, P]),
     "rp_attn_fwd_savep": (c_int, [P, P, P, P, P, P, P, I, I, I, I, I, I, F, P]),
     "rp_attn_bwd_dkdv_p": (c_int, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, F, P, P, I, P]),
+    "rp_ds_matmul_t": (c_int, [P, P, P, I, I, I, I, I, P, I, P]),
     "rp_dw192_f32_splits": (c_int, [I, I]),
     "rp_dw192_f32_workspace_bytes": (c_size_t, [I, I]),
     "rp_dw192_f32": (c_int, [P, I, P, I, I, P, c_size_t, P]),

@@ -31,8 +31,7 @@ struct AttnP {
   float scale;
   int ZH;
   float* colpart;   // COLS only: [ZH][18 owner blocks][576 loop rows][2] = (max, sum of exp2(. - max)) of each loop row over one owner block
-  float* pst;       // SAVEP only: [ZH][18 query blocks][18 key tiles][1024]: exp2(s - running max) of every 32 x 32 tile in the layout the
-                    // stored-P backward reads (store_p_tile), and
+  float* pst;       // SAVEP only: [ZH][18 query blocks][18 key tiles][32 queries][32 keys]: exp2(s - running max) of every tile, and
   float* mrun;      // [ZH][18 key tiles][576 queries]: the running max (log2 units) each tile was normalised with
 };
 
@@ -149,28 +148,16 @@ RP_DEV void pack_owner(const float (&reg)[32], bf16x8 (&pk)[4]) {
   for (int c = 0; c < 4; ++c) pk[c] = pack8(&reg[8 * c]);
 }
 
-// Stored-P training forward: the tile of un-normalised probabilities a wave has just formed (lane (q = l31, hf), register r = 4 g' + j'
-// = key 8 g' + 4 hf + j') leaves in the layout the stored-P backward pass (attn_bwd_dkdv_p_kernel: lane = key kk, registers = queries)
-// loads with four fully contiguous 16-byte-per-lane instructions:  Pt[g][hb][kk][j] = P[q = 8 g + 4 hb + j][kk]  (4 KB).  The
-// transposition runs through 2.1 KB of wave-private LDS in two halves of eight registers (keys 16 h .. 16 h + 15): sixteen ds_write_b32
-// with immediate offsets (rows of 16 chunks skewed by one chunk: 2-way conflicts only), four ds_read_b128, four 16-byte stores that
-// cover 256-byte runs -- no VALU instruction (an fp32 MFMA kernel pays for every one of them: profiles/r5_shadow_lab.txt).
-constexpr int PST_LDS = 544;      // floats per wave
-RP_DEV void store_p_tile(float* tile, float* T, const f32x16& v, int lane) {
-  const int q = lane & 31, hf = lane >> 5;
-  float* wbase = T + (q >> 2) * 68 + (q & 3) + 16 * hf;
-  const float* rbase = T + 4 * lane + 4 * (lane >> 4);
-  float* gbase = tile + ((lane >> 4) * 32 + (lane & 15)) * 4;
+// A wave's 32 x 32 accumulator tile (lane (c = l31, hf), register 4 g + j = row 8 g + 4 hf + j) stored as the four 16-byte runs each lane
+// holds, run (g, lane) at chunk 64 g + lane:  element (row, c) sits at chunk (row >> 2) * 32 + c, dword row & 3.  Four
+// global_store_dwordx4 of 1 KB CONTIGUOUS each, straight from the accumulators: no LDS round trip, no VALU (an fp32 MFMA kernel pays
+// for every VALU instruction: profiles/r5_shadow_lab.txt), and 16 write requests per instruction (a row-major tile -- 16-byte pieces
+// 128 bytes apart -- cost the forward 20 us and the backward 45 us per launch in request issue alone).  The readers pay the gather
+// instead, on the load side where it is hidden: attn_bwd_dkdv_p_kernel (P tiles, 4-byte loads) and ds_matmul_t_kernel (dS tiles,
+// through LDS-DMA).
+RP_DEV void store_tile_runs(float* tile, const f32x16& v, int lane) {
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) wbase[32 * (e >> 2) + 4 * (e & 3)] = v[8 * h + e];      // register 8 h + e: local key 8 (e >> 2) + 4 hf + (e & 3)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const float4 x = *reinterpret_cast<const float4*>(rbase + i * 272);               // local chunk 64 i + lane, skew 4 (4 i + (lane >> 4))
-      *reinterpret_cast<float4*>(gbase + i * 512 + 64 * h) = x;                         // chunk (4 i + (lane >> 4)) * 32 + 16 h + (lane & 15)
-    }
-  }
+  for (int g = 0; g < 4; ++g) st4(tile + 4 * (64 * g + lane), make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]));
 }
 
 // Software-pipelined tile loop (one barrier per tile, two LDS buffers).  MFMA operands are fetched from LDS one phase
@@ -186,14 +173,13 @@ RP_DEV void store_p_tile(float* tile, float* T, const f32x16& v, int lane) {
 // per key combine into the column log-sum-exp (colstats_finalize_kernel).  The dual softmax's row and column normalisers then cost
 // ONE pass over S instead of two (rp_emm_stats).
 // SAVEP (training forward of the stored-P backward, exact fp32 only): every tile's exp2(s - running max) also leaves for HBM
-// (store_p_tile) together with that running max; the backward then needs neither Q K^T nor an exponential (attn_bwd_dkdv_p_kernel).
+// (store_tile_runs) together with that running max; the backward then needs neither Q K^T nor an exponential (attn_bwd_dkdv_p_kernel).
 template <int NW, bool STATS, int WPS, bool BF, bool COLS = false, bool SAVEP = false>
 __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_kernel(AttnP p) {
   constexpr int NT = NW * 64;
   constexpr int NPF = (512 + NT - 1) / NT;
   __shared__ __attribute__((aligned(16))) float Ks[2][32 * KST];
   __shared__ __attribute__((aligned(16))) float Vs[STATS ? 1 : 2][STATS ? 4 : 32 * 64];
-  __shared__ __attribute__((aligned(16))) float Pst[SAVEP ? NW : 1][SAVEP ? PST_LDS : 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   int zh, qblk;
   if (!xcd_problem(NTILE / NW, p.ZH, zh, qblk)) return;
@@ -291,7 +277,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_kernel(AttnP p) {
     }
     l = l * alpha + ps;
     if (SAVEP) {
-      store_p_tile(p.pst + (((long long)zh * NTILE + (q0 >> 5)) * NTILE + t) * 1024, Pst[SAVEP ? wave : 0], s, lane);
+      store_tile_runs(p.pst + (((long long)zh * NTILE + (q0 >> 5)) * NTILE + t) * 1024, s, lane);      // element (key k, query q): chunk (k >> 2) * 32 + q, dword k & 3
       p.mrun[((long long)zh * NTILE + t) * NTOK + q0 + l31] = mn;      // (both halves hold the same value: no exec-masked block)
     }
     if (!STATS) {
@@ -489,13 +475,16 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dkdv_kernel(AttnBwdP p)
 }
 
 // ------------------------------------------------------------------------------------------------
-// Stored-P form of the dK/dV pass: the training forward left exp2(s - m_t) of every tile (store_p_tile) and the running maxima m_t, so
+// Stored-P form of the dK/dV pass: the training forward left exp2(s - m_t) of every tile (store_tile_runs) and the running
+// maxima m_t, so
 //   P[q][kv] = Pt * exp2(m_t[q] - lse2[q])        one multiply per element, the factor formed once per (query, tile) by the loader lanes
 // and the pass executes THREE products per tile (dP = dO V^T, dV += dO^T P, dK += Q^T dS) instead of four: no Q K^T recompute, no
-// exponential, K is not read at all.  With rp_ds_matmul for dQ the attention backward executes exactly its four algorithmic products.
+// exponential, K is not read at all.  With rp_ds_matmul_t for dQ the attention backward executes exactly its four algorithmic products.
 // A wave owns 32 keys (V rows in VGPRs, dV / dK in 64 accumulators) and walks the 18 query tiles {Q, dO} staged in LDS; its P tile
-// (4 KB, this wave's alone) comes straight from HBM one tile ahead: four contiguous 16-byte-per-lane loads, register 4 g + j of lane
-// (kv, hi) = query 8 g + 4 hi + j -- the accumulator layout of the dP product, which is why the forward stores it that way.
+// (4 KB, this wave's alone) comes straight from HBM one tile ahead -- sixteen 4-byte loads, register r of lane (kv, hi) = query
+// acc_row(r, hi), the accumulator layout of the dP product -- and scale * dS leaves as store_tile_runs writes it: neither tile touches
+// LDS or costs a VALU instruction.  `scale` rides on the V rows and on delta:
+// dP' = scale dP, delta' = scale delta  =>  P (dP' - delta') = scale dS, the stored tile and the dK operand.
 // ------------------------------------------------------------------------------------------------
 template <int NW, int WPS>
 __global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dkdv_p_kernel(AttnBwdP p) {
@@ -503,8 +492,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dkdv_p_kernel(AttnBwdP 
   constexpr int NPF = (512 + NT - 1) / NT;
   __shared__ __attribute__((aligned(16))) float Qs[2][32 * KST];
   __shared__ __attribute__((aligned(16))) float Ds[2][32 * KST];
-  __shared__ __attribute__((aligned(16))) float Ls[2][NW][64];   // per wave (the factor depends on the key block): [0..31] exp2(m_t - lse2), [32..63] delta
-  __shared__ __attribute__((aligned(16))) float Tst[NW][512];    // per-wave staging of the stored dS tile (store_acc_image_lds)
+  __shared__ __attribute__((aligned(16))) float Ls[2][NW][64];   // per wave (the factor depends on the key block): [0..31] exp2(m_t - lse2), [32..63] scale * delta
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   int zh, qblk;
   if (!xcd_problem(NTILE / NW, p.ZH, zh, qblk)) return;
@@ -515,25 +503,32 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dkdv_p_kernel(AttnBwdP 
   const float* lseb = p.lse + (long long)zh * NTOK;
   const float* delb = p.delta + (long long)zh * NTOK;
   const float* mb = p.mrun + ((long long)zh * NTILE + kb) * NTOK;
-  const float* pt = p.pst + ((long long)zh * NTILE * NTILE + kb) * 1024 + 4 * lane;      // tile (t, kb): + t * 18 * 1024; register group g: + 256 g
+  // P tile (t, kb): + t * 18 * 1024; element (key kk = l31, query q) at chunk (kk >> 2) * 32 + q, dword kk & 3 (store_tile_runs by the forward's
+  // lanes = queries): register r = query acc_row(r, hi) is a 4-byte load 16 (acc_row(r, 0) + 4 hi) bytes further on
+  const float* pt = p.pst + ((long long)zh * NTILE * NTILE + kb) * 1024 + (l31 >> 2) * 128 + (l31 & 3) + 16 * hi;
+  float* dst = p.ds + ((long long)zh * NTILE * NTILE + kb) * 1024;                           // likewise
 
   float vreg[32];
-  load_owner(p.v + ((long long)z * NTOK + k0 + l31) * p.ldv + h * 64, hi, 1.0f, vreg);
+  load_owner(p.v + ((long long)z * NTOK + k0 + l31) * p.ldv + h * 64, hi, p.scale, vreg);
   const bf16x8 nopk[4] = {};
   f32x16 dv0 = zero16(), dv1 = zero16(), dk0 = zero16(), dk1 = zero16();
   float4 qpre[NPF], dpre[NPF];
-  // branch-free loader (see attn_bwd_dkdv_kernel): lanes 0-31 form the factor of query l31, lanes 32-63 carry its delta
+  // branch-free loader (see attn_bwd_dkdv_kernel): lanes 0-31 form the factor of query l31, lanes 32-63 carry its scaled delta
   const float* asrc = (lane & 32) ? delb + l31 : lseb + l31;
   const float* bsrc = (lane & 32) ? delb + l31 : mb + l31;
+  // pure arithmetic, no select: a ternary around the exponential became a divergent branch whose blocks hipcc joined with
+  // s_waitcnt vmcnt(0) -- every tile then waited for its own just-issued prefetch (the pitfall attn_bwd_dkdv_kernel's loader documents)
+  const float km = (lane & 32) ? p.scale : 0.f, ke = (lane & 32) ? 0.f : 1.f;
   auto lfac = [&](int t) {
     const float a = asrc[t * 32], b = bsrc[t * 32];
-    return (lane & 32) ? a : fast_exp2(b - a * RP_LOG2E);
+    return fmaf(km, a, ke * fast_exp2(ke * fmaf(-a, RP_LOG2E, b)));
   };
-  auto pload = [&](float4 (&x)[4], int t) {
+  auto pload = [&](f32x16& x, int t) {
+    const float* tp = pt + (long long)t * (NTILE * 1024);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) x[g] = ld4(pt + (long long)t * (NTILE * 1024) + 256 * g);
+    for (int r = 0; r < 16; ++r) x[r] = tp[acc_row(r, 0) * 4];
   };
-  float4 pa[4], pb[4];
+  f32x16 pa, pb;
   tile_gload<NT>(qb, p.ldq, tid, qpre);
   tile_gload<NT>(dob, p.lddo, tid, dpre);
   float lpre = lfac(0);
@@ -543,7 +538,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dkdv_p_kernel(AttnBwdP 
   Ls[0][wave][lane] = lpre;
   __syncthreads();
 
-  auto step = [&](const float4 (&pc)[4], float4 (&pn)[4], int t) {
+  auto step = [&](f32x16& pc, f32x16& pn, int t) {
     const int cur = t & 1;
     if (t + 1 < NTILE) {
       tile_gload<NT>(qb + (long long)(t + 1) * 32 * p.ldq, p.ldq, tid, qpre);
@@ -551,23 +546,17 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dkdv_p_kernel(AttnBwdP 
       lpre = lfac(t + 1);
       pload(pn, t + 1);
     }
-    f32x16 dp = score_tile<false>(Ds[cur], l31, hi, vreg, nopk);      // dP: rows = queries acc_row(r, hi), lane = key
-    f32x16 pr;
+    f32x16 dp = score_tile<false>(Ds[cur], l31, hi, vreg, nopk);      // scale dP: rows = queries acc_row(r, hi), lane = key
     const float* L = Ls[cur][wave];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float pv[4] = {pc[g].x, pc[g].y, pc[g].z, pc[g].w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int r = 4 * g + j, qi = acc_row(r, hi);
-        pr[r] = pv[j] * L[qi];
-        dp[r] = pr[r] * (dp[r] - L[32 + qi]);
-      }
+    for (int r = 0; r < 16; ++r) {
+      const int qi = acc_row(r, hi);
+      pc[r] *= L[qi];
+      dp[r] = pc[r] * (dp[r] - L[32 + qi]);
     }
-    const long long tile = ((long long)zh * NTILE + t) * NTILE + kb;
-    store_acc_image_lds(p.ds + tile * 1024, Tst[wave], dp, p.scale, lane);
-    accum_tile<KST, false>(Ds[cur], l31, hi, pr, dv0, dv1);     // dV^T += dO^T P
-    accum_tile<KST, false>(Qs[cur], l31, hi, dp, dk0, dk1);     // dK^T += Q^T dS
+    store_tile_runs(dst + (long long)t * (NTILE * 1024), dp, lane);     // scale dS; element (query q, key k): chunk (q >> 2) * 32 + k, dword q & 3
+    accum_tile<KST, false>(Ds[cur], l31, hi, pc, dv0, dv1);     // dV^T += dO^T P
+    accum_tile<KST, false>(Qs[cur], l31, hi, dp, dk0, dk1);     // dK^T += Q^T (scale dS)
     if (t + 1 < NTILE) {
       tile_sstore<NT, KST>(Qs[cur ^ 1], tid, qpre);
       tile_sstore<NT, KST>(Ds[cur ^ 1], tid, dpre);
@@ -580,11 +569,11 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dkdv_p_kernel(AttnBwdP 
     step(pb, pa, t + 1);
   }
   store_ownerT(p.dv + ((long long)z * NTOK + k0 + l31) * p.lddv + h * 64, hi, dv0, dv1, 1.0f);
-  store_ownerT(p.dk + ((long long)z * NTOK + k0 + l31) * p.lddk + h * 64, hi, dk0, dk1, p.scale);
+  store_ownerT(p.dk + ((long long)z * NTOK + k0 + l31) * p.lddk + h * 64, hi, dk0, dk1, 1.0f);
   if (p.dk_colpart) {
     const long long prow = ((long long)z * NTILE + kb) * p.ldp + h * 64;
     colsum_ownerT(p.dv_colpart + prow, l31, hi, dv0, dv1, 1.0f);
-    colsum_ownerT(p.dk_colpart + prow, l31, hi, dk0, dk1, p.scale);
+    colsum_ownerT(p.dk_colpart + prow, l31, hi, dk0, dk1, 1.0f);
   }
 }
 
@@ -740,6 +729,64 @@ __global__ __launch_bounds__(NW * 64, 4) void ds_matmul_kernel(DsMmP p) {
   }
   store_ownerT(p.out + ((long long)z * NTOK + i0 + l31) * p.ldo + h * 64, hi, o0, o1, 1.0f);
   if (p.colpart) colsum_ownerT(p.colpart + ((long long)z * NTILE + (i0 >> 5)) * p.ldp + h * 64, l31, hi, o0, o1, 1.0f);
+}
+
+// rp_ds_matmul_t: the same product for tiles stored by store_tile_runs (what attn_bwd_dkdv_p_kernel writes with four contiguous 16-byte
+// stores per lane straight from its accumulators).  Both operands reach LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR, no ds_write,
+// nothing to wait for but vmcnt) -- the wave's own dS tile, 4 KB, gathered into T[j][i] row-major in a wave-private double buffer, and the
+// 32 x 64 rows of b shared by the workgroup -- and feed the matrix pipe through conflict-free ds_read_b32 with
+// immediate offsets: k-step s pairs column j = 2 s + hi with the two half-waves, lane (i = l31, hi) reads T[2 s + hi][i] as the B operand
+// and b[2 s + hi][l31], [l31 + 32] as the A operands (three LDS reads per two MFMAs; LDS reads are free next to an fp32 MFMA).
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 3) void ds_matmul_t_kernel(DsMmP p) {
+  __shared__ __attribute__((aligned(16))) float Bs[2][32 * 64];
+  __shared__ __attribute__((aligned(16))) float Dt[NW][2][1024];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
+  int zh, blk;
+  if (!xcd_problem(NTILE / NW, p.ZH, zh, blk)) return;
+  if (p.reverse) zh = p.ZH - 1 - zh;
+  const int h = zh % p.H, z = zh / p.H;
+  const int ib = blk * NW + wave, i0 = ib * 32;
+  const float* bb = p.b + (long long)(z ^ p.b_xor) * NTOK * p.ldb + h * 64;
+  const float* tiles = p.ds + ((long long)zh * NTILE + ib) * NTILE * 1024;
+  // DMA plan per step: this wave's dS tile = 4 pieces of 1 KB as they lie; the b tile = 8 pieces of 4 rows (lane -> row lane >> 4, 16-byte
+  // chunk lane & 15), wave w moves pieces w, w + NW, ... (every wave issues the same number: the last ones repeat piece 7)
+  constexpr int BP = (8 + NW - 1) / NW;
+  // dS tile: stored by store_tile_runs (element (query i, key j) at chunk (i >> 2) * 32 + j, dword i & 3); LDS wants T[j][i] row-major =
+  // chunk j * 8 + (i >> 2): DMA piece c (LDS chunks 64 c + lane: j = 8 c + (lane >> 3), i >> 2 = lane & 7) gathers global chunk
+  // (lane & 7) * 32 + 8 c + (lane >> 3) -- eight whole 128-byte lines per instruction
+  const unsigned dvoff = ((lane & 7) * 32 + (lane >> 3)) * 16, bvoff = (unsigned)((lane >> 4) * p.ldb * 4 + (lane & 15) * 16);
+  const unsigned dt0 = lds_byte_addr(&Dt[wave][0][0]), bs0 = lds_byte_addr(&Bs[0][0]);
+  auto issue = [&](int t, int buf) {
+    const float* ts = tiles + (long long)t * 1024;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) glds16(uniform_ptr(ts + 32 * c), dvoff, dt0 + buf * 4096 + c * 1024);
+#pragma unroll
+    for (int c = 0; c < BP; ++c) {
+      const int piece = min(wave + NW * c, 7);
+      glds16(uniform_ptr(bb + (long long)(t * 32 + 4 * piece) * p.ldb), bvoff, bs0 + buf * 8192 + piece * 1024);
+    }
+  };
+  f32x16 o0 = zero16(), o1 = zero16();
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int t = 0; t < NTILE; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < NTILE) issue(t + 1, cur ^ 1);
+    const float* B = Bs[cur] + hi * 64 + l31;
+    const float* D = Dt[wave][cur] + hi * 32 + l31;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const float dsv = D[64 * s];
+      o0 = mfma32(B[128 * s], dsv, o0);
+      o1 = mfma32(B[128 * s + 32], dsv, o1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  store_ownerT(p.out + ((long long)z * NTOK + i0 + l31) * p.ldo + h * 64, hi, o0, o1, 1.0f);
+  if (p.colpart) colsum_ownerT(p.colpart + ((long long)z * NTILE + ib) * p.ldp + h * 64, l31, hi, o0, o1, 1.0f);
 }
 
 // The bf16 configuration's form: the producer stored bf16 tiles (store_acc_image_bf16: the same [16 r][64 lanes] image, 2 KB), so
@@ -985,8 +1032,8 @@ extern "C" int rp_attn_fwd(const float* q, const float* k, const float* v, float
   return RP_OK;
 }
 
-// Training forward of the stored-P backward (exact fp32): rp_attn_fwd plus pst [Z][H][18][18][1024] (un-normalised probabilities of every
-// 32 x 32 tile, store_p_tile's layout) and mrun [Z][H][18][576] (the running maxima they are relative to)
+// Training forward of the stored-P backward (exact fp32): rp_attn_fwd plus pst [Z][H][18][18][32][32] (un-normalised probabilities of every
+// 32 x 32 tile, store_tile_runs' layout) and mrun [Z][H][18][576] (the running maxima they are relative to)
 extern "C" int rp_attn_fwd_savep(const float* q, const float* k, const float* v, float* o, float* lse, float* pst, float* mrun, int Z,
                                  int H, int ldq, int ldk, int ldv, int ldo, float scale, void* stream) {
   if (Z <= 0 || H <= 0 || !q || !k || !v || !o || !lse || !pst || !mrun) return RP_EBADSHAPE;
@@ -999,7 +1046,7 @@ extern "C" int rp_attn_fwd_savep(const float* q, const float* k, const float* v,
   return RP_OK;
 }
 
-// The dK/dV pass over what rp_attn_fwd_savep stored (attn_bwd_dkdv_p_kernel): dk, dv, and scale * dS in rp_ds_matmul's tiles
+// The dK/dV pass over what rp_attn_fwd_savep stored (attn_bwd_dkdv_p_kernel): dk, dv, and scale * dS in rp_ds_matmul_t's tiles
 extern "C" int rp_attn_bwd_dkdv_p(const float* q, const float* v, const float* dout, const float* lse, const float* delta,
                                   const float* pst, const float* mrun, float* dk, float* dv, float* ds, int Z, int H, int ldq, int ldv,
                                   int lddo, int lddk, int lddv, float scale, float* dk_colpart, float* dv_colpart, int ldp, void* stream) {
@@ -1093,6 +1140,19 @@ extern "C" int rp_ds_matmul(const float* ds, const float* b, float* out, int Z, 
   if (ds_bf16) hipLaunchKernelGGL((ds_matmul_bf16_kernel<3>), dim3(xcd_grid(NTILE / 3, Z * H)), dim3(192), 0, st, p);
   else if (ov && ov[0] == '1' && !colpart) hipLaunchKernelGGL((ds_matmul16_kernel<3>), dim3(xcd_grid(NTILE / 3, Z * H)), dim3(192), 0, st, p);
   else hipLaunchKernelGGL((ds_matmul_kernel<3>), dim3(xcd_grid(NTILE / 3, Z * H)), dim3(192), 0, st, p);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
+// rp_ds_matmul for tiles stored by store_tile_runs (what rp_attn_bwd_dkdv_p writes)
+extern "C" int rp_ds_matmul_t(const float* ds, const float* b, float* out, int Z, int H, int ldb, int ldo, int b_xor, float* colpart,
+                              int ldp, void* stream) {
+  if (Z <= 0 || H <= 0 || !ds || !b || !out || (b_xor & ~1) || (b_xor && (Z & 1))) return RP_EBADSHAPE;
+  if ((ldb | ldo) & 3) return RP_EALIGN;
+  if (colpart && ldp < H * 64) return RP_EBADSHAPE;
+  static const char* const rv = getenv("RP_DSMM_REV");
+  DsMmP p{ds, b, out, H, ldb, ldo, b_xor, Z * H, rv ? rv[0] - '0' : 1, colpart, ldp};
+  hipLaunchKernelGGL((ds_matmul_t_kernel<3>), dim3(xcd_grid(NTILE / 3, Z * H)), dim3(192), 0, (hipStream_t)stream, p);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }

@@ -960,7 +960,9 @@ def attn_bwd(qkv, o, lse, do, Z, fork=None, kv_xor=0, want_bias_partials=False, 
                                               P(d + 8 * DIM), _p(ds), Z, HEADS, ld, ld, DIM, ld, ld, sc,
                                               P(pb + 4 * DIM) if pb else None, P(pb + 8 * DIM) if pb else None, 3 * DIM, _st()),
                        "rp_attn_bwd_dkdv_p")
-        ds_matmul(ds, b + 4 * DIM, ld, d, ld, Z, colpart_base=pb, ldp=3 * DIM)      # dQ = dS K
+        with timed("ds_matmul_t", 2.0 * Z * HEADS * N_TOK * N_TOK * hd, Z * HEADS * N_TOK * (4.0 * N_TOK + 4.0 * 128)):
+            _lib.check(lib.rp_ds_matmul_t(_p(ds), P(b + 4 * DIM), P(d), Z, HEADS, ld, ld, 0, P(pb) if pb else None, 3 * DIM, _st()),
+                       "rp_ds_matmul_t")                                             # dQ = dS K
         return (dqkv, part) if want_bias_partials else dqkv
     if kv_xor:
         _lib.check(lib.rp_attn_bwd_cross(P(b), P(b + 4 * DIM), P(b + 8 * DIM), _p(do), _p(lse), _p(delta), P(d),

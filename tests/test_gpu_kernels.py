@@ -553,13 +553,12 @@ def test_attention_stored_p_fwd_bwd(ops, Z):
     o0, lse0 = ops.attn_fwd(qkv, Z)
     o, lse, pst, mrun = ops.attn_fwd(qkv, Z, save_p=True)
     assert torch.equal(o, o0) and torch.equal(lse, lse0)
-    # tile layout: element (query i, key j) of tile (qb, t) at float ((i >> 3) * 64 + ((i >> 2) & 1) * 32 + j) * 4 + (i & 3)
+    # tile layout: element (query i, key j) of tile (qb, t) at float ((j >> 2) * 32 + i) * 4 + (j & 3)
     q64 = qkv.double().requires_grad_(True)
     o_ref, lse_ref, S = _attn_ref(q64, Z)                                           # S [Z,3,576,576], natural-log units
     Pn = torch.exp(S.detach() - lse_ref.detach().view(Z, 3, 576, 1))
-    t5 = pst.view(Z, 3, 18, 18, 4, 2, 32, 4)                                        # [z,h,qb,t, g,hb,kk,j]: i = 8 g + 4 hb + j
     fac = torch.exp2(mrun.double() - lse.double().view(Z, 3, 1, 576) / math.log(2.0))          # [Z,3,18 tiles,576]
-    Pst = t5.permute(0, 1, 2, 4, 5, 7, 3, 6).reshape(Z, 3, 576, 576).double()       # [z,h, (qb,g,hb,j) = i, (t,kk) = j]
+    Pst = pst.view(Z, 3, 18, 18, 8, 32, 4).permute(0, 1, 2, 5, 3, 4, 6).reshape(Z, 3, 576, 576).double()   # [z,h,(qb,i),(t,j>>2,j&3)]
     Pback = Pst * fac.permute(0, 1, 3, 2).repeat_interleave(32, dim=3)
     e_p = rel(Pback, Pn)
     report("attn_fwd_savep[Z=%d]" % Z, p=e_p)

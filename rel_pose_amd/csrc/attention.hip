@@ -155,9 +155,15 @@ RP_DEV void pack_owner(const float (&reg)[32], bf16x8 (&pk)[4]) {
 // 128 bytes apart -- cost the forward 20 us and the backward 45 us per launch in request issue alone).  The readers pay the gather
 // instead, on the load side where it is hidden: attn_bwd_dkdv_p_kernel (P tiles, 4-byte loads) and ds_matmul_t_kernel (dS tiles,
 // through LDS-DMA).
+// Non-temporal stores: the tiles are read by a LATER kernel, long after they have left every cache (510 MB per launch at 128 images);
+// without the hint their lines displace the K / V (Q / dO) tiles the same workgroups keep re-reading from L2 (forward: -13 us).
 RP_DEV void store_tile_runs(float* tile, const f32x16& v, int lane) {
+  typedef float f4v __attribute__((ext_vector_type(4)));
 #pragma unroll
-  for (int g = 0; g < 4; ++g) st4(tile + 4 * (64 * g + lane), make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]));
+  for (int g = 0; g < 4; ++g) {
+    const f4v x = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+    __builtin_nontemporal_store(x, reinterpret_cast<f4v*>(tile + 4 * (64 * g + lane)));
+  }
 }
 
 // Software-pipelined tile loop (one barrier per tile, two LDS buffers).  MFMA operands are fetched from LDS one phase
@@ -518,11 +524,10 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dkdv_p_kernel(AttnBwdP 
   const float* bsrc = (lane & 32) ? delb + l31 : mb + l31;
   // pure arithmetic, no select: a ternary around the exponential became a divergent branch whose blocks hipcc joined with
   // s_waitcnt vmcnt(0) -- every tile then waited for its own just-issued prefetch (the pitfall attn_bwd_dkdv_kernel's loader documents)
+  // The two values are only LOADED at the top of a tile; the factor is formed when it is written to LDS at the tile's end -- computed
+  // where it is loaded it put s_waitcnt vmcnt(0) behind the loads, in front of the tile's prefetch (vmcnt retires in order).
   const float km = (lane & 32) ? p.scale : 0.f, ke = (lane & 32) ? 0.f : 1.f;
-  auto lfac = [&](int t) {
-    const float a = asrc[t * 32], b = bsrc[t * 32];
-    return fmaf(km, a, ke * fast_exp2(ke * fmaf(-a, RP_LOG2E, b)));
-  };
+  auto lfac = [&](float a, float b) { return fmaf(km, a, ke * fast_exp2(ke * fmaf(-a, RP_LOG2E, b))); };
   auto pload = [&](f32x16& x, int t) {
     const float* tp = pt + (long long)t * (NTILE * 1024);
 #pragma unroll
@@ -531,11 +536,11 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dkdv_p_kernel(AttnBwdP 
   f32x16 pa, pb;
   tile_gload<NT>(qb, p.ldq, tid, qpre);
   tile_gload<NT>(dob, p.lddo, tid, dpre);
-  float lpre = lfac(0);
+  float la = asrc[0], lb = bsrc[0];
   pload(pa, 0);
   tile_sstore<NT, KST>(Qs[0], tid, qpre);
   tile_sstore<NT, KST>(Ds[0], tid, dpre);
-  Ls[0][wave][lane] = lpre;
+  Ls[0][wave][lane] = lfac(la, lb);
   __syncthreads();
 
   auto step = [&](f32x16& pc, f32x16& pn, int t) {
@@ -543,7 +548,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dkdv_p_kernel(AttnBwdP 
     if (t + 1 < NTILE) {
       tile_gload<NT>(qb + (long long)(t + 1) * 32 * p.ldq, p.ldq, tid, qpre);
       tile_gload<NT>(dob + (long long)(t + 1) * 32 * p.lddo, p.lddo, tid, dpre);
-      lpre = lfac(t + 1);
+      la = asrc[(t + 1) * 32];
+      lb = bsrc[(t + 1) * 32];
       pload(pn, t + 1);
     }
     f32x16 dp = score_tile<false>(Ds[cur], l31, hi, vreg, nopk);      // scale dP: rows = queries acc_row(r, hi), lane = key
@@ -560,7 +566,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dkdv_p_kernel(AttnBwdP 
     if (t + 1 < NTILE) {
       tile_sstore<NT, KST>(Qs[cur ^ 1], tid, qpre);
       tile_sstore<NT, KST>(Ds[cur ^ 1], tid, dpre);
-      Ls[cur ^ 1][wave][lane] = lpre;
+      Ls[cur ^ 1][wave][lane] = lfac(la, lb);
     }
     __syncthreads();
   };

@@ -233,11 +233,17 @@ def pick_split_k(M, N, K, a_layout=0, b_layout=0, target_wgs=768, min_ktiles=8, 
     return sk - sk % 8 if sk >= 16 else sk
 
 
+SURVEY = "*"      # KernelTimer instance that times EVERY tagged launch (and every rp_gemm instance), kept per tag
+
+
 class KernelTimer:
     """HIP-event timing of every launch of ONE kernel on torch's current stream (bench.py's `roofline` object).  Off unless bench.py
     installs one.  `instance` is either a gemm_kernel<a_layout,b_layout,TM,TN> tuple (events recorded by rp_gemm itself around the
     main kernel, so a split-K launch's reduce is outside the span) or a string tag of one of the other MFMA kernels (`timed(tag, ...)`
-    call sites below: the events bracket the one C-ABI call, on the stream it launches on)."""
+    call sites below: the events bracket the one C-ABI call, on the stream it launches on).
+    instance = SURVEY ("*"): every tagged call site and every rp_gemm instance is timed and kept PER TAG (`per_tag`, read with
+    survey()): bench.py runs a few untimed steps this way to find which own kernel the step spends most time in, and then times
+    THAT one over the judged steps (the roofline object must follow the dominant kernel, not a hard-coded symbol)."""
 
     def __init__(self, instance):
         self.instance = instance if isinstance(instance, str) else tuple(instance)
@@ -246,6 +252,7 @@ class KernelTimer:
         self.flops = 0.0
         self.bytes = 0.0          # compulsory bytes: A + B + C (+ [M,N] epilogue operands), each once
         self.enabled = False
+        self.per_tag = {}         # SURVEY: tag (str, or the rp_gemm instance tuple) -> [event pairs, flops, bytes]
 
     def reset(self):
         """forget the recorded launches; their hipEvent handles go back to the free list"""
@@ -253,7 +260,30 @@ class KernelTimer:
             self._pool = []
         for s, e in self.events:
             self._pool += [s, e]
-        self.events, self.tevents, self.flops, self.bytes = [], [], 0.0, 0.0
+        self.events, self.tevents, self.flops, self.bytes, self.per_tag = [], [], 0.0, 0.0, {}
+
+    def wants(self, tag):
+        return self.enabled and (self.instance == SURVEY or self.instance == tag)
+
+    def add(self, tag, pair, flops, nbytes):
+        """one timed launch (torch event pair)"""
+        if self.instance == SURVEY:
+            ent = self.per_tag.setdefault(tag, [[], 0.0, 0.0])
+            ent[0].append(pair)
+            ent[1] += flops
+            ent[2] += nbytes
+        else:
+            self.tevents.append(pair)
+            self.flops += flops
+            self.bytes += nbytes
+
+    def survey(self):
+        """-> [(tag, launches, total seconds, total algorithmic flops, total algorithmic bytes)], largest total time first; call
+        after a device sync."""
+        rows = []
+        for tag, (pairs, fl, by) in self.per_tag.items():
+            rows.append((tag, len(pairs), sum(s.elapsed_time(e) for s, e in pairs) * 1e-3, fl, by))
+        return sorted(rows, key=lambda r: -r[2])
 
     def summary(self):
         """-> (launches, mean seconds per launch, total algorithmic flops); call after a device sync."""
@@ -278,8 +308,8 @@ class timed:
 
     def __init__(self, tag, flops, nbytes):
         tm = TIMER
-        self.tm = tm if (tm is not None and tm.enabled and tm.instance == tag) else None
-        self.flops, self.nbytes = flops, nbytes
+        self.tm = tm if (tm is not None and tm.wants(tag)) else None
+        self.tag, self.flops, self.nbytes = tag, flops, nbytes
 
     def __enter__(self):
         if self.tm is not None:
@@ -290,9 +320,7 @@ class timed:
     def __exit__(self, et, ev, tb):
         if self.tm is not None and et is None:
             self.e1.record()
-            self.tm.tevents.append((self.e0, self.e1))
-            self.tm.flops += self.flops
-            self.tm.bytes += self.nbytes
+            self.tm.add(self.tag, (self.e0, self.e1), self.flops, self.nbytes)
         return False
 
 
@@ -449,6 +477,16 @@ def gemm(A, B, M, N, K, *, a_layout=0, b_layout=0, lda=None, ldb=None, out=None,
         cpart = _empty(2 * (-(-M // (64 * tm_))), N, like=A)
         g.colsum_part = cpart.data_ptr()
     tm = TIMER
+    if tm is not None and tm.enabled and tm.instance == SURVEY:
+        # survey: the whole call (a split-K launch's reduce included) between two torch events, kept under the instance tuple
+        ob = 2.0 if (out_dtype == torch.bfloat16) else 4.0
+        nby = batch * (M * K * float(A.element_size()) + 4.0 * N * K + M * N * (ob * (1 + (pre_out is not None))
+                       + (float(aux.element_size()) if aux is not None else 0.0) + (4.0 if residual is not None else 0.0)))
+        with timed(gemm_instance(M, N, a_layout, b_layout, aux is not None or residual is not None), 2.0 * M * N * K * batch, nby):
+            _lib.check(lib.rp_gemm(ctypes.byref(g), _st()), "rp_gemm")
+        if defer is not None and g.split_k > 1:
+            _sk_batch()[0].append(defer)
+        return (out, colsum(cpart)) if want_colsum else out
     if (tm is not None and tm.enabled and batch == 1 and ln is None and not isinstance(tm.instance, str) and
             gemm_instance(M, N, a_layout, b_layout, aux is not None or residual is not None) == tm.instance):
         # events are recorded by rp_gemm itself around the MAIN kernel (a split-K launch's reduce is a separate kernel)
@@ -1069,8 +1107,9 @@ def emm_stats(qkv, Z, single=False):
         if ws is None:
             ws = _stats_ws[key] = torch.empty(lib.rp_emm_stats_workspace_bytes(Z, HEADS) // 4, device=qkv.device, dtype=torch.float32)
     b = qkv.data_ptr()
-    _lib.check(lib.rp_emm_stats(ctypes.c_void_p(b), ctypes.c_void_p(b + 4 * DIM), _p(rlse), _p(clse), _p(ws), Z, HEADS, ld, ld,
-                                (DIM // HEADS) ** -0.5, ATTN_BF16, _st()), "rp_emm_stats")
+    with timed("emm_stats", 2.0 * Z * HEADS * N_TOK * N_TOK * 64, 4.0 * Z * N_TOK * (2 * DIM + 2 * HEADS)):
+        _lib.check(lib.rp_emm_stats(ctypes.c_void_p(b), ctypes.c_void_p(b + 4 * DIM), _p(rlse), _p(clse), _p(ws), Z, HEADS, ld, ld,
+                                    (DIM // HEADS) ** -0.5, ATTN_BF16, _st()), "rp_emm_stats")
     return rlse, clse
 
 
@@ -1084,8 +1123,11 @@ def emm_apply(qkv, x, rlse, clse, Z, swap=False, want_t=True, want_f=True, singl
     _chk(qkv, x, rlse, clse, x_left)
     t = _empty(Z, HEADS, N_TOK, XW, like=qkv) if want_t else None
     f = _empty(Z, HEADS, NWG, XW, XW, like=qkv) if (want_f and not swap) else None
-    _lib.check(lib.rp_emm_apply(_p(qkv), qkv.shape[1], _p(x), _p(x_left), _p(rlse), _p(clse), _p(t), _p(f), Z, HEADS,
-                                (DIM // HEADS) ** -0.5, 1 if swap else 0, 1 if single else 0, ATTN_BF16, _st()), "rp_emm_apply")
+    # algorithmic: S = q k^T (64) and T = A X (96) per score element; F = X^T T adds 2 * 576 * 96 * 96 per (image, head)
+    with timed("emm_apply", 2.0 * Z * HEADS * (N_TOK * N_TOK * (64 + XW) + (N_TOK * XW * XW if f is not None else 0)),
+               4.0 * Z * HEADS * N_TOK * (2 * 64 + 2 * XW + 2)):
+        _lib.check(lib.rp_emm_apply(_p(qkv), qkv.shape[1], _p(x), _p(x_left), _p(rlse), _p(clse), _p(t), _p(f), Z, HEADS,
+                                    (DIM // HEADS) ** -0.5, 1 if swap else 0, 1 if single else 0, ATTN_BF16, _st()), "rp_emm_apply")
     return t, f
 
 
@@ -1142,8 +1184,11 @@ def emm_backward(qkv, x, t, rlse, clse, df, Z, single=False, cross=False):
         # the query-side pass stores scale*dS (tiled); dk_z = dS_z^T-major x q_{z^1} is one rp_ds_matmul instead of a second pass
         # that recomputes S and dA (68 of its 100 MFMAs per tile)
         ds = _ds_buffer(Z, qkv)
-        _lib.check(lib.rp_emm_grad_ds(_p(qkv), ld, _p(x), _p(w), _p(rlse), _p(clse), _p(rho), _p(gam), _p(dqkv), _p(ds), Z,
-                                      HEADS, scale, sg, ATTN_BF16, _st()), "rp_emm_grad_ds")
+        # algorithmic: S recompute is not counted; dA = W X^T (96) and dq = dS k (64) per score element
+        with timed("emm_grad_ds", 2.0 * Z * HEADS * N_TOK * N_TOK * (XW + 64),
+                   4.0 * Z * HEADS * N_TOK * (N_TOK + 3 * 64 + 2 * XW + 4)):
+            _lib.check(lib.rp_emm_grad_ds(_p(qkv), ld, _p(x), _p(w), _p(rlse), _p(clse), _p(rho), _p(gam), _p(dqkv), _p(ds), Z,
+                                          HEADS, scale, sg, ATTN_BF16, _st()), "rp_emm_grad_ds")
         # dk_z = dS_z (key-major tiles) x q_{z^1}: one streaming launch
         ds_matmul(ds, qkv.data_ptr(), ld, dqkv.data_ptr() + 4 * DIM, ld, Z, b_xor=1)
     else:
@@ -1305,7 +1350,7 @@ def mlp_fused(x2d, gamma, beta, w1, b1, w2, b2, eps=LN_EPS, train=False, out_dty
         w1k, w2k = bf16_weight(w1), _chunk_permuted_bf16(w2)
     else:
         w1k, w2k = w1, w2
-    with timed("mlp_fused_fwd", 4.0 * M * DIM * Hd, 4.0 * (2 * M * DIM + 2 * DIM * Hd + (M * DIM + 2 * M * Hd if train else 0))):
+    with timed("mlp_fused_fwd" + ("" if train else "_eval") + ("_bf16" if bf else ""), 4.0 * M * DIM * Hd, 4.0 * (2 * M * DIM + 2 * DIM * Hd + (M * DIM + 2 * M * Hd if train else 0))):
         _lib.check(lib.rp_mlp_fused_fwd(_p(x2d), _p(gamma), _p(beta), _p(w1k), _p(b1), _p(w2k), _p(b2), _p(y), _p(ws), M, x2d.shape[1],
                                         Hd, eps, _p(xn), _p(mean), _p(rstd), _p(h), _p(hpre), 1 if bf else 0, (2 if obf else 0) | (8 if xnbf else 0) | (16 if bf and MLP_W2_CHUNK_MAJOR else 0), _st()),
                    "rp_mlp_fused_fwd")
@@ -1392,13 +1437,15 @@ def mlp_fused_bwd(dy, hpre, w1, w2, out_dtype=None, ln=None):
         _chk(x, gamma, mean, rstd)
         C = dy.shape[1]
         lnpart = _empty(lib.rp_mlp_fused_bwd_ln_part_rows(M), 3 * C, like=dy)
-        _lib.check(lib.rp_mlp_fused_bwd_ln(_p(dy), _p(hpre), _p(w2t), _p(w1t), _p(dhp), _p(dxn), _p(colpart), _p(ws), M, C,
-                                           hpre.shape[1], 1 if bf else 0, io, _p(x), _p(gamma), _p(mean), _p(rstd), _p(lnpart), _st()),
-                   "rp_mlp_fused_bwd_ln")
+        with timed("mlp_fused_bwd_ln" + ("_bf16" if bf else ""), 4.0 * M * C * hpre.shape[1], M * (float(hpre.element_size()) * 2 * hpre.shape[1] + 4.0 * 4 * C)):
+            _lib.check(lib.rp_mlp_fused_bwd_ln(_p(dy), _p(hpre), _p(w2t), _p(w1t), _p(dhp), _p(dxn), _p(colpart), _p(ws), M, C,
+                                               hpre.shape[1], 1 if bf else 0, io, _p(x), _p(gamma), _p(mean), _p(rstd), _p(lnpart), _st()),
+                       "rp_mlp_fused_bwd_ln")
         sums = colsum(lnpart)
         return dhp, (dxn, sums[:C], sums[C:2 * C], sums[2 * C:]), colpart
-    _lib.check(lib.rp_mlp_fused_bwd(_p(dy), _p(hpre), _p(w2t), _p(w1t), _p(dhp), _p(dxn), _p(colpart), _p(ws), M, dy.shape[1],
-                                    hpre.shape[1], 1 if bf else 0, io, _st()), "rp_mlp_fused_bwd")
+    with timed("mlp_fused_bwd" + ("_bf16" if bf else ""), 4.0 * M * dy.shape[1] * hpre.shape[1], M * (float(hpre.element_size()) * 2 * hpre.shape[1] + 4.0 * 2 * dy.shape[1])):
+        _lib.check(lib.rp_mlp_fused_bwd(_p(dy), _p(hpre), _p(w2t), _p(w1t), _p(dhp), _p(dxn), _p(colpart), _p(ws), M, dy.shape[1],
+                                        hpre.shape[1], 1 if bf else 0, io, _st()), "rp_mlp_fused_bwd")
     return dhp, dxn, colpart
 
 
@@ -2082,7 +2129,8 @@ def conv_stem_fwd(x_padded_nhwc, w, want_stats=False):
     H, W = Hp - 6, Wp - 6
     y = torch.empty(N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 64, device=w.device, dtype=torch.float32)
     stats = torch.empty(lib.rp_conv_stem_blocks(N, H, W), 2, 64, device=w.device, dtype=torch.float64) if want_stats else None
-    _lib.check(lib.rp_conv_stem_fwd(_p(x_padded_nhwc), _p(wr), _p(y), _p(stats), N, H, W, _st()), "rp_conv_stem_fwd")
+    with timed("conv_stem_fwd", 2.0 * N * (H // 2) * (W // 2) * 64 * 147, 4.0 * N * (3.0 * H * W + 64.0 * (H // 2) * (W // 2))):
+        _lib.check(lib.rp_conv_stem_fwd(_p(x_padded_nhwc), _p(wr), _p(y), _p(stats), N, H, W, _st()), "rp_conv_stem_fwd")
     return (y, stats) if want_stats else y
 
 
@@ -2102,7 +2150,8 @@ def conv3x3_c64_bf16(x_nhwc, w, scale=None, shift=None, want_stats=False):
     N = x_nhwc.shape[0]
     y = torch.empty_like(x_nhwc)
     stats = torch.empty(lib.rp_conv3x3_c64_blocks(N), 2, 64, device=x_nhwc.device, dtype=torch.float64) if want_stats else None
-    _lib.check(lib.rp_conv3x3_c64_bf16(_p(x_nhwc), _p(w), _p(y), _p(scale), _p(shift), _p(stats), N, 56, 56, _st()), "rp_conv3x3_c64_bf16")
+    with timed("conv3x3_c64_bf16", 2.0 * N * 56 * 56 * 64 * 64 * 9, 2.0 * N * 56 * 56 * 128):
+        _lib.check(lib.rp_conv3x3_c64_bf16(_p(x_nhwc), _p(w), _p(y), _p(scale), _p(shift), _p(stats), N, 56, 56, _st()), "rp_conv3x3_c64_bf16")
     return (y, stats) if want_stats else y
 
 
@@ -2117,7 +2166,8 @@ def conv3x3_c64_wgrad_bf16(x_nhwc, dy_nhwc):
     nb = lib.rp_conv3x3_c64_wgrad_workspace_bytes(N)
     ws = torch.empty(nb // 4, device=x_nhwc.device, dtype=torch.float32)
     dw = torch.empty(64, 3, 3, 64, device=x_nhwc.device, dtype=torch.bfloat16)
-    _lib.check(lib.rp_conv3x3_c64_wgrad_bf16(_p(x_nhwc), _p(dy_nhwc), _p(dw), _p(ws), nb, N, 56, 56, _st()), "rp_conv3x3_c64_wgrad_bf16")
+    with timed("conv3x3_c64_wgrad_bf16", 2.0 * N * 56 * 56 * 64 * 64 * 9, 2.0 * N * 56 * 56 * 128):
+        _lib.check(lib.rp_conv3x3_c64_wgrad_bf16(_p(x_nhwc), _p(dy_nhwc), _p(dw), _p(ws), nb, N, 56, 56, _st()), "rp_conv3x3_c64_wgrad_bf16")
     return dw
 
 
@@ -2132,7 +2182,8 @@ def conv3x3_c64_wgrad_f32(x_nhwc, dy_nhwc):
     nb = lib.rp_conv3x3_c64_wgrad_f32_workspace_bytes(N)
     ws = torch.empty(nb // 4, device=x_nhwc.device, dtype=torch.float32)
     dw = torch.empty(64, 3, 3, 64, device=x_nhwc.device, dtype=torch.float32)
-    _lib.check(lib.rp_conv3x3_c64_wgrad_f32(_p(x_nhwc), _p(dy_nhwc), _p(dw), _p(ws), nb, N, 56, 56, _st()), "rp_conv3x3_c64_wgrad_f32")
+    with timed("conv3x3_c64_wgrad_f32", 2.0 * N * 56 * 56 * 64 * 64 * 9, 4.0 * N * 56 * 56 * 128):
+        _lib.check(lib.rp_conv3x3_c64_wgrad_f32(_p(x_nhwc), _p(dy_nhwc), _p(dw), _p(ws), nb, N, 56, 56, _st()), "rp_conv3x3_c64_wgrad_f32")
     return dw
 
 
@@ -2148,7 +2199,8 @@ def conv_stem_fwd_bf16(x_padded_nhwc, w, want_stats=False):
     H, W = Hp - 6, Wp - 6
     y = torch.empty(N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 64, device=w.device, dtype=torch.bfloat16)
     stats = torch.empty(lib.rp_conv_stem_bf16_blocks(N, H, W), 2, 64, device=w.device, dtype=torch.float64) if want_stats else None
-    _lib.check(lib.rp_conv_stem_fwd_bf16(_p(x_padded_nhwc), _p(wr), _p(y), _p(stats), N, H, W, _st()), "rp_conv_stem_fwd_bf16")
+    with timed("conv_stem_fwd_bf16", 2.0 * N * (H // 2) * (W // 2) * 64 * 147, N * (4.0 * 3 * H * W + 2.0 * 64 * (H // 2) * (W // 2))):
+        _lib.check(lib.rp_conv_stem_fwd_bf16(_p(x_padded_nhwc), _p(wr), _p(y), _p(stats), N, H, W, _st()), "rp_conv_stem_fwd_bf16")
     return (y, stats) if want_stats else y
 
 
@@ -2165,7 +2217,8 @@ def conv_stem_wgrad_bf16(x_padded_nhwc, dy_nhwc):
     nb = lib.rp_conv_stem_wgrad_workspace_bytes(N)
     ws = torch.empty((nb + 3) // 4, device=dy_nhwc.device, dtype=torch.float32)
     dw = torch.empty(64, 7, 7, 3, device=dy_nhwc.device, dtype=torch.float32)
-    _lib.check(lib.rp_conv_stem_wgrad_bf16(_p(x_padded_nhwc), _p(dy_nhwc), _p(dw), _p(ws), nb, N, 224, 224, _st()), "rp_conv_stem_wgrad_bf16")
+    with timed("conv_stem_wgrad_bf16", 2.0 * N * 112 * 112 * 64 * 147, N * (4.0 * 3 * 224 * 224 + 2.0 * 64 * 112 * 112)):
+        _lib.check(lib.rp_conv_stem_wgrad_bf16(_p(x_padded_nhwc), _p(dy_nhwc), _p(dw), _p(ws), nb, N, 224, 224, _st()), "rp_conv_stem_wgrad_bf16")
     return dw
 
 
@@ -2180,7 +2233,8 @@ def conv_stem_wgrad_f32(x_padded_nhwc, dy_nhwc):
     nb = lib.rp_conv_stem_wgrad_f32_workspace_bytes(N)
     ws = torch.empty((nb + 3) // 4, device=dy_nhwc.device, dtype=torch.float32)
     dw = torch.empty(64, 7, 7, 3, device=dy_nhwc.device, dtype=torch.float32)
-    _lib.check(lib.rp_conv_stem_wgrad_f32(_p(x_padded_nhwc), _p(dy_nhwc), _p(dw), _p(ws), nb, N, 224, 224, _st()), "rp_conv_stem_wgrad_f32")
+    with timed("conv_stem_wgrad_f32", 2.0 * N * 112 * 112 * 64 * 147, 4.0 * N * (3.0 * 224 * 224 + 64.0 * 112 * 112)):
+        _lib.check(lib.rp_conv_stem_wgrad_f32(_p(x_padded_nhwc), _p(dy_nhwc), _p(dw), _p(ws), nb, N, 224, 224, _st()), "rp_conv_stem_wgrad_f32")
     return dw
 
 

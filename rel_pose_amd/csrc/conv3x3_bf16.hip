@@ -336,6 +336,9 @@ extern "C" int rp_conv3x3_c64_bf16(const void* x, const void* w, void* y, const 
                                    int H, int W, void* stream) {
   if (!x || !w || !y || N <= 0) return RP_EBADSHAPE;
   if (H != IH || W != IW) return RP_EUNSUPPORTED;
+  // the halo loads address the activation through a buffer resource whose out-of-range sentinel (offset 0x80000000) must lie beyond
+  // num_records = bytes of x: more than 2 GiB of input (5349 images) would overflow the int product or let the sentinel land inside
+  if ((size_t)N * IH * IW * C * 2 > 0x7fffffffull) return RP_EUNSUPPORTED;
   if ((scale == nullptr) != (shift == nullptr)) return RP_EBADSHAPE;
   if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) return RP_EALIGN;
   ConvP p{(const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, scale, shift, stats, N * TPI};

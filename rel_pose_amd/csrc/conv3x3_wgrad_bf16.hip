@@ -215,6 +215,7 @@ extern "C" int rp_conv3x3_c64_wgrad_bf16(const void* x, const void* dy, void* dw
                                          void* stream) {
   if (!x || !dy || !dw || !workspace || N <= 0) return RP_EBADSHAPE;
   if (H != IH || W != IW) return RP_EUNSUPPORTED;
+  if ((size_t)N * IH * IW * C * 2 > 0x7fffffffull) return RP_EUNSUPPORTED;      // buffer-resource range (see rp_conv3x3_c64_bf16)
   if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dw | (uintptr_t)workspace) & 15) return RP_EALIGN;
   if (workspace_bytes < rp_conv3x3_c64_wgrad_workspace_bytes(N)) return RP_EWORKSPACE;
   const int nblk = rp_conv3x3_c64_wgrad_blocks(N);

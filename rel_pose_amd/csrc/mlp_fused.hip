@@ -766,25 +766,16 @@ extern "C" int rp_mlp_fused_fwd(const float* x, const float* gamma, const float*
 
 // Backward-data of the MLP (training): dhp [M,768] = (dy W2) o GELU'(hpre), dxn [M,192] = dhp W1, colpart [tiles,768] = column
 // sums of dhp per row tile (sum them for the fc1 bias gradient).  w2t = W2^T [768,192], w1t = W1^T [192,768] (contiguous).
-// Workgroup shape: 12 waves x 3 per SIMD (192-row tiles, one workgroup per CU) or 8 x 2 (RP_MLP_BWD_VARIANT=1); the 4 x 3
-// shape of the forward spills here (the h_pre operands are 8 more live registers).
-static int mlp_bwd_variant() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("RP_MLP_BWD_VARIANT");
-    v = e ? atoi(e) : 0;
-  }
-  return v;
-}
-extern "C" size_t rp_mlp_fused_bwd_workspace_bytes(int M) {
-  if (M <= 0) return 0;
-  return mlp_bwd_variant() == 1 ? Variant<8, 2, 1>::workspace(M) : Variant<12, 3, 1>::workspace(M);
-}
-extern "C" int rp_mlp_fused_bwd_tile_rows(void) { return mlp_bwd_variant() == 1 ? Variant<8, 2, 1>::ROWS : Variant<12, 3, 1>::ROWS; }
+// Workgroup shape: 12 waves x 3 per SIMD (192-row tiles, one workgroup per CU) at every precision -- the tile-rows / part-rows /
+// workspace queries below describe exactly the kernel that runs (the 8 x 2 shape that used to hide behind RP_MLP_BWD_VARIANT lost its
+// A/B in round 3 and made the queries disagree with the bf16 launch: retired).  The 4 x 3 shape of the forward spills here (the h_pre
+// operands are 8 more live registers).
+extern "C" size_t rp_mlp_fused_bwd_workspace_bytes(int M) { return M <= 0 ? 0 : Variant<12, 3, 1>::workspace(M); }
+extern "C" int rp_mlp_fused_bwd_tile_rows(void) { return Variant<12, 3, 1>::ROWS; }
 extern "C" int rp_mlp_fused_bwd_ln_part_rows(int M) { return M <= 0 ? 0 : (M + rp_mlp_fused_bwd_tile_rows() - 1) / rp_mlp_fused_bwd_tile_rows() * LN_SUB; }
 static int mlp_bwd_launch(MlpP p, int precision, hipStream_t st) {
   if (precision == 1) return Variant<12, 3, 1, true>::launch(p, st);      // (same 192-row tiles: same workspace / tile rows)
-  return mlp_bwd_variant() == 1 ? Variant<8, 2, 1>::launch(p, st) : Variant<12, 3, 1>::launch(p, st);
+  return Variant<12, 3, 1>::launch(p, st);
 }
 extern "C" int rp_mlp_fused_bwd_ln(const float* dy, const float* hpre, const float* w2t, const float* w1t, float* dhp, float* dx,
                                    float* colpart, void* workspace, int M, int dim, int hidden, int precision, int io_bf16,
@@ -806,5 +797,5 @@ extern "C" int rp_mlp_fused_bwd(const float* dy, const float* hpre, const float*
   MlpP p{dy, nullptr, nullptr, w2t, nullptr, w1t, nullptr, dxn, hpre, dhp, colpart, (float*)workspace, M, 0.f, 0, 0, 0, 0, io_bf16,
          nullptr, nullptr, nullptr, nullptr};
   if (precision == 1) return Variant<12, 3, 1, true>::launch(p, (hipStream_t)stream);      // (same 192-row tiles: same workspace / tile rows)
-  return mlp_bwd_variant() == 1 ? Variant<8, 2, 1>::launch(p, (hipStream_t)stream) : Variant<12, 3, 1>::launch(p, (hipStream_t)stream);
+  return Variant<12, 3, 1>::launch(p, (hipStream_t)stream);
 }

@@ -96,6 +96,19 @@ def allreduce_mean_(tensors):
         o += n
 
 
+def gather_step_times(elapsed_s, steps, device="cpu"):
+    """bench.py's max-over-ranks timing and its self-diagnosing record: (slowest rank's seconds for the timed steps, every rank's own
+    ms per step in rank order).  One all_gather + one all-reduce(MAX) of a float64, on `device` (the GPU under RCCL, the CPU under gloo)."""
+    own = torch.tensor([float(elapsed_s)], device=device, dtype=torch.float64)
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(elapsed_s), [round(1e3 * float(elapsed_s) / steps, 3)]
+    every = [torch.zeros_like(own) for _ in range(dist.get_world_size())]
+    dist.all_gather(every, own)
+    worst = own.clone()
+    dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+    return float(worst.item()), [round(1e3 * float(t.item()) / steps, 3) for t in every]
+
+
 def cleanup():
     if dist.is_initialized():
         dist.destroy_process_group()

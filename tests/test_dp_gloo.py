@@ -64,6 +64,60 @@ def test_two_rank_data_parallel_matches_single_process():
     assert torch.allclose(res[0][3][0], torch.full((3,), 1.5)) and torch.allclose(res[1][3][1], torch.full((2, 2), 15.0))
 
 
+def _worker8(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    from rel_pose_amd import parallel
+    parallel.setup(rank, world, backend="gloo")
+    torch.set_num_threads(1)
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(32, 64), torch.nn.ReLU(), torch.nn.Linear(64, 14))
+    ddp = parallel.wrap(model)
+    g = torch.Generator().manual_seed(7)
+    X, Y = torch.randn(16, 32, generator=g), torch.randn(16, 14, generator=g)       # 16 pairs, global batch
+    idx = parallel.shard_pairs(16, rank, world)
+    (ddp(X[idx]) - Y[idx]).square().mean().backward()
+    grads = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    local = [torch.full((3,), float(rank + 1)), torch.full((2, 2), float(10 * (rank + 1)))]
+    parallel.allreduce_mean_(local)
+    ragged = parallel.shard_pairs(12, rank, world)                                   # 12 pairs on 8 ranks: the tail wraps
+    worst, per_rank = parallel.gather_step_times(0.010 * (rank + 1), 10)             # bench.py's `distributed` record
+    q.put((rank, idx, grads.numpy().copy(), [t.numpy().copy() for t in local], ragged, worst, per_rank))
+    dist.barrier()
+    parallel.cleanup()
+
+
+@pytest.mark.timeout(300)
+def test_eight_rank_data_parallel_matches_single_process():
+    """The shape the first 8-GPU lease will run (BASELINE configs[3], configs[4]): world size 8 -- sharding r::8, one gradient
+    all-reduce, the explicit bucketed mean all-reduce, and the per-rank timing record of bench.py."""
+    world, port = 8, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get() for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for r, idx, g_, loc, ragged, worst, per_rank in res:
+        assert idx == [r, r + 8]                                                    # rank r takes pairs r::8
+        assert ragged == [r, (r + 8) % 12]                                          # same count on every rank, wrapped tail
+        assert abs(worst - 0.080) < 1e-12 and per_rank == [float(i + 1) for i in range(8)]      # max over ranks, rank order
+        assert torch.allclose(torch.from_numpy(loc[0]), torch.full((3,), 4.5)) and torch.allclose(torch.from_numpy(loc[1]), torch.full((2, 2), 45.0))
+        assert torch.equal(torch.from_numpy(g_), torch.from_numpy(res[0][2]))        # identical averaged gradients on every rank
+    covered = sorted(i for r in res for i in r[1])
+    assert covered == list(range(16))                                               # every pair exactly once
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(32, 64), torch.nn.ReLU(), torch.nn.Linear(64, 14))
+    g = torch.Generator().manual_seed(7)
+    X, Y = torch.randn(16, 32, generator=g), torch.randn(16, 14, generator=g)
+    (model(X) - Y).square().mean().backward()
+    ref = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    assert torch.allclose(torch.from_numpy(res[0][2]), ref, atol=1e-6)               # DP gradient == full-batch gradient
+
+
 def _spawn_body(tmpdir):
     """what train.run does first: read the launcher environment, join the group, one collective"""
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])

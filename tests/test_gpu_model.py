@@ -1,8 +1,9 @@
 """Module- and model-level parity on the GPU: Block / CrossBlock / ViT stack / head / full ViTEss against the CPU
 oracle (fp64) and against the reference's own outputs (tests/golden).  Stated tolerances:
-  * features (final LayerNorm output)  <= 1e-3 of max|ref|   (the reference's own fp32-vs-fp64 gap is 2-3e-4)
+  * features (final LayerNorm output)  <= 8e-6 of max|ref|   (measured 7.5e-7; the reference's own fp32-vs-fp64 gap is 8.3e-7)
   * R,t (pose slot 1)                  <= 1e-4 relative       (BASELINE.json north_star)
-  * gradients                          <= 1e-3 of max|ref| per tensor
+  * gradients                          <= 2.5e-5 of max|ref| per tensor on the hot path (measured 2.2e-6): <= ~10x the errors
+    profiles/r5_test_report.txt records, so that a change costing a decimal digit fails
 """
 import json
 import os
@@ -70,7 +71,7 @@ def test_block_and_crossblock_forward(model, states):
         r5 = O.cross_block(sd64, "fusion_transformer.blocks.5.", r0, intr24(torch.float64))
         e5 = rel(y5, r5)
     report("block_fwd", block=e0, crossblock=e5)
-    assert e0 < 2e-5 and e5 < 2e-4
+    assert e0 < 4e-6 and e5 < 8e-6          # measured 3.2e-7 / 7.5e-7 (profiles/r5_test_report.txt): <= ~10x, a lost digit fails
 
 
 def test_vit_stack_matches_reference_outputs(model, states, golden):
@@ -92,8 +93,8 @@ def test_vit_stack_matches_reference_outputs(model, states, golden):
     t_err, q_err, ang = O.pose_errors(pose.cpu(), torch.as_tensor(golden["pose_from_tokens_f64"]))
     ref_gap = rel(golden["vit_feat_f32"], golden["vit_feat_f64"])
     report("vit_stack_vs_reference", block4=e4, feats=ef, t=t_err, q=q_err, ang=ang, ref_fp32_gap=ref_gap)
-    assert e4 < 1e-4
-    assert ef < 1e-3
+    assert e4 < 6e-6                          # measured 5.1e-7
+    assert ef < 8e-6                          # measured 7.5e-7 (the reference's own fp32-vs-fp64 gap on these features: 8.3e-7)
     assert max(t_err, q_err) < 1e-4 and ang < 2e-4
     assert torch.equal(pose[:, 0].cpu(), Gs[:, 0].cpu())                 # slot 0 passthrough is bit-exact
 
@@ -130,7 +131,7 @@ def test_full_stack_backward_vs_oracle(model, states, golden):
             if name.startswith("fusion_transformer") or name.startswith("pose_regressor"):
                 assert p.grad is not None, name
                 worst[name] = rel(p.grad, sd[name].grad)
-        bad = {k: v for k, v in worst.items() if v > 1e-3}
+        bad = {k: v for k, v in worst.items() if v > 2.5e-5}       # measured worst 2.2e-6 (a norm1.weight): 10x
         top = sorted(worst.items(), key=lambda kv: -kv[1])[:5]
         report("stack_backward", max=max(worst.values()), tokens=e_tok)
         with open(os.path.join(ROOT, "gpurun_out", "test_report.txt"), "a") as f:
@@ -172,9 +173,9 @@ def test_feature_backward_vs_reference_golden(model, golden):
                       abs(got[2] - ref[i][2]) / max(ref[i][2], 1e-30),
                       np.abs(got[3:] - ref[i][3:]).max() / max(np.abs(ref[i][3:]).max(), 1e-30))
             worst = max(worst, err)
-            assert err < 2e-3, (n, err)
+            assert err < 8e-5, (n, err)           # measured worst 7.7e-6 (summaries of the reference's fp64 gradients)
         report("feature_backward_vs_reference", tokens=e_tok, params=worst)
-        assert e_tok < 1e-3
+        assert e_tok < 1.5e-5                     # measured 1.5e-6
     finally:
         model.eval()
 
@@ -194,7 +195,7 @@ def test_full_model_forward_vs_reference(model, golden, tag, B, H, W, key):
     e_tok = rel(toks.reshape(-1)[::101], golden["full_%s_tokens_sub_f32" % tag])
     t_err, q_err, ang = O.pose_errors(out[0].data.cpu(), torch.as_tensor(golden["full_%s_pose_f64" % tag]))
     report("full_model_" + tag, tokens=e_tok, t=t_err, q=q_err, ang=ang)
-    assert e_tok < 1e-3                   # MIOpen vs CPU convolution order
+    assert e_tok < 1.5e-5                 # MIOpen vs CPU convolution order: measured 9.2e-7 / 1.3e-6
     assert max(t_err, q_err) < 1e-4
     # inference=True returns numpy [2,7] of element 0 (src/model.py:155-156)
     with torch.no_grad():
@@ -265,7 +266,7 @@ def test_full_size_backward_config3(model, states):
                 assert p.grad is not None, name
                 worst[name] = rel(p.grad, R * sd[name].grad)
         report("config3_backward_64pairs", t=t_err, q=q_err, max_grad=max(worst.values()), tokens=e_tok, pair_copies=indep)
-        bad = {k: v for k, v in worst.items() if v > 1e-3}
+        bad = {k: v for k, v in worst.items() if v > 2.5e-5}       # measured worst 2.0e-6
         assert max(t_err, q_err) < 1e-4 and not bad, bad
     finally:
         model.eval()
@@ -305,7 +306,7 @@ def _compare_all_trainable(model, sd, sd_f32, scale, tag):
             continue
         cnn = name.startswith("resnet") or name.startswith("extractor")
         worst[name] = rel(p.grad, scale * ref)
-        tol_used[name] = max(1e-3, min(5e-2, rel(sd_f32[name].grad, ref))) if cnn else 1e-3
+        tol_used[name] = max(1e-3, min(5e-2, rel(sd_f32[name].grad, ref))) if cnn else 4e-5      # hot path measured 3.7e-6 / 1.6e-6
         if cnn:
             cnn_worst = max(cnn_worst, worst[name])
     top = sorted(worst.items(), key=lambda kv: -kv[1])[:6]
@@ -456,7 +457,7 @@ def test_ablation_variants_fwd_bwd_vs_reference(states, golden, tag):
     e_w = float(np.abs(g[:16].numpy() - ref[3:]).max() / np.abs(ref[3:]).max())
     e_l1 = abs(float(g.abs().sum()) - ref[1]) / ref[1]
     report("variant_" + tag, feats=e_f, grad_tokens=e_g, grad_qkv16=e_w, grad_qkv_l1=e_l1)
-    assert e_f < 1e-3 and e_g < 1e-3 and e_w < 2e-3 and e_l1 < 1e-3
+    assert e_f < 1e-5 and e_g < 2.5e-5 and e_w < 4e-5 and e_l1 < 5e-6      # measured <= 9.7e-7 / 2.1e-6 / 4.0e-6 / 2.7e-7 over the four variants
 
 
 @pytest.mark.parametrize("B", [1, 3])
@@ -479,7 +480,7 @@ def test_odd_batch_sizes_fwd_bwd(model, states, B):
         e_tok = rel(fmap.grad.view(2 * B, 192, 576).permute(0, 2, 1), gtok)
         e_w = rel(model.pose_regressor[0].weight.grad, sd["pose_regressor.0.weight"].grad)
         report("odd_batch_%d" % B, t=t_err, q=q_err, grad_tokens=e_tok, grad_reg0=e_w)
-        assert max(t_err, q_err) < 1e-4 and e_tok < 1e-3 and e_w < 1e-3
+        assert max(t_err, q_err) < 1e-4 and e_tok < 2e-5 and e_w < 1.5e-5      # measured 1.5e-6 / 1.1e-6
     finally:
         model.eval()
 
@@ -536,7 +537,7 @@ def test_noess_fwd_bwd_vs_reference(golden_noess, train):
         errs.append(max(float(np.abs(g[:16].numpy() - r[3:]).max() / np.abs(r[3:]).max()),
                         abs(float(g.abs().sum()) - r[1]) / r[1]))
     report("noess_" + tag, t=t_err, q=q_err, grad_tokens=e_g, grad_params=max(errs))
-    assert max(t_err, q_err) < 1e-4 and e_g < 1e-3 and max(errs) < 2e-3
+    assert max(t_err, q_err) < 1e-4 and e_g < 2.5e-5 and max(errs) < 6e-5      # measured 2.3e-6 / 5.9e-6
 
 
 def test_noess_features_and_full_model(golden_noess):
@@ -555,7 +556,7 @@ def test_noess_features_and_full_model(golden_noess):
         pose = m(imgs, SE3(torch.tensor([0, 0, 0, 0, 0, 0, 1.0]).repeat(2, 2, 1).cuda()), intrinsics=intr)[0].data
     t_err, q_err, ang = O.pose_errors(pose.cpu(), torch.from_numpy(golden_noess["noess_full_sq_pose_f64"]))
     report("noess_full", feats=e_f, t=t_err, q=q_err)
-    assert e_f < 1e-3 and max(t_err, q_err) < 1e-4     # same bounds as the default model
+    assert e_f < 8e-6 and max(t_err, q_err) < 1e-4     # same bounds as the default model (measured 6.1e-7)
 
 
 def test_bf16_operand_mode_is_a_different_precision(model, states):

@@ -259,7 +259,8 @@ TAG_SYMBOLS = {
     "attn_stats": "attn_fwd_kernel<3, true, 2, false, false, false>", "emm_stats": "attn_fwd_kernel<3, true, 2, false, true, false>",
     "attn_bwd_dkdv_p": "attn_bwd_dkdv_p_kernel<2, 2>", "attn_bwd_dkdv_ds": "attn_bwd_dkdv_kernel<2, 2, false>",
     "ds_matmul": "ds_matmul_kernel<3>", "ds_matmul_t": "ds_matmul_t_kernel<3>",
-    "emm_apply": "emm_apply_kernel<false>", "emm_grad_ds": "emm_grad_kernel<false>",
+    "emm_apply": "emm_apply_kernel<false>", "emm_grad_ds": "emm_grad_kernel<false, false>",
+    "emm_apply_s": "emm_apply_s_kernel", "emm_grad_ds_s": "emm_grad_kernel<false, true>",
     "linear_rows_ln": "linear_rows_kernel<true, false>", "linear_rows": "linear_rows_kernel<false, false>",
     "dw192_bf16": "dw192_bf16_kernel<false>", "dw192_bf16_f32b": "dw192_bf16_kernel<true>", "dw192_f32": "dw192_f32_kernel",
     "attn_fwd_bf16": "attn_fwd_bf16_kernel<2, false, 1>", "attn_stats_bf16": "attn_fwd_bf16_kernel<3, true, 1>", "attn_bwd_bf16": "attn_bwd_dkdv_bf16_kernel + attn_bwd_dq_bf16_kernel",

@@ -36,7 +36,7 @@ extern "C" {
  * functions this header declares.  rp_abi_version() / rp_abi_export_count() return the values the library was COMPILED with, so a
  * binding (rel_pose_amd/_lib.py parses both macros and counts the declarations) rejects a stale .so at load time instead of
  * failing later on a missing symbol. */
-#define RP_ABI_VERSION 19
+#define RP_ABI_VERSION 20
 #define RP_ABI_EXPORTS 104
 int rp_abi_version(void);
 int rp_abi_export_count(void);
@@ -322,8 +322,12 @@ int rp_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* do
  * as ONE pass over S (bf16 = 0): the rows online, the columns from per-32-row-block (max, sum) partials kept in `workspace`
  * (rp_emm_stats_workspace_bytes(Z, H) bytes) and combined by a second, tiny launch.  bf16 != 0: two rp_attn_fwd(stats_only) passes
  * (the reductions would cost that mode more than the second pass saves); workspace may then be NULL.  Z must be even. */
+/* s_out (bf16 = 0 only; NULL = off): [Z][H][18 query blocks][18 key tiles][1024] -- the score tiles themselves, in log2 units (scale
+ * log2(e) q.k), element (query i, key j) of a tile at float ((j >> 2) * 32 + i) * 4 + (j & 3) (four contiguous 16-byte stores per lane from
+ * the accumulators).  With 288 GB of HBM the three later passes over S (rp_emm_apply forward and swap, rp_emm_grad_ds; `s_in` there)
+ * read these 4 MB per image instead of recomputing q k^T: 96 of their 260 MFMAs per tile disappear. */
 size_t rp_emm_stats_workspace_bytes(int Z, int H);
-int rp_emm_stats(const float* q, const float* k, float* rlse, float* clse, void* workspace, int Z, int H, int ldq, int ldk,
+int rp_emm_stats(const float* q, const float* k, float* rlse, float* clse, void* workspace, float* s_out, int Z, int H, int ldq, int ldk,
                  float scale, int bf16, void* stream);
 /* delta[z][h][i] = sum_e dO[z][i][h*64+e] * O[z][i][h*64+e] */
 int rp_attn_bwd_delta(const float* dout, const float* o, float* delta, int Z, int H, int ld, void* stream);
@@ -402,9 +406,11 @@ int rp_emm_build_x(const float* qkv, const float* pos, float* x, int Z, int H, i
 int rp_emm_build_x_bwd(const float* dx, float* dqkv, int Z, int H, int ldqkv, void* stream); /* dqkv[:, 384+h*64+e] = dx[..][e] */
 /* ablation flags of the reference that are runnable there:
  *   single != 0 : use_single_softmax (:201-203), A = softmax(S,-1) (clse unused);
- *   x_left != 0 : cross_features (:218-220), F_z = X_left[z^1]^T A_z X_z  (x_left indexed like x). */
+ *   x_left != 0 : cross_features (:218-220), F_z = X_left[z^1]^T A_z X_z  (x_left indexed like x);
+ *   s_in != 0 (bf16 = 0 only): the score tiles rp_emm_stats stored are read instead of q k^T being recomputed (qkv is then unused). */
 int rp_emm_apply(const float* qkv, int ldqkv, const float* x, const float* x_left, const float* rlse, const float* clse,
-                 float* t_out, float* f_part, int Z, int H, float scale, int swap, int single, int bf16, void* stream);
+                 const float* s_in, float* t_out, float* f_part, int Z, int H, float scale, int swap, int single, int bf16,
+                 void* stream);
 int rp_emm_finalize(const float* f_part, float* g, int Z, int H, int ldg, void* stream);
 int rp_emm_finalize_bwd(const float* dg, float* df, int Z, int H, int ldg, void* stream); /* df[z][h][96][96] */
 /* rowdot: out[r] = sum_c a[r][c]*b[r][c], C = 96 */
@@ -418,9 +424,10 @@ int rp_emm_grad(const float* qkv, int ldqkv, const float* x, const float* w, con
 /* the owner = query pass (swap = 0) that also stores scale * dS_ij ([Z,H,576,576] floats) key index major and TILED like
  * rp_attn_bwd_dkdv_ds (rows = keys j, columns = queries i): the key-side gradient dk_z = ds_z q_{z^1} is then one
  * rp_ds_matmul(b_xor = 1) instead of the swap = 1 pass.  bf16 != 0: bf16 tiles, as for rp_attn_bwd_dkdv_ds */
+/* s_in (NULL = recompute; bf16 = 0 only): rp_emm_stats' stored score tiles, as for rp_emm_apply */
 int rp_emm_grad_ds(const float* qkv, int ldqkv, const float* x, const float* w, const float* rlse, const float* clse,
-                   const float* rho, const float* gamma, float* dqkv, float* ds, int Z, int H, float scale, int single,
-                   int bf16, void* stream);
+                   const float* rho, const float* gamma, const float* s_in, float* dqkv, float* ds, int Z, int H, float scale,
+                   int single, int bf16, void* stream);
 
 /* Weight gradient of a Linear on the bf16 data path (csrc/dw192_bf16.hip): slabs of C[n][k] = sum_m A[m][n] B[m][k] for A [M,N] BF16
  * (row stride lda elements, N a multiple of 192), B [M,192] contiguous, BF16 or (b_is_f32) fp32 rounded to bf16 on chip, M a multiple

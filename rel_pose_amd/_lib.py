@@ -94,7 +94,7 @@ _SIGS = {
     "rp_attn_bwd": (c_int, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, P]),
     "rp_attn_bwd_dkdv_ds": (c_int, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, F, I, P, P, I, P]),
     "rp_emm_stats_workspace_bytes": (ctypes.c_size_t, [I, I]),
-    "rp_emm_stats": (c_int, [P, P, P, P, P, I, I, I, I, F, I, P]),
+    "rp_emm_stats": (c_int, [P, P, P, P, P, P, I, I, I, I, F, I, P]),
     "rp_ds_matmul": (c_int, [P, P, P, I, I, I, I, I, I, P, I, P]),
     "rp_attn_bwd_cross": (c_int, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, I, P]),
     "rp_attn_bwd_dkdv": (c_int, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, F, I, P]),
@@ -120,12 +120,12 @@ _SIGS = {
     "rp_posenc": (c_int, [P, P, P, I, I, P]),
     "rp_emm_build_x": (c_int, [P, P, P, I, I, I, P]),
     "rp_emm_build_x_bwd": (c_int, [P, P, I, I, I, P]),
-    "rp_emm_apply": (c_int, [P, I, P, P, P, P, P, P, I, I, F, I, I, I, P]),
+    "rp_emm_apply": (c_int, [P, I, P, P, P, P, P, P, P, I, I, F, I, I, I, P]),
     "rp_emm_finalize": (c_int, [P, P, I, I, I, P]),
     "rp_emm_finalize_bwd": (c_int, [P, P, I, I, I, P]),
     "rp_rowdot96": (c_int, [P, P, P, L, P]),
     "rp_emm_grad": (c_int, [P, I, P, P, P, P, P, P, P, I, I, F, I, I, I, P]),
-    "rp_emm_grad_ds": (c_int, [P, I, P, P, P, P, P, P, P, P, I, I, F, I, I, P]),
+    "rp_emm_grad_ds": (c_int, [P, I, P, P, P, P, P, P, P, P, P, I, I, F, I, I, P]),
     "rp_pose_normalize_fwd": (c_int, [P, P, P, I, P]),
     "rp_pose_normalize_bwd": (c_int, [P, P, P, I, P]),
     "rp_preprocess_padded": (c_int, [P, P, I, I, I, I, P]),

@@ -157,12 +157,14 @@ RP_DEV void pack_owner(const float (&reg)[32], bf16x8 (&pk)[4]) {
 // through LDS-DMA).
 // Non-temporal stores: the tiles are read by a LATER kernel, long after they have left every cache (510 MB per launch at 128 images);
 // without the hint their lines displace the K / V (Q / dO) tiles the same workgroups keep re-reading from L2 (forward: -13 us).
+template <bool NTS = true>      // NTS = false: plain stores, for tiles the NEXT kernel reads (the EMM's score tiles)
 RP_DEV void store_tile_runs(float* tile, const f32x16& v, int lane) {
   typedef float f4v __attribute__((ext_vector_type(4)));
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const f4v x = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
-    __builtin_nontemporal_store(x, reinterpret_cast<f4v*>(tile + 4 * (64 * g + lane)));
+    if (NTS) __builtin_nontemporal_store(x, reinterpret_cast<f4v*>(tile + 4 * (64 * g + lane)));
+    else *reinterpret_cast<f4v*>(tile + 4 * (64 * g + lane)) = x;
   }
 }
 
@@ -257,6 +259,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_kernel(AttnP p) {
       s = mfma32(kb2[c].w, qreg[16 + 4 * c + 3], s);
     }
     }
+    if (STATS && SAVEP)      // the EMM's score tiles (log2 units, scale folded in): rp_emm_apply / rp_emm_grad_ds read them instead of recomputing q k^T
+      store_tile_runs<false>(p.pst + (((long long)zh * NTILE + (q0 >> 5)) * NTILE + t) * 1024, s, lane);
     if (COLS) {
       float2* cp = reinterpret_cast<float2*>(p.colpart) + ((long long)zh * NTILE + (q0 >> 5)) * NTOK + t * 32;
 #pragma unroll
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_kernel(AttnP p) {
       ps += s[r];
     }
     l = l * alpha + ps;
-    if (SAVEP) {
+    if (SAVEP && !STATS) {
       store_tile_runs(p.pst + (((long long)zh * NTILE + (q0 >> 5)) * NTILE + t) * 1024, s, lane);      // element (key k, query q): chunk (k >> 2) * 32 + q, dword k & 3
       p.mrun[((long long)zh * NTILE + t) * NTOK + q0 + l31] = mn;      // (both halves hold the same value: no exec-masked block)
     }
@@ -986,13 +990,17 @@ __global__ __launch_bounds__(256) void colstats_finalize_kernel(const float2* pa
 // two normalisers): rlse[z][h][i] over keys j, clse[z][h][j] over queries i.  fp32: ONE pass over S (rows online, columns from per-block
 // partials in `workspace`, rp_emm_stats_workspace_bytes) + a finalize launch; bf16 != 0: the two stats_only passes of rp_attn_fwd.
 extern "C" size_t rp_emm_stats_workspace_bytes(int Z, int H) { return (size_t)Z * H * NTILE * NTOK * 2 * sizeof(float); }
-extern "C" int rp_emm_stats(const float* q, const float* k, float* rlse, float* clse, void* workspace, int Z, int H, int ldq, int ldk,
-                            float scale, int bf16, void* stream) {
+// s_out (fp32 only, NULL = off): [Z][H][18 query blocks][18 key tiles][1024] -- the score tiles themselves (log2 units: scale log2(e) q.k),
+// element (query i, key j) of a tile at float ((j >> 2) * 32 + i) * 4 + (j & 3) (store_tile_runs): with 288 GB of HBM the three later
+// passes over S (rp_emm_apply forward and swap, rp_emm_grad_ds) read these 4 MB per image instead of recomputing q k^T.
+extern "C" int rp_emm_stats(const float* q, const float* k, float* rlse, float* clse, void* workspace, float* s_out, int Z, int H,
+                            int ldq, int ldk, float scale, int bf16, void* stream) {
   if (Z <= 0 || H <= 0 || (Z & 1) || !q || !k || !rlse || !clse) return RP_EBADSHAPE;
   if ((ldq | ldk) & 3) return RP_EALIGN;
   hipStream_t st = (hipStream_t)stream;
   const dim3 g3(xcd_grid(NTILE / 3, Z * H));
   if (bf16) {
+    if (s_out) return RP_EUNSUPPORTED;
     AttnP a{q, k, nullptr, nullptr, rlse, H, ldq, ldk, 4, 4, 1, 0, scale, Z * H, nullptr};
     hipLaunchKernelGGL((attn_fwd_kernel<3, true, 2, true>), g3, dim3(192), 0, st, a);
     AttnP b{k, q, nullptr, nullptr, clse, H, ldk, ldq, 4, 4, 0, 1, scale, Z * H, nullptr};
@@ -1001,8 +1009,9 @@ extern "C" int rp_emm_stats(const float* q, const float* k, float* rlse, float* 
     return RP_OK;
   }
   if (!workspace) return RP_EBADSHAPE;
-  AttnP a{q, k, nullptr, nullptr, rlse, H, ldq, ldk, 4, 4, 1, 0, scale, Z * H, (float*)workspace};
-  hipLaunchKernelGGL((attn_fwd_kernel<3, true, 2, false, true>), g3, dim3(192), 0, st, a);
+  AttnP a{q, k, nullptr, nullptr, rlse, H, ldq, ldk, 4, 4, 1, 0, scale, Z * H, (float*)workspace, s_out, nullptr};
+  if (s_out) hipLaunchKernelGGL((attn_fwd_kernel<3, true, 2, false, true, true>), g3, dim3(192), 0, st, a);
+  else hipLaunchKernelGGL((attn_fwd_kernel<3, true, 2, false, true>), g3, dim3(192), 0, st, a);
   RP_CHECK_LAUNCH();
   const long long total = (long long)Z * H * NTOK;
   hipLaunchKernelGGL(colstats_finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float2*)workspace, clse, total);

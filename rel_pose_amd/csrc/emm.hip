@@ -34,6 +34,8 @@ struct EmmP {
   int H; float scale; int swap; int ZH;
   int single;            // use_single_softmax (vision_transformer.py:201-203): A = softmax(S, -1) only
   const float* x_left;   // cross_features (:218-220): left operand of F = X_L^T A X comes from the partner image
+  const float* s_in;     // stored-S forms: the score tiles rp_emm_stats wrote (log2 units): [Z][H][18 query blocks][18 key tiles][1024], element
+                         // (query i, key j) at float ((j >> 2) * 32 + i) * 4 + (j & 3)
   float* ds;             // emm_grad, owner = query pass: optional [Z][H][18 j-blocks][18 i-blocks][16][64] = scale * dS_ij in 32x32 tiles
                          // (the MFMA accumulator image of the tile), so the key-side gradient dk = scale dS^T q is one rp_ds_matmul
                          // instead of a second pass that recomputes S and dA
@@ -243,12 +245,143 @@ __global__ __launch_bounds__(NT, 3) void emm_apply_kernel(EmmP p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// rp_emm_apply over STORED score tiles (p.s_in, written by rp_emm_stats): the same T = A X (+ F partials) without the q k^T product --
+// 48 MFMAs per tile instead of 80, no K tile in LDS, no owner rows in registers.  A wave's tile comes straight from HBM one tile ahead:
+//   SWAP = false (owner = queries, the forward): the stats wave that owned the same 32 queries wrote exactly this register image --
+//                four contiguous 16-byte-per-lane loads;
+//   SWAP = true  (owner = keys, U = A^T X_L of the backward): the transposed view of the same tiles -- register r of lane (key j, hi) is
+//                query acc_row(r, hi): sixteen 4-byte loads 16 bytes apart (the gather is on the load side, where it is hidden).
+template <bool SWAP>
+__global__ __launch_bounds__(NT, 3) void emm_apply_s_kernel(EmmP p) {
+  // LDS carve: loop phase  Xs[2][32*96] | Cl[2][32]   (6208 floats);   F phase  Ts[96][96]  (9216 floats, aliases the above)
+  __shared__ __attribute__((aligned(16))) float lds[XW * XW];
+  float* Xs = lds;
+  float* Cl = lds + 2 * 32 * XW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  int zh_, wgi;
+  if (!xcd_problem(NTILE / NW, p.ZH, zh_, wgi)) return;
+  const int h = zh_ % p.H, z = zh_ / p.H;
+  const int wg0 = wgi * (NW * 32);
+  const int o0 = wg0 + wave * 32;
+  const long long zh = (long long)z * p.H + h;
+  const float* own_lse = (SWAP ? p.clse : p.rlse) + zh * NTOK;
+  const float* loop_lse = (SWAP ? p.rlse : p.clse) + zh * NTOK;
+  const float* xb = p.x + zh * NTOK * XW;
+  const float ls_o = own_lse[o0 + l31] * RP_LOG2E;
+  // tile (query block qb, key tile kt) at ((zh * 18 + qb) * 18 + kt) * 1024
+  const float* sp = SWAP ? p.s_in + (zh * NTILE * NTILE + (o0 >> 5)) * 1024 + (l31 >> 2) * 128 + (l31 & 3) + 16 * hi      // loop tile t = query block: + t * 18 * 1024
+                         : p.s_in + (zh * NTILE + (o0 >> 5)) * NTILE * 1024 + 4 * lane;                                   // loop tile t = key tile:    + t * 1024
+  auto sload = [&](f32x16& v, int t) {
+    if (SWAP) {
+      const float* tp = sp + (long long)t * (NTILE * 1024);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = tp[acc_row(r, 0) * 4];
+    } else {
+      const float* tp = sp + t * 1024;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 x = ld4(tp + 256 * g);
+        v[4 * g] = x.x; v[4 * g + 1] = x.y; v[4 * g + 2] = x.z; v[4 * g + 3] = x.w;
+      }
+    }
+  };
+
+  f32x16 tacc[3] = {zero16(), zero16(), zero16()};
+  float4 xpre[4];
+  float cpre = 0.f;
+  auto x_gload = [&](int t) {   // 32 rows x 24 float4 = 768 float4 -> 4 per thread
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xpre[j] = ld4(xb + (long long)t * 32 * XW + (tid + NT * j) * 4);
+  };
+  auto x_sstore = [&](float* d) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) st4(d + (tid + NT * j) * 4, xpre[j]);
+  };
+  f32x16 sa, sb;
+  x_gload(0);
+  const float* csrc = loop_lse + (tid & 31);      // branch-free (see emm_apply_kernel)
+  cpre = csrc[0] * RP_LOG2E;
+  sload(sa, 0);
+  x_sstore(Xs);
+  if (tid < 32) Cl[tid] = cpre;
+  __syncthreads();
+
+  auto step = [&](f32x16& s, f32x16& sn, int t) {
+    const int cur = t & 1;
+    if (t + 1 < NTILE) {
+      x_gload(t + 1);
+      cpre = csrc[(t + 1) * 32] * RP_LOG2E;
+      sload(sn, t + 1);
+    }
+    const float* cl = Cl + cur * 32;
+    const float* xs = Xs + cur * 32 * XW;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float ll = cl[acc_row(r, hi)];
+      s[r] = p.single ? fast_exp2(s[r] - (SWAP ? ll : ls_o)) : fast_exp2(2.0f * s[r] - ls_o - ll);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float* xr = xs + acc_row(r, hi) * XW + l31;
+      tacc[0] = mfma32(s[r], xr[0], tacc[0]);
+      tacc[1] = mfma32(s[r], xr[32], tacc[1]);
+      tacc[2] = mfma32(s[r], xr[64], tacc[2]);
+    }
+    if (t + 1 < NTILE) {
+      x_sstore(Xs + (cur ^ 1) * 32 * XW);
+      if (tid < 32) Cl[(cur ^ 1) * 32 + tid] = cpre;
+    }
+    __syncthreads();
+  };
+  for (int t = 0; t < NTILE; t += 2) {      // two register sets rotate without copies
+    step(sa, sb, t);
+    step(sb, sa, t + 1);
+  }
+
+  if (p.t_out) {
+    float* tb = p.t_out + (zh * NTOK + o0) * XW;
+#pragma unroll
+    for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tb[acc_row(r, hi) * XW + 32 * nb + l31] = tacc[nb][r];
+  }
+  if (!p.f_part) return;
+
+  // ---- F_partial[a][c] = sum_{i in this workgroup's 96 rows} X[i][a] T[i][c] (as emm_apply_kernel) ----------------------
+  float* Ts = lds;
+#pragma unroll
+  for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Ts[(wave * 32 + acc_row(r, hi)) * XW + 32 * nb + l31] = tacc[nb][r];
+  __syncthreads();
+  f32x16 facc[3] = {zero16(), zero16(), zero16()};
+  const float* xlb = p.x_left ? p.x_left + ((long long)(z ^ 1) * p.H + h) * NTOK * XW : xb;
+  const float* xa = xlb + (long long)wg0 * XW + 32 * wave + l31;   // column a = 32*wave + l31 of the LEFT operand's rows
+#pragma unroll 4
+  for (int t = 0; t < 48; ++t) {
+    const int i = 48 * hi + t;
+    const float av = xa[(long long)i * XW];
+    const float* tr = Ts + i * XW + l31;
+    facc[0] = mfma32(av, tr[0], facc[0]);
+    facc[1] = mfma32(av, tr[32], facc[1]);
+    facc[2] = mfma32(av, tr[64], facc[2]);
+  }
+  float* fb = p.f_part + ((zh * (NTOK / (NW * 32)) + wgi) * XW + 32 * wave) * XW;
+#pragma unroll
+  for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) fb[acc_row(r, hi) * XW + 32 * nb + l31] = facc[nb][r];
+}
+
+// ------------------------------------------------------------------------------------------------
 constexpr int XG = 72;       // live columns of X / W used by the dA contraction (70 rounded up to even, x4)
 constexpr int XGS = 76;      // LDS row stride for the X tile read along c with ds_read_b128
 
 // 2-wave workgroups: the kernel needs ~250 VGPRs (2 waves/SIMD = 8 wave slots per CU); 4 x 2 waves fill them, 2 x 3 do not
 constexpr int GW = 2, GT = GW * 64;
-template <bool BF>
+// LS (exact fp32, owner = query pass): the score tile is LOADED from p.s_in (what rp_emm_stats stored: the same register image, four
+// contiguous 16-byte-per-lane loads one tile ahead) instead of recomputed -- 68 MFMAs per tile instead of 100, no owner q rows in registers.
+template <bool BF, bool LS = false>
 __global__ __launch_bounds__(GT, 2) void emm_grad_kernel(EmmP p) {
   __shared__ __attribute__((aligned(16))) float Ks[2][32 * KST];
   __shared__ __attribute__((aligned(16))) float Xs[2][32 * XGS];
@@ -270,7 +403,15 @@ __global__ __launch_bounds__(GT, 2) void emm_grad_kernel(EmmP p) {
   const float* xb = p.x + zh * NTOK * XW;
 
   float oreg[32], wreg[36];
-  load_owner(p.qkv + ((long long)own_img * NTOK + o0 + l31) * p.ld + own_col, hi, p.scale * RP_LOG2E, oreg);
+  if (!LS) load_owner(p.qkv + ((long long)own_img * NTOK + o0 + l31) * p.ld + own_col, hi, p.scale * RP_LOG2E, oreg);
+  const float* sp = LS ? p.s_in + (zh * NTILE + (o0 >> 5)) * NTILE * 1024 + 4 * lane : nullptr;      // tile t: + t * 1024
+  auto sload = [&](f32x16& v, int t) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 x = ld4(sp + t * 1024 + 256 * g);
+      v[4 * g] = x.x; v[4 * g + 1] = x.y; v[4 * g + 2] = x.z; v[4 * g + 3] = x.w;
+    }
+  };
   {
     const float* wr = p.w + (zh * NTOK + o0 + l31) * XW + 36 * hi;
 #pragma unroll
@@ -309,19 +450,22 @@ __global__ __launch_bounds__(GT, 2) void emm_grad_kernel(EmmP p) {
   const float* lsrc = (tid & 32) ? loop_g + (tid & 31) : loop_lse + (tid & 31);      // branch-free, see emm_apply_kernel
   const float lmul = (tid & 32) ? 1.0f : RP_LOG2E;
   lpre = lsrc[0] * lmul;
+  f32x16 sa = zero16(), sb = zero16();
+  if (LS) sload(sa, 0);
   kv_sstore<GT>(Ks[0], tid, kpre);
   x_sstore(Xs[0]);
   if (tid < 64) Ll[0][tid] = lpre;
   __syncthreads();
 
-  for (int t = 0; t < NTILE; ++t) {
+  auto step = [&](f32x16& s, f32x16& sn, int t) {
     const int cur = t & 1;
     if (t + 1 < NTILE) {
       kv_gload<GT>(lb + (long long)(t + 1) * 32 * p.ld, p.ld, tid, kpre);
       x_gload(t + 1);
       lpre = lsrc[(t + 1) * 32] * lmul;
+      if (LS) sload(sn, t + 1);
     }
-    f32x16 s = score_tile<BF>(Ks[cur], l31, hi, oreg, opk);      // S^T[loop][owner]
+    if (!LS) s = score_tile<BF>(Ks[cur], l31, hi, oreg, opk);      // S^T[loop][owner]
     f32x16 da = zero16();                                // dA^T[loop][owner] = sum_c X[loop][c] W[owner][c]
     {
       const float* xr = Xs[cur] + l31 * XGS + 36 * hi;
@@ -391,6 +535,10 @@ __global__ __launch_bounds__(GT, 2) void emm_grad_kernel(EmmP p) {
       if (tid < 64) Ll[cur ^ 1][tid] = lpre;
     }
     __syncthreads();
+  };
+  for (int t = 0; t < NTILE; t += 2) {      // (two register sets for the loaded score tiles rotate without copies)
+    step(sa, sb, t);
+    step(sb, sa, t + 1);
   }
   float* orow = p.dqkv + ((long long)own_img * NTOK + o0 + l31) * p.ld + own_col;
 #pragma unroll
@@ -403,13 +551,20 @@ __global__ __launch_bounds__(GT, 2) void emm_grad_kernel(EmmP p) {
 }  // namespace
 
 extern "C" int rp_emm_apply(const float* qkv, int ldqkv, const float* x, const float* x_left, const float* rlse,
-                            const float* clse, float* t_out, float* f_part, int Z, int H, float scale, int swap,
+                            const float* clse, const float* s_in, float* t_out, float* f_part, int Z, int H, float scale, int swap,
                             int single, int bf16, void* stream) {
   if (Z <= 0 || (Z & 1) || H <= 0 || (ldqkv & 3)) return RP_EBADSHAPE;
   if (swap && f_part) return RP_EUNSUPPORTED;
+  if (s_in && bf16) return RP_EUNSUPPORTED;
   EmmP p{};
   p.qkv = qkv; p.ld = ldqkv; p.x = x; p.rlse = rlse; p.clse = clse; p.t_out = t_out; p.f_part = f_part;
-  p.H = H; p.scale = scale; p.swap = swap ? 1 : 0; p.ZH = Z * H; p.single = single ? 1 : 0; p.x_left = x_left;
+  p.H = H; p.scale = scale; p.swap = swap ? 1 : 0; p.ZH = Z * H; p.single = single ? 1 : 0; p.x_left = x_left; p.s_in = s_in;
+  if (s_in) {
+    if (swap) hipLaunchKernelGGL(emm_apply_s_kernel<true>, dim3(xcd_grid(NTILE / NW, Z * H)), dim3(NT), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(emm_apply_s_kernel<false>, dim3(xcd_grid(NTILE / NW, Z * H)), dim3(NT), 0, (hipStream_t)stream, p);
+    RP_CHECK_LAUNCH();
+    return RP_OK;
+  }
   if (bf16) hipLaunchKernelGGL(emm_apply_kernel<true>, dim3(xcd_grid(NTILE / NW, Z * H)), dim3(NT), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(emm_apply_kernel<false>, dim3(xcd_grid(NTILE / NW, Z * H)), dim3(NT), 0, (hipStream_t)stream, p);
   RP_CHECK_LAUNCH();
@@ -418,13 +573,15 @@ extern "C" int rp_emm_apply(const float* qkv, int ldqkv, const float* x, const f
 
 static int emm_grad_impl(const float* qkv, int ldqkv, const float* x, const float* w, const float* rlse, const float* clse,
                          const float* rho, const float* gamma, float* dqkv, float* ds, int Z, int H, float scale, int swap,
-                         int single, int bf16, void* stream) {
+                         int single, int bf16, void* stream, const float* s_in = nullptr) {
   if (Z <= 0 || (Z & 1) || H <= 0 || (ldqkv & 3)) return RP_EBADSHAPE;
   if (ds && swap) return RP_EUNSUPPORTED;
+  if (s_in && (bf16 || swap)) return RP_EUNSUPPORTED;
   EmmP p{};
   p.qkv = qkv; p.ld = ldqkv; p.x = x; p.w = w; p.rlse = rlse; p.clse = clse; p.rho = rho; p.gamma = gamma;
-  p.dqkv = dqkv; p.H = H; p.scale = scale; p.swap = swap ? 1 : 0; p.ZH = Z * H; p.single = single ? 1 : 0; p.ds = ds;
-  if (bf16) hipLaunchKernelGGL(emm_grad_kernel<true>, dim3(xcd_grid(NTILE / GW, Z * H)), dim3(GT), 0, (hipStream_t)stream, p);
+  p.dqkv = dqkv; p.H = H; p.scale = scale; p.swap = swap ? 1 : 0; p.ZH = Z * H; p.single = single ? 1 : 0; p.ds = ds; p.s_in = s_in;
+  if (s_in) hipLaunchKernelGGL((emm_grad_kernel<false, true>), dim3(xcd_grid(NTILE / GW, Z * H)), dim3(GT), 0, (hipStream_t)stream, p);
+  else if (bf16) hipLaunchKernelGGL(emm_grad_kernel<true>, dim3(xcd_grid(NTILE / GW, Z * H)), dim3(GT), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(emm_grad_kernel<false>, dim3(xcd_grid(NTILE / GW, Z * H)), dim3(GT), 0, (hipStream_t)stream, p);
   RP_CHECK_LAUNCH();
   return RP_OK;
@@ -437,8 +594,8 @@ extern "C" int rp_emm_grad(const float* qkv, int ldqkv, const float* x, const fl
 }
 
 extern "C" int rp_emm_grad_ds(const float* qkv, int ldqkv, const float* x, const float* w, const float* rlse,
-                              const float* clse, const float* rho, const float* gamma, float* dqkv, float* ds, int Z, int H,
-                              float scale, int single, int bf16, void* stream) {
+                              const float* clse, const float* rho, const float* gamma, const float* s_in, float* dqkv, float* ds, int Z,
+                              int H, float scale, int single, int bf16, void* stream) {
   if (!ds) return RP_EBADSHAPE;
-  return emm_grad_impl(qkv, ldqkv, x, w, rlse, clse, rho, gamma, dqkv, ds, Z, H, scale, 0, single, bf16, stream);
+  return emm_grad_impl(qkv, ldqkv, x, w, rlse, clse, rho, gamma, dqkv, ds, Z, H, scale, 0, single, bf16, stream, s_in);
 }

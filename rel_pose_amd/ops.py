@@ -1087,15 +1087,22 @@ EMM_STATS_ONE_PASS = os.environ.get("RP_EMM_STATS_ONE_PASS", "1") == "1"      # 
 _stats_ws = {}
 
 
-def emm_stats(qkv, Z, single=False):
+# Stored-S EMM (exact-fp32 configuration): the statistics pass also writes the score tiles (Z * 4 MB, kept for the backward), and the
+# three later passes over S -- rp_emm_apply forward and swap, rp_emm_grad_ds -- read them instead of recomputing q k^T (96 of 260 MFMAs
+# per tile).  RP_EMM_STORE_S=0: the recompute form.
+EMM_STORE_S = os.environ.get("RP_EMM_STORE_S", "1") == "1"
+
+
+def emm_stats(qkv, Z, single=False, want_s=False):
     """row / column log-sum-exp of S_z = scale q_{z^1} k_z^T (single softmax: rows only).  Both normalisers come from ONE pass over S
-    (rp_emm_stats; two rp_attn_fwd(stats_only) passes in the bf16 configuration)."""
+    (rp_emm_stats; two rp_attn_fwd(stats_only) passes in the bf16 configuration).
+    want_s: -> (rlse, clse, s) with s the stored score tiles [Z,H,18,18,1024] (None where the one-pass fp32 kernel does not run)."""
     if single or not EMM_STATS_ONE_PASS:
         _, rlse = attn_fwd(qkv, Z, stats_only=True, q_off=0, k_off=DIM, q_xor=1, k_xor=0)
         if single:
-            return rlse, rlse
+            return (rlse, rlse, None) if want_s else (rlse, rlse)
         _, clse = attn_fwd(qkv, Z, stats_only=True, q_off=DIM, k_off=0, q_xor=0, k_xor=1)
-        return rlse, clse
+        return (rlse, clse, None) if want_s else (rlse, clse)
     lib = _lib.load()
     _chk(qkv)
     ld = qkv.shape[1]
@@ -1107,10 +1114,12 @@ def emm_stats(qkv, Z, single=False):
         if ws is None:
             ws = _stats_ws[key] = torch.empty(lib.rp_emm_stats_workspace_bytes(Z, HEADS) // 4, device=qkv.device, dtype=torch.float32)
     b = qkv.data_ptr()
-    with timed("emm_stats", 2.0 * Z * HEADS * N_TOK * N_TOK * 64, 4.0 * Z * N_TOK * (2 * DIM + 2 * HEADS)):
-        _lib.check(lib.rp_emm_stats(ctypes.c_void_p(b), ctypes.c_void_p(b + 4 * DIM), _p(rlse), _p(clse), _p(ws), Z, HEADS, ld, ld,
+    s = _empty(Z, HEADS, N_TOK // 32, N_TOK // 32, 1024, like=qkv) if (want_s and EMM_STORE_S and not ATTN_BF16) else None
+    with timed("emm_stats", 2.0 * Z * HEADS * N_TOK * N_TOK * 64,
+               4.0 * Z * N_TOK * (2 * DIM + 2 * HEADS) + (4.0 * Z * HEADS * N_TOK * N_TOK if s is not None else 0.0)):
+        _lib.check(lib.rp_emm_stats(ctypes.c_void_p(b), ctypes.c_void_p(b + 4 * DIM), _p(rlse), _p(clse), _p(ws), _p(s), Z, HEADS, ld, ld,
                                     (DIM // HEADS) ** -0.5, ATTN_BF16, _st()), "rp_emm_stats")
-    return rlse, clse
+    return (rlse, clse, s) if want_s else (rlse, clse)
 
 
 def pair_swap(x):
@@ -1118,15 +1127,17 @@ def pair_swap(x):
     return x.view(x.shape[0] // 2, 2, *x.shape[1:]).flip(1).reshape(x.shape).contiguous()
 
 
-def emm_apply(qkv, x, rlse, clse, Z, swap=False, want_t=True, want_f=True, single=False, x_left=None):
+def emm_apply(qkv, x, rlse, clse, Z, swap=False, want_t=True, want_f=True, single=False, x_left=None, s=None):
+    """s: the score tiles emm_stats(want_s=True) stored -> the kernel reads them instead of recomputing q k^T"""
     lib = _lib.load()
-    _chk(qkv, x, rlse, clse, x_left)
+    _chk(qkv, x, rlse, clse, x_left, s)
     t = _empty(Z, HEADS, N_TOK, XW, like=qkv) if want_t else None
     f = _empty(Z, HEADS, NWG, XW, XW, like=qkv) if (want_f and not swap) else None
-    # algorithmic: S = q k^T (64) and T = A X (96) per score element; F = X^T T adds 2 * 576 * 96 * 96 per (image, head)
-    with timed("emm_apply", 2.0 * Z * HEADS * (N_TOK * N_TOK * (64 + XW) + (N_TOK * XW * XW if f is not None else 0)),
-               4.0 * Z * HEADS * N_TOK * (2 * 64 + 2 * XW + 2)):
-        _lib.check(lib.rp_emm_apply(_p(qkv), qkv.shape[1], _p(x), _p(x_left), _p(rlse), _p(clse), _p(t), _p(f), Z, HEADS,
+    # algorithmic: T = A X (96 per score element) -- plus S = q k^T (64) where it is recomputed; F = X^T T adds 2 * 576 * 96 * 96 per (image, head)
+    with timed("emm_apply_s" if s is not None else "emm_apply",
+               2.0 * Z * HEADS * (N_TOK * N_TOK * ((0 if s is not None else 64) + XW) + (N_TOK * XW * XW if f is not None else 0)),
+               4.0 * Z * HEADS * N_TOK * ((N_TOK if s is not None else 2 * 64) + 2 * XW + 2)):
+        _lib.check(lib.rp_emm_apply(_p(qkv), qkv.shape[1], _p(x), _p(x_left), _p(rlse), _p(clse), _p(s), _p(t), _p(f), Z, HEADS,
                                     (DIM // HEADS) ** -0.5, 1 if swap else 0, 1 if single else 0, ATTN_BF16, _st()), "rp_emm_apply")
     return t, f
 
@@ -1164,16 +1175,16 @@ def _bmm96(X, D, transpose_d, residual=None):
     return out
 
 
-def emm_backward(qkv, x, t, rlse, clse, df, Z, single=False, cross=False):
+def emm_backward(qkv, x, t, rlse, clse, df, Z, single=False, cross=False, s=None):
     """Gradient of F = X_L^T A X wrt qkv (q, k through A; v through X_L and X).  df: [Z,H,96,96] zero-padded.
-    cross (cross_features): X_L[z] = X[z^1]; otherwise X_L = X."""
+    cross (cross_features): X_L[z] = X[z^1]; otherwise X_L = X.  s: the forward's stored score tiles (emm_stats(want_s=True))."""
     lib = _lib.load()
     scale = (DIM // HEADS) ** -0.5
     sg = 1 if single else 0
     xl = pair_swap(x) if cross else x   # left operand, indexed by the problem z
     w = _bmm96(xl, df, False)       # W  = X_L dF    (rows i)
     wp = _bmm96(x, df, True)        # W' = X dF^T    (rows j)
-    u, _ = emm_apply(qkv, xl, rlse, clse, Z, swap=True, want_f=False, single=single)     # U = A^T X_L
+    u, _ = emm_apply(qkv, xl, rlse, clse, Z, swap=True, want_f=False, single=single, s=s)     # U = A^T X_L
     rho = rowdot96(w, t)            # rho_i   = sum_j A_ij dA_ij
     gam = rho if single else rowdot96(wp, u)           # gamma_j = sum_i A_ij dA_ij (unused by the single softmax)
     dxl = _bmm96(t, df, True)                                   # d X_L = T dF^T  (belongs to image z^1 when cross)
@@ -1185,9 +1196,9 @@ def emm_backward(qkv, x, t, rlse, clse, df, Z, single=False, cross=False):
         # that recomputes S and dA (68 of its 100 MFMAs per tile)
         ds = _ds_buffer(Z, qkv)
         # algorithmic: S recompute is not counted; dA = W X^T (96) and dq = dS k (64) per score element
-        with timed("emm_grad_ds", 2.0 * Z * HEADS * N_TOK * N_TOK * (XW + 64),
-                   4.0 * Z * HEADS * N_TOK * (N_TOK + 3 * 64 + 2 * XW + 4)):
-            _lib.check(lib.rp_emm_grad_ds(_p(qkv), ld, _p(x), _p(w), _p(rlse), _p(clse), _p(rho), _p(gam), _p(dqkv), _p(ds), Z,
+        with timed("emm_grad_ds_s" if s is not None else "emm_grad_ds", 2.0 * Z * HEADS * N_TOK * N_TOK * (XW + 64),
+                   4.0 * Z * HEADS * N_TOK * ((2 if s is not None else 1) * N_TOK + 3 * 64 + 2 * XW + 4)):
+            _lib.check(lib.rp_emm_grad_ds(_p(qkv), ld, _p(x), _p(w), _p(rlse), _p(clse), _p(rho), _p(gam), _p(s), _p(dqkv), _p(ds), Z,
                                           HEADS, scale, sg, ATTN_BF16, _st()), "rp_emm_grad_ds")
         # dk_z = dS_z (key-major tiles) x q_{z^1}: one streaming launch
         ds_matmul(ds, qkv.data_ptr(), ld, dqkv.data_ptr() + 4 * DIM, ld, Z, b_xor=1)
@@ -1595,15 +1606,16 @@ class CrossBlockFn(_Fn):
         Z = x.shape[0]
         x2 = x.view(Z * N_TOK, DIM)
         ctx.single, ctx.cross = single, cross
+        sc = None
         if _bf16_path() and not single and not cross:      # the bf16 data path (csrc/emm_bf16.hip): bf16 q | k | v, X, T; log2 normalisers
             qkv, xn, m1, r1 = ln_linear(x2, n1w, n1b, qkv_w, qkv_b, train=train, out_dtype=torch.bfloat16, xn_dtype=torch.bfloat16)
             g, (xa, t, rlse, clse) = emm_forward_bf16(qkv, pos, Z)
         else:
             qkv, xn, m1, r1 = ln_linear(x2, n1w, n1b, qkv_w, qkv_b, train=train)
-            rlse, clse = emm_stats(qkv, Z, single)
+            rlse, clse, sc = emm_stats(qkv, Z, single, want_s=True)
             xa = emm_build_x(qkv, pos, Z)
             t, fpart = emm_apply(qkv, xa, rlse, clse, Z, swap=False, want_t=train, single=single,
-                                 x_left=xa if cross else None)
+                                 x_left=xa if cross else None, s=sc)
             g = emm_finalize(fpart, Z)                                 # [Z*70, 224]
         pf_wp = _padded(pf_w, (0, GW - pf_w.shape[1]))
         f = linear(g, pf_wp, pf_b)                                     # [Z*70, 192]
@@ -1613,7 +1625,7 @@ class CrossBlockFn(_Fn):
             if qkv.dtype == torch.bfloat16:
                 register_transposed(qkv_w)
             ctx.save_for_backward(x2, m1, r1, xn, qkv, rlse, clse, xa, t, g, f, m2, r2, fn, h, hpre, n1w, qkv_w, pf_wp,
-                                  n2w, fc1_w, fc2_w)
+                                  n2w, fc1_w, fc2_w, sc)
             ctx.Z = Z
             ctx.pf_cols = pf_w.shape[1]
         return y.view(Z, 70, DIM)
@@ -1621,7 +1633,7 @@ class CrossBlockFn(_Fn):
     @staticmethod
     def backward(ctx, dy):
         (x2, m1, r1, xn, qkv, rlse, clse, xa, t, g, f, m2, r2, fn, h, hpre, n1w, qkv_w, pf_wp, n2w, fc1_w,
-         fc2_w) = ctx.saved_tensors
+         fc2_w, sc) = ctx.saved_tensors
         Z = ctx.Z
         dy = dy.contiguous().view(Z * 70, DIM)
         fork = _Fork(dy.device)
@@ -1638,7 +1650,7 @@ class CrossBlockFn(_Fn):
                 dqkvw = fork.on_side(lambda: linear_dw(dqkv, xn))
                 dqkvb = dqkv.sum(0, dtype=torch.float32)                # (one bf16 pass per step; the Blocks get theirs from kernel epilogues)
             else:
-                dqkv = emm_backward(qkv, xa, t, rlse, clse, dF, Z, single=ctx.single, cross=ctx.cross)
+                dqkv = emm_backward(qkv, xa, t, rlse, clse, dF, Z, single=ctx.single, cross=ctx.cross, s=sc)
                 fork.sync_side()
                 dqkvw, dqkvb = _param_grads(fork, dqkv, xn)
             dx, dn1w, dn1b = linear_dx_lnbwd(dqkv, qkv_w, x2, n1w, m1, r1)

@@ -684,6 +684,47 @@ def test_emm_backward(ops):
     assert max(e) < 5e-5
 
 
+@pytest.mark.parametrize("Z", [2, 6])
+def test_emm_stored_scores(ops, Z):
+    """Stored-S form of the EMM (rp_emm_stats(s_out) -> rp_emm_apply / rp_emm_grad_ds(s_in); vision_transformer.py:198-223 and its
+    autograd): the stored tiles are the scores in log2 units in the documented layout, the statistics are BIT-identical to the pass that
+    does not store, and T, F, U and the gradients agree with fp64 like the recompute form's (same bounds) -- and with the recompute
+    form itself to fp32 rounding."""
+    qkv = rnd(Z * 576, 576, seed=4)
+    intr = torch.tensor([[30.0, 26.0, 12.0, 12.0], [18.0, 21.0, 12.0, 9.0], [25.0, 25.0, 11.0, 13.0]])[:Z // 2, None, :].repeat(1, 2, 1).contiguous().cuda()
+    pos = ops.posenc(intr, Z // 2, qkv.device)
+    q64 = qkv.double().requires_grad_(True)
+    F_ref, T_ref, U_ref, _, _ = _emm_ref(q64, pos, Z)
+    rlse, clse, sc = ops.emm_stats(qkv, Z, want_s=True)
+    r0, c0 = ops.emm_stats(qkv, Z)
+    assert sc is not None and torch.equal(rlse, r0) and torch.equal(clse, c0)
+    # S_z[i][j] = scale q_{z^1,i} . k_{z,j}; tile (query block, key tile), element (i, j) at float ((j >> 2) * 32 + i) * 4 + (j & 3)
+    q3 = qkv.double().view(Z, 576, 3, 3, 64)
+    qp = q3[[z ^ 1 for z in range(Z)], :, 0]                                       # [Z,576,3,64] queries of the partner image
+    S = torch.einsum("zihd,zjhd->zhij", qp, q3[:, :, 1]) * 0.125 * math.log2(math.e)
+    got = sc.view(Z, 3, 18, 18, 8, 32, 4).permute(0, 1, 2, 5, 3, 4, 6).reshape(Z, 3, 576, 576).double()      # [z,h,(qb,i),(t,j>>2,j&3)]
+    assert rel(got, S) < 2e-6
+    xa = ops.emm_build_x(qkv, pos, Z)
+    t, fpart = ops.emm_apply(qkv, xa, rlse, clse, Z, s=sc)
+    u, _ = ops.emm_apply(qkv, xa, rlse, clse, Z, swap=True, want_f=False, s=sc)
+    F = fpart.double().sum(2)
+    e = dict(T=rel(t[..., :70], T_ref), U=rel(u[..., :70], U_ref), F=rel(F[..., :70, :70], F_ref))
+    report("emm_fwd_stored_s[Z=%d]" % Z, **e)
+    assert max(e.values()) < 1e-5
+    t0, f0 = ops.emm_apply(qkv, xa, rlse, clse, Z)
+    u0, _ = ops.emm_apply(qkv, xa, rlse, clse, Z, swap=True, want_f=False)
+    assert rel(t, t0) < 2e-6 and rel(u, u0) < 2e-6 and rel(fpart, f0) < 2e-6
+    dF = torch.zeros(Z, 3, 96, 96, device="cuda")
+    dF[..., :70, :70] = rnd(Z, 3, 70, 70, seed=6)
+    (F_ref * dF[..., :70, :70].double()).sum().backward()
+    dqkv = ops.emm_backward(qkv, xa, t, rlse, clse, dF, Z, s=sc)
+    eb = [rel(dqkv[:, i * 192:(i + 1) * 192], q64.grad[:, i * 192:(i + 1) * 192]) for i in range(3)]
+    report("emm_bwd_stored_s[Z=%d]" % Z, dq=eb[0], dk=eb[1], dv=eb[2])
+    assert max(eb) < 5e-5
+    assert torch.equal(dqkv, ops.emm_backward(qkv, xa, t, rlse, clse, dF, Z, s=sc))          # deterministic
+    assert rel(dqkv, ops.emm_backward(qkv, xa, t0, rlse, clse, dF, Z)) < 1e-5
+
+
 @pytest.mark.parametrize("H,W", [(384, 384), (256, 320), (384, 512), (480, 640)])
 def test_preprocess_bit_exact(ops, H, W):
     """channel flip, /255, mean/std, nearest resize to 224 -- bit-exact vs the oracle (which is pinned to

@@ -31,6 +31,7 @@ HBM_PEAK_GBS = 8000.0                # same guide, HBM3E peak (spec); 6.29 TB/s 
 PRECISIONS = {"fp32": 0, "split3": 3, "bf16": 1}
 FLOPS_FWD_PER_PAIR = 8588216320      # GEMM flops of the ViT+EMM+regressor hot path, forward
 METRIC = "image-pairs/sec fwd+bwd @384x384, 1/2/4/8 MI355X; R,t err vs ref"
+GRAPH_BELOW_PAIRS = 16               # single-GPU training steps at or below this many pairs replay captured HIP graphs by default
 
 
 def model_args():
@@ -334,9 +335,12 @@ def main():
     ap.add_argument("--no-supplementary", action="store_true",
                     help="skip the two extra bounded points (BASELINE configs[1] forward-only at 64 pairs, configs[4] bf16 at 128 pairs "
                          "per GPU) that the default single-GPU run times after the headline loop and attaches as `supplementary`")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay the step from captured HIP graphs (rel_pose_amd/graph.py) instead of launching eagerly; "
-                         "measured neutral at N=1 once the step had no host syncs left, so eager + DDP is the default")
+    ap.add_argument("--graph", action="store_true", default=None,
+                    help="replay the step from captured HIP graphs (rel_pose_amd/graph.py) instead of launching eagerly.  Default: graphs "
+                         "for single-GPU training at <= %d pairs per GPU -- there the ~350 launches of a step are host-bound when issued "
+                         "eagerly (6 pairs: 740-900 pairs/s from run to run, 892 +- 1 replayed) -- and eager + DDP above, where replay "
+                         "measured neutral" % GRAPH_BELOW_PAIRS)
+    ap.add_argument("--no-graph", dest="graph", action="store_false", help="always launch eagerly")
     ap.add_argument("--scope", default="full", choices=("full", "hot"),
                     help="full = images -> CNN -> hot path (the metric); hot = synthetic CNN maps -> hot path only "
                          "(kernel profiling; not the headline number)")
@@ -349,6 +353,9 @@ def main():
                          "three bf16 limbs per operand, six limb products on the bf16 MFMA pipe, fp32-grade results; "
                          "bf16 = operands rounded to bf16 (BASELINE.json configs[4]; NOT the headline metric)")
     args = ap.parse_args()
+    if args.graph is None:
+        args.graph = (args.mode == "train" and args.batch <= GRAPH_BELOW_PAIRS and int(os.environ.get("WORLD_SIZE", "1")) == 1
+                      and args.scope == "full" and not os.environ.get("RP_BENCH_FORCE_DIST"))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -17,8 +17,21 @@
 #include "common.h"
 #include "../../include/relpose_hip.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
+
+template <int OFF> RP_DEV float lds_rd32(unsigned addr) {      // ds_read_b32 with an immediate byte offset (invisible to hipcc's waitcnt pass)
+  float v;
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <int N, class F> RP_DEV void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
 
 constexpr int NTOK = 576;
 constexpr int KST = 68;   // LDS row stride (floats) for tiles read along d with ds_read_b128
@@ -498,6 +511,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dkdv_kernel(AttnBwdP p)
 // ------------------------------------------------------------------------------------------------
 template <int NW, int WPS>
 __global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dkdv_p_kernel(AttnBwdP p) {
+#ifdef RP_DKDV_PROBE
+  unsigned long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_readcyclecounter();
+#endif
   constexpr int NT = NW * 64;
   constexpr int NPF = (512 + NT - 1) / NT;
   __shared__ __attribute__((aligned(16))) float Qs[2][32 * KST];
@@ -556,7 +572,12 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dkdv_p_kernel(AttnBwdP 
       lb = bsrc[(t + 1) * 32];
       pload(pn, t + 1);
     }
+    STAMP(1)
     f32x16 dp = score_tile<false>(Ds[cur], l31, hi, vreg, nopk);      // scale dP: rows = queries acc_row(r, hi), lane = key
+#ifdef RP_DKDV_PROBE
+    asm volatile("" : "+v"(dp));
+#endif
+    STAMP(2)
     const float* L = Ls[cur][wave];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -564,20 +585,34 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_bwd_dkdv_p_kernel(AttnBwdP 
       pc[r] *= L[qi];
       dp[r] = pc[r] * (dp[r] - L[32 + qi]);
     }
+#ifdef RP_DKDV_PROBE
+    asm volatile("" : "+v"(dp), "+v"(pc));
+#endif
+    STAMP(3)
     store_tile_runs(dst + (long long)t * (NTILE * 1024), dp, lane);     // scale dS; element (query q, key k): chunk (q >> 2) * 32 + k, dword q & 3
+    STAMP(4)
     accum_tile<KST, false>(Ds[cur], l31, hi, pc, dv0, dv1);     // dV^T += dO^T P
     accum_tile<KST, false>(Qs[cur], l31, hi, dp, dk0, dk1);     // dK^T += Q^T (scale dS)
+#ifdef RP_DKDV_PROBE
+    asm volatile("" : "+v"(dv0), "+v"(dv1), "+v"(dk0), "+v"(dk1));
+#endif
+    STAMP(5)
     if (t + 1 < NTILE) {
       tile_sstore<NT, KST>(Qs[cur ^ 1], tid, qpre);
       tile_sstore<NT, KST>(Ds[cur ^ 1], tid, dpre);
       Ls[cur ^ 1][wave][lane] = lfac(la, lb);
     }
+    STAMP(6)
     __syncthreads();
+    STAMP(7)
   };
   for (int t = 0; t < NTILE; t += 2) {      // two register sets for the P tiles rotate without copies (18 tiles)
     step(pa, pb, t);
     step(pb, pa, t + 1);
   }
+#ifdef RP_DKDV_PROBE
+  if (lane == 0) { for (int i = 0; i < 8; ++i) atomicAdd(&g_probe[i], acc_[i]); atomicAdd(&g_probe[8], 1ull); }
+#endif
   store_ownerT(p.dv + ((long long)z * NTOK + k0 + l31) * p.lddv + h * 64, hi, dv0, dv1, 1.0f);
   store_ownerT(p.dk + ((long long)z * NTOK + k0 + l31) * p.lddk + h * 64, hi, dk0, dk1, 1.0f);
   if (p.dk_colpart) {
@@ -797,6 +832,97 @@ __global__ __launch_bounds__(NW * 64, 3) void ds_matmul_t_kernel(DsMmP p) {
   }
   store_ownerT(p.out + ((long long)z * NTOK + i0 + l31) * p.ldo + h * 64, hi, o0, o1, 1.0f);
   if (p.colpart) colsum_ownerT(p.colpart + ((long long)z * NTILE + ib) * p.ldp + h * 64, l31, hi, o0, o1, 1.0f);
+}
+
+// ds_matmul_t_kernel on v_mfma_f32_16x16x4_f32.  Why: with several waves per SIMD taking turns, v_mfma_f32_32x32x2_f32 issues every ~82
+// cycles instead of 64 (profiles/README.md "measured ceilings": 103-123 TF at 2-8 waves per SIMD against 148 TF alone) while 16x16x4 holds
+// 152-155 TF at every occupancy -- and this kernel is nothing but MFMAs fed from LDS by three waves per SIMD.
+//   out^T[d][i] += b[j][d] ds[i][j]:  A[m = d][k = j] = b,  lane (d' = l & 15, kq = l >> 4) reads b[4 ks + kq][16 mb + d']   (4 reads per k-step)
+//                                     B[k = j][n = i] = T,  lane (i' = l & 15, kq)          reads T[4 ks + kq][16 nb + i']   (2 reads per k-step)
+//   8 MFMAs of 32 cycles per k-step of four keys, 8 k-steps per tile; C block (mb, nb): lane (i', kq) register e = out[16 nb + i'][16 mb + 4 kq + e]
+//   -> 16-byte stores.
+// Both LDS images are laid out by the DMA's SOURCE addressing so that the four kq groups of a read hit different banks:
+//   b tile : chunk c of row j sits at chunk c ^ (4 (j & 3))        -> logical column 16 mb + d' of row 4 ks + kq at  16 (mb ^ kq) + d'
+//   T tile : chunk c of row j sits at chunk c ^ (4 ((j >> 1) & 1))  -> logical column 16 nb + i' of row 4 ks + kq at  16 (nb ^ (kq >> 1)) + i'
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 3) void ds_matmul_t16_kernel(DsMmP p) {
+  __shared__ __attribute__((aligned(16))) float Bs[2][32 * 64];
+  __shared__ __attribute__((aligned(16))) float Dt[NW][2][1024];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, kq = lane >> 4;
+  int zh, blk;
+  if (!xcd_problem(NTILE / NW, p.ZH, zh, blk)) return;
+  if (p.reverse) zh = p.ZH - 1 - zh;
+  const int h = zh % p.H, z = zh / p.H;
+  const int ib = blk * NW + wave, i0 = ib * 32;
+  const float* bb = p.b + (long long)(z ^ p.b_xor) * NTOK * p.ldb + h * 64;
+  const float* tiles = p.ds + ((long long)zh * NTILE + ib) * NTILE * 1024;
+  constexpr int BP = (8 + NW - 1) / NW;
+  // dS piece c: LDS chunks 64 c + lane -> row j = 8 c + (lane >> 3), physical chunk lane & 7 = logical (i >> 2) ^ (4 ((j >> 1) & 1));
+  // the tile stores element (query i, key j) at chunk (i >> 2) * 32 + j (store_tile_runs)
+  const unsigned dvoff = ((((lane & 7) ^ (4 * ((lane >> 4) & 1))) * 32) + (lane >> 3)) * 16;
+  // b piece: 4 rows (lane >> 4) x 16 chunks; physical chunk lane & 15 holds logical chunk (lane & 15) ^ (4 (row & 3)), row & 3 = lane >> 4
+  const unsigned bvoff = (unsigned)((lane >> 4) * p.ldb * 4 + (((lane & 15) ^ (4 * (lane >> 4))) * 16));
+  const unsigned dt0 = lds_byte_addr(&Dt[wave][0][0]), bs0 = lds_byte_addr(&Bs[0][0]);
+  auto issue = [&](int t, int buf) {
+    const float* ts = tiles + (long long)t * 1024;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) glds16(uniform_ptr(ts + 32 * c), dvoff, dt0 + buf * 4096 + c * 1024);
+#pragma unroll
+    for (int c = 0; c < BP; ++c) {
+      const int piece = min(wave + NW * c, 7);
+      glds16(uniform_ptr(bb + (long long)(t * 32 + 4 * piece) * p.ldb), bvoff, bs0 + buf * 8192 + piece * 1024);
+    }
+  };
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // per-lane read offsets (floats) inside a tile image; k-step ks adds 4 rows
+  int aoff[4], boff[2];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) aoff[m] = kq * 64 + 16 * (m ^ kq) + l15;
+#pragma unroll
+  for (int n = 0; n < 2; ++n) boff[n] = kq * 32 + 16 * (n ^ (kq >> 1)) + l15;
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int t = 0; t < NTILE; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < NTILE) issue(t + 1, cur ^ 1);
+    const float* B = Bs[cur];
+    const float* D = Dt[wave][cur];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      float av[4], bv[2];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) av[m] = B[ks * 256 + aoff[m]];
+#pragma unroll
+      for (int n = 0; n < 2; ++n) bv[n] = D[ks * 128 + boff[n]];
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[n], acc[m][n], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    float* orow = p.out + ((long long)z * NTOK + i0 + 16 * n + l15) * p.ldo + h * 64 + 4 * kq;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) st4(orow + 16 * m, make_float4(acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]));
+  }
+  if (p.colpart) {      // column sums of `out` over the wave's 32 rows: lane (i', kq) register e is column 16 m + 4 kq + e of rows 16 n + i'
+    float* part = p.colpart + ((long long)z * NTILE + ib) * p.ldp + h * 64;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = row16_sum(acc[m][0][e] + acc[m][1][e]);
+        if (l15 == 0) part[16 * m + 4 * kq + e] = v;
+      }
+  }
 }
 
 // The bf16 configuration's form: the producer stored bf16 tiles (store_acc_image_bf16: the same [16 r][64 lanes] image, 2 KB), so
@@ -1167,7 +1293,10 @@ extern "C" int rp_ds_matmul_t(const float* ds, const float* b, float* out, int Z
   if (colpart && ldp < H * 64) return RP_EBADSHAPE;
   static const char* const rv = getenv("RP_DSMM_REV");
   DsMmP p{ds, b, out, H, ldb, ldo, b_xor, Z * H, rv ? rv[0] - '0' : 1, colpart, ldp};
-  hipLaunchKernelGGL((ds_matmul_t_kernel<3>), dim3(xcd_grid(NTILE / 3, Z * H)), dim3(192), 0, (hipStream_t)stream, p);
+  // RP_DSMM_T=32: the v_mfma_f32_32x32x2_f32 form (A/B aid)
+  static const char* const ov = getenv("RP_DSMM_T");
+  if (ov && ov[0] == '3') hipLaunchKernelGGL((ds_matmul_t_kernel<3>), dim3(xcd_grid(NTILE / 3, Z * H)), dim3(192), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((ds_matmul_t16_kernel<3>), dim3(xcd_grid(NTILE / 3, Z * H)), dim3(192), 0, (hipStream_t)stream, p);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }

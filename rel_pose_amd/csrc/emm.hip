@@ -386,7 +386,7 @@ __global__ __launch_bounds__(GT, 2) void emm_grad_kernel(EmmP p) {
   __shared__ __attribute__((aligned(16))) float Ks[2][32 * KST];
   __shared__ __attribute__((aligned(16))) float Xs[2][32 * XGS];
   __shared__ float Ll[2][64];   // loop-side lse [0..31] and rho/gamma [32..63]
-  __shared__ __attribute__((aligned(16))) float Tst[BF ? 1 : GW][BF ? 4 : 256];      // per-wave staging of the stored dS tile (1 KB: four workgroups per CU stay)
+  __shared__ __attribute__((aligned(16))) float Tst[(BF || LS) ? 1 : GW][(BF || LS) ? 4 : 256];      // per-wave staging of the stored dS tile (1 KB: four workgroups per CU stay)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   int zh_, wgi;
   if (!xcd_problem(NTILE / GW, p.ZH, zh_, wgi)) return;
@@ -412,15 +412,18 @@ __global__ __launch_bounds__(GT, 2) void emm_grad_kernel(EmmP p) {
       v[4 * g] = x.x; v[4 * g + 1] = x.y; v[4 * g + 2] = x.z; v[4 * g + 3] = x.w;
     }
   };
+  // LS: `scale` rides on the W rows and on rho / gamma (dA' = scale dA, ...): the dS formed below IS scale * dS -- the stored tile and the
+  // dq operand -- with no multiply of its own in the loop, and the tile leaves as the four 16-byte runs each lane holds (no LDS staging)
+  const float pre = LS ? p.scale : 1.0f;
   {
     const float* wr = p.w + (zh * NTOK + o0 + l31) * XW + 36 * hi;
 #pragma unroll
     for (int c = 0; c < 9; ++c) {
       const float4 v = ld4(wr + 4 * c);
-      wreg[4 * c] = v.x; wreg[4 * c + 1] = v.y; wreg[4 * c + 2] = v.z; wreg[4 * c + 3] = v.w;
+      wreg[4 * c] = v.x * pre; wreg[4 * c + 1] = v.y * pre; wreg[4 * c + 2] = v.z * pre; wreg[4 * c + 3] = v.w * pre;
     }
   }
-  const float ls_o = own_lse[o0 + l31] * RP_LOG2E, g_o = own_g[o0 + l31];
+  const float ls_o = own_lse[o0 + l31] * RP_LOG2E, g_o = own_g[o0 + l31] * pre;
   bf16x8 opk[4], wpk[5];         // bf16 mode: the 36 W columns of this half-wave as 4 x 8 + (4 live + 4 zero)
   if (BF) {
 #pragma unroll
@@ -448,7 +451,7 @@ __global__ __launch_bounds__(GT, 2) void emm_grad_kernel(EmmP p) {
   kv_gload<GT>(lb, p.ld, tid, kpre);
   x_gload(0);
   const float* lsrc = (tid & 32) ? loop_g + (tid & 31) : loop_lse + (tid & 31);      // branch-free, see emm_apply_kernel
-  const float lmul = (tid & 32) ? 1.0f : RP_LOG2E;
+  const float lmul = (tid & 32) ? pre : RP_LOG2E;
   lpre = lsrc[0] * lmul;
   f32x16 sa = zero16(), sb = zero16();
   if (LS) sload(sa, 0);
@@ -504,7 +507,10 @@ __global__ __launch_bounds__(GT, 2) void emm_grad_kernel(EmmP p) {
       // 4 KB contiguous, rows = loop index j, columns = owners i: fully coalesced 256-byte stores; rp_ds_matmul reads it (attention.hip)
       const long long tile = (zh * (NTOK / 32) + t) * (NTOK / 32) + (o0 >> 5);
       if (BF) store_acc_image_bf16(reinterpret_cast<unsigned short*>(p.ds) + tile * 1024, s, p.scale, lane);
-      else store_acc_image_lds<4>(p.ds + tile * 1024, Tst[BF ? 0 : wave], s, p.scale, lane);
+      else if (LS) {      // element (key j = row, query i = lane) at chunk (j >> 2) * 32 + i, dword j & 3 (attention.hip: store_tile_runs)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) st4(p.ds + tile * 1024 + 4 * (64 * g + lane), make_float4(s[4 * g], s[4 * g + 1], s[4 * g + 2], s[4 * g + 3]));
+      } else store_acc_image_lds<4>(p.ds + tile * 1024, Tst[(BF || LS) ? 0 : wave], s, p.scale, lane);
     }
     // d owner^T[d][owner] += sum_loop other[loop][d] dS^T[loop][owner]
     if (BF) {
@@ -543,8 +549,9 @@ __global__ __launch_bounds__(GT, 2) void emm_grad_kernel(EmmP p) {
   float* orow = p.dqkv + ((long long)own_img * NTOK + o0 + l31) * p.ld + own_col;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    st4(orow + 8 * g + 4 * hi, make_float4(d0[4 * g] * p.scale, d0[4 * g + 1] * p.scale, d0[4 * g + 2] * p.scale, d0[4 * g + 3] * p.scale));
-    st4(orow + 32 + 8 * g + 4 * hi, make_float4(d1[4 * g] * p.scale, d1[4 * g + 1] * p.scale, d1[4 * g + 2] * p.scale, d1[4 * g + 3] * p.scale));
+    const float om = LS ? 1.0f : p.scale;
+    st4(orow + 8 * g + 4 * hi, make_float4(d0[4 * g] * om, d0[4 * g + 1] * om, d0[4 * g + 2] * om, d0[4 * g + 3] * om));
+    st4(orow + 32 + 8 * g + 4 * hi, make_float4(d1[4 * g] * om, d1[4 * g + 1] * om, d1[4 * g + 2] * om, d1[4 * g + 3] * om));
   }
 }
 

@@ -1200,8 +1200,13 @@ def emm_backward(qkv, x, t, rlse, clse, df, Z, single=False, cross=False, s=None
                    4.0 * Z * HEADS * N_TOK * ((2 if s is not None else 1) * N_TOK + 3 * 64 + 2 * XW + 4)):
             _lib.check(lib.rp_emm_grad_ds(_p(qkv), ld, _p(x), _p(w), _p(rlse), _p(clse), _p(rho), _p(gam), _p(s), _p(dqkv), _p(ds), Z,
                                           HEADS, scale, sg, ATTN_BF16, _st()), "rp_emm_grad_ds")
-        # dk_z = dS_z (key-major tiles) x q_{z^1}: one streaming launch
-        ds_matmul(ds, qkv.data_ptr(), ld, dqkv.data_ptr() + 4 * DIM, ld, Z, b_xor=1)
+        # dk_z = dS_z (key-major tiles) x q_{z^1}: one streaming launch (the stored-S pass writes the 16-byte-run tiles rp_ds_matmul_t takes)
+        if s is not None:
+            with timed("ds_matmul_t", 2.0 * Z * HEADS * N_TOK * N_TOK * 64, Z * HEADS * N_TOK * (4.0 * N_TOK + 4.0 * 128)):
+                _lib.check(lib.rp_ds_matmul_t(_p(ds), ctypes.c_void_p(qkv.data_ptr()), ctypes.c_void_p(dqkv.data_ptr() + 4 * DIM), Z, HEADS,
+                                              ld, ld, 1, None, 0, _st()), "rp_ds_matmul_t")
+        else:
+            ds_matmul(ds, qkv.data_ptr(), ld, dqkv.data_ptr() + 4 * DIM, ld, Z, b_xor=1)
     else:
         _lib.check(lib.rp_emm_grad(_p(qkv), ld, _p(x), _p(w), _p(rlse), _p(clse), _p(rho), _p(gam), _p(dqkv), Z, HEADS,
                                    scale, 0, sg, ATTN_BF16, _st()), "rp_emm_grad(q)")

@@ -335,7 +335,12 @@ TIMER = None
 # backward: torch.autograd.grad or a checkpoint recompute inside a BlockFn.backward) does not share the outer block's slab arena --
 # its products reduce immediately, and the outer block resumes deferring when it closes.
 # ------------------------------------------------------------------------------------------------
-SPLITK_BATCHING = os.environ.get("RP_SPLITK_BATCH", "1") == "1"
+# Kernel-path selectors WITHOUT an environment switch (round 6: every alternative below lost its interleaved A/B two or more rounds
+# ago; the RP_* variables that used to flip them are retired).  They stay module attributes because the alternatives are real code --
+# the fallbacks other shapes and variants take -- and tests/test_gpu_entrypoints.py flips each one on a whole training step so that no
+# fallback rots: SPLITK_BATCHING, ROWS_LINEAR, ROWS_DX, FUSE_LN_BWD, DX_LNBWD_BF16, COLSUM_BATCHING, QKV_BIAS_FROM_PRODUCERS,
+# EMM_STATS_ONE_PASS, FUSE_MLP, FUSE_MLP_TRAIN, FUSE_MLP_BWD, MLP_W2_CHUNK_MAJOR, STEM_CONV, STEM_STATS, FUSE_STEM_POOL.
+SPLITK_BATCHING = True
 _TLS = threading.local()
 _ARENA = {}
 
@@ -584,10 +589,10 @@ def bf16_weight(w):
 
 # K = 192 Linear layers on the row-resident kernel (csrc/linear_rows.hip) instead of the generic LDS-DMA GEMM: exact fp32, and the
 # bf16 configuration (operand precision 1) on the same kernel with v_mfma_f32_16x16x32_bf16
-ROWS_LINEAR = os.environ.get("RP_ROWS_LINEAR", "1") != "0"
+ROWS_LINEAR = True
 
 
-ROWS_DX = os.environ.get("RP_ROWS_DX", "1") != "0"      # input-gradient GEMMs that contract over 192 (fc2, proj) likewise
+ROWS_DX = True      # input-gradient GEMMs that contract over 192 (fc2, proj) likewise
 
 
 def _rows_ok(x, W):
@@ -676,8 +681,8 @@ def linear_dx(dy, W, dact=0, aux=None, want_colsum=False, out_dtype=None):
 
 
 # LayerNorm backward fused into the epilogue of the input-gradient GEMM that feeds it (RpGemm.ln_*): the exact-fp32 GEMM only
-FUSE_LN_BWD = os.environ.get("RP_FUSE_LN_BWD", "1") == "1"
-DX_LNBWD_BF16 = os.environ.get("RP_DX_LNBWD_BF16", "1") == "1"      # A/B aid
+FUSE_LN_BWD = True
+DX_LNBWD_BF16 = True      # A/B aid
 
 
 def linear_dx_lnbwd(dy, W, x, gamma, mean, rstd, add=None):
@@ -775,7 +780,7 @@ def linear_dw(dy, x):
     return gemm(dy, x, N, K, M, a_layout=1, b_layout=1, defer=True)
 
 
-COLSUM_BATCHING = os.environ.get("RP_COLSUM_BATCH", "1") == "1"      # A/B aid
+COLSUM_BATCHING = True      # A/B aid
 _COLSUM_BATCH = None      # inside `with colsum_batch():` the (input, output) pairs collected so far
 _COLSUM_STREAM = None     # ... and the stream the block was entered on = the stream rp_colsum_multi will run on at exit
 
@@ -965,7 +970,7 @@ def ds_matmul(ds, b_base, ldb, out_base, ldo, Z, b_xor=0, colpart_base=None, ldp
                                     ctypes.c_void_p(colpart_base) if colpart_base else None, ldp, _st()), "rp_ds_matmul")
 
 
-QKV_BIAS_FROM_PRODUCERS = os.environ.get("RP_QKV_BIAS_PARTIALS", "1") != "0"      # A/B aid
+QKV_BIAS_FROM_PRODUCERS = True      # A/B aid
 
 
 def attn_bwd(qkv, o, lse, do, Z, fork=None, kv_xor=0, want_bias_partials=False, saved_p=None):
@@ -1083,7 +1088,7 @@ def emm_build_x(qkv, pos, Z):
     return x
 
 
-EMM_STATS_ONE_PASS = os.environ.get("RP_EMM_STATS_ONE_PASS", "1") == "1"      # A/B aid
+EMM_STATS_ONE_PASS = True      # A/B aid
 _stats_ws = {}
 
 
@@ -1332,8 +1337,8 @@ class TokensFn(_Fn):
 # The transformer MLP's forward: LayerNorm + fc1 + GELU + fc2 + residual as ONE kernel (csrc/mlp_fused.hip).  Inference
 # keeps the hidden activation on chip; training runs the same kernel and stores xn, h and h_pre for the backward on the way
 # (RP_FUSE_MLP_TRAIN=0: the LayerNorm+fc1 launch and the fc2 launch instead).
-FUSE_MLP = os.environ.get("RP_FUSE_MLP", "1") != "0"
-FUSE_MLP_TRAIN = os.environ.get("RP_FUSE_MLP_TRAIN", "1") != "0"
+FUSE_MLP = True
+FUSE_MLP_TRAIN = True
 _mlp_ws = {}
 
 
@@ -1373,7 +1378,7 @@ def mlp_fused(x2d, gamma, beta, w1, b1, w2, b2, eps=LN_EPS, train=False, out_dty
     return (y, xn, mean, rstd, h, hpre) if train else y
 
 
-FUSE_MLP_BWD = os.environ.get("RP_FUSE_MLP_BWD", "1") != "0"
+FUSE_MLP_BWD = True
 # the LayerNorm backward in front of fc1 on the epilogue of rp_mlp_fused_bwd (rp_mlp_fused_bwd_ln): dxn never reaches HBM.  1 = in the
 # bf16 configuration (HBM-bound there: 19.67 -> 19.48 ms per 128 pairs), 2 = also with exact fp32 operands, where the kernel is
 # matrix-bound, every workgroup's epilogue burst lands at the same moment and the fold LOSES 8 us per Block (profiles/r5_ab_mlp_bwd_ln.txt)
@@ -1394,7 +1399,7 @@ def _mlp_unit_perm(device):
     return pm
 
 
-MLP_W2_CHUNK_MAJOR = os.environ.get("RP_MLP_W2_CHUNK_MAJOR", "1") != "0"      # io_bf16 bit 4 of rp_mlp_fused_fwd / _bwd
+MLP_W2_CHUNK_MAJOR = True      # io_bf16 bit 4 of rp_mlp_fused_fwd / _bwd
 
 
 def _chunk_permuted_bf16(w, transpose=False):
@@ -2255,9 +2260,9 @@ def conv_stem_wgrad_f32(x_padded_nhwc, dy_nhwc):
     return dw
 
 
-STEM_CONV = os.environ.get("RP_STEM_CONV", "1") != "0"      # hand-written stem convolution forward
+STEM_CONV = True      # hand-written stem convolution forward
 STEM_WGRAD = os.environ.get("RP_STEM_WGRAD", "1") != "0"    # ... and (224 x 224) its weight gradient: bf16 configuration and exact fp32
-STEM_STATS = os.environ.get("RP_STEM_STATS", "1") != "0"    # ... with the BatchNorm batch statistics from its epilogue
+STEM_STATS = True    # ... with the BatchNorm batch statistics from its epilogue
 
 
 class StemConvFn(_Fn):
@@ -2323,7 +2328,7 @@ def stem_conv_ok(conv, images):
             and conv.stride == (2, 2) and conv.padding == (3, 3))
 
 
-FUSE_STEM_POOL = os.environ.get("RP_FUSE_STEM_POOL", "1") != "0"
+FUSE_STEM_POOL = True
 
 
 class BnReluPoolFn(_Fn):

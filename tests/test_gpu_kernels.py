@@ -199,7 +199,7 @@ def test_gemm_bf16_storage_of_activation_operands(ops):
 
 def test_gemm_precision1_epilogue_uses_the_bf16_configurations_gelu_pair(ops):
     """at operand precision 1 the BF instantiations of mlp_fused / linear_rows compute the sigmoid ("tanh") GELU and its exact
-    derivative; rp_gemm's GELU / GELU' epilogues -- the fallback path under RP_ROWS_LINEAR=0 / RP_ROWS_DX=0 / RP_MLP_FUSED_*=0 -- must be
+    derivative; rp_gemm's GELU / GELU' epilogues -- the fallback path (ops.ROWS_LINEAR / ROWS_DX / FUSE_MLP* = False, and every shape the row-resident kernels do not take) -- must be
     the SAME function, or forward and backward of one step disagree.  With bf16-representable operands the products are exact, so the
     epilogue is visible at fp32 accuracy: <= 3e-6 against the tanh form, and measurably (> 1e-4) away from the erf form; precisions 0
     and 3 (the fp32-grade parity modes) keep the reference's erf GELU (vision_transformer.py:397, mlp.py:22)."""

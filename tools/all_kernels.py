@@ -32,15 +32,17 @@ for _ in range(reps):
     ops.gemm(qkv, Wq, M, 192, 576, b_layout=1)        # dX of qkv: gemm_dma<0,1,...>
     ops.linear_dw(dY768, x)                           # dW split-K
     ops.linear_dw(dY192, h)
-    o, lse = ops.attn_fwd(qkv, Z)
-    ops.attn_bwd(qkv, o, lse, dY192, Z)
-    # EMM
+    ops.mlp_fused(x, g1, be1, W1, b1, W2, b2, train=True)      # training MLP forward (stores xn, h, h_pre)
+    ops.attn_fwd(qkv, Z)                                       # inference attention
+    o, lse, pst, mrun = ops.attn_fwd(qkv, Z, save_p=True)      # training attention: stored-P forward
+    ops.attn_bwd(qkv, o, lse, dY192, Z, want_bias_partials=True, saved_p=(pst, mrun))      # dkdv_p + ds_matmul_t
+    # EMM (stored-S form)
     pos = ops.posenc(intr, Z // 2, dev)
     X = ops.emm_build_x(qkv, pos, Z)
-    rlse, clse = ops.emm_stats(qkv, Z)
-    t, f = ops.emm_apply(qkv, X, rlse, clse, Z)
+    rlse, clse, sc = ops.emm_stats(qkv, Z, want_s=True)
+    t, f = ops.emm_apply(qkv, X, rlse, clse, Z, s=sc)
     df = torch.randn(Z, 3, 96, 96, device=dev) * 0.01
-    ops.emm_backward(qkv, X, t, rlse, clse, df, Z)
+    ops.emm_backward(qkv, X, t, rlse, clse, df, Z, s=sc)
     y, mu, rs = ops.layernorm_fwd(x, torch.ones(192, device=dev), torch.zeros(192, device=dev))
     ops.layernorm_bwd(dY192, x, torch.ones(192, device=dev), mu, rs)
 torch.cuda.synchronize()

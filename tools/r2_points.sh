@@ -1,4 +1,5 @@
 #!/bin/bash
+# (historical: round-2/3 evidence recipe; the RP_ROWS_* / RP_FUSE_MLP* / RP_EMM_STATS_ONE_PASS switches it flips were retired in round 6 -- set the ops.* attribute instead)
 # round-2 end state: the other operating points of bench.py and the per-kernel timing tools (all 1 GPU)
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out

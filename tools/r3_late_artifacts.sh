@@ -1,4 +1,5 @@
 #!/bin/bash
+# (historical: round-2/3 evidence recipe; the RP_ROWS_* / RP_FUSE_MLP* / RP_EMM_STATS_ONE_PASS switches it flips were retired in round 6 -- set the ops.* attribute instead)
 # late round-3 evidence (run on the GPU box from the repo root; lands in gpurun_out/, copy what is judged into profiles/)
 set -x
 O=gpurun_out

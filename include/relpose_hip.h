@@ -36,8 +36,8 @@ extern "C" {
  * functions this header declares.  rp_abi_version() / rp_abi_export_count() return the values the library was COMPILED with, so a
  * binding (rel_pose_amd/_lib.py parses both macros and counts the declarations) rejects a stale .so at load time instead of
  * failing later on a missing symbol. */
-#define RP_ABI_VERSION 20
-#define RP_ABI_EXPORTS 104
+#define RP_ABI_VERSION 21
+#define RP_ABI_EXPORTS 106
 int rp_abi_version(void);
 int rp_abi_export_count(void);
 const char* rp_target_arch(void);
@@ -226,6 +226,14 @@ int rp_conv3x3_c64_wgrad_f32_blocks(int N);
 size_t rp_conv3x3_c64_wgrad_f32_workspace_bytes(int N);
 int rp_conv3x3_c64_wgrad_f32(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes, int N, int H, int W,
                              void* stream);
+/* The same convolution's FORWARD in exact fp32 (csrc/conv3x3_f32.hip): y [N,56,56,64] = conv3x3(x [N,56,56,64], w [64 co][3][3][64 ci]), stride 1,
+ * pad 1, NHWC memory, w = the memory of a channels-last [64,64,3,3] weight (src/model.py:131's BasicBlock convolutions, which the reference
+ * runs through cuDNN).  The filter lives in registers (a wave owns 16 output channels: 144 VGPRs of A operands of
+ * v_mfma_f32_16x16x4_f32), the input rows in a padded LDS ring read by one conflict-free ds_read_b32 per MFMA; one persistent
+ * workgroup per CU (rp_conv3x3_c64_f32_blocks).  input_gradient != 0: x is dY and y is dX of the same convolution -- the filter
+ * w'[ci][r][s][co] = w[co][2 - r][2 - s][ci] is read out of the forward weight w (no rotated copy). */
+int rp_conv3x3_c64_f32_blocks(int N);
+int rp_conv3x3_c64_f32(const float* x, const float* w, float* y, int N, int H, int W, int input_gradient, void* stream);
 
 /* The stem's BatchNorm -> ReLU -> MaxPool2d(3, 2, 1) chain (src/model.py:127-130 on torchvision's resnet.bn1 / relu / maxpool) without
  * the [N,H,W,C] intermediates.  Forward (after rp_bn_stats, or with the running statistics in eval): y [N,OH,OW,C], idx = window

@@ -1,0 +1,190 @@
+// conv3x3_f32.hip -- the 3x3 / stride 1 / pad 1, 64 -> 64 convolutions of resnet.layer1 in EXACT fp32 (the headline configuration;
+// src/model.py:131's BasicBlock convolutions, which the reference runs through cuDNN), forward and -- with the filter rotated and its
+// channel roles swapped by the host -- input gradient:
+//
+//     Y[n, y, x, co] = sum over (r, s, ci) of X[n, y + r - 1, x + s - 1, ci] * W[co][r][s][ci]          (X zero outside the image)
+//
+// MIOpen's implicit-GEMM solvers run this shape at 0.71 (forward, 267 us at 128 images) and 0.61 (backward-data, 307 us) of the fp32
+// MFMA peak.  Here:
+//   * the FILTER LIVES IN REGISTERS: wave w owns 16 output channels and keeps their 9 x 64 filter values as the A operands of
+//     v_mfma_f32_16x16x4_f32 (lane (co = l & 15, kq = l >> 4) holds W[co][tap][4 kk + kq]: 144 VGPRs), one wave per SIMD, persistent
+//     workgroup per CU walking pairs of image rows;
+//   * the INPUT is the B operand: a pair of output rows is 112 pixels = seven 16-pixel blocks; lane (px = l & 15, kq) reads
+//     X[pixel + tap][4 kk + kq] from an LDS ring of six 58-position row slots (position 0 / 57 = the zero padding) whose pixel stride is
+//     66 floats -- the 16 pixels x 2 channels of a half-wave hit 32 different banks -- with ONE conflict-free ds_read_b32 per MFMA, the tap column and the
+//     k-step in the immediate offset (next to fp32 MFMAs LDS instructions are free, VALU instructions are not: profiles/r5_shadow_lab.txt).
+//     16x16x4 because it holds the matrix pipe's rate at any occupancy and its 4-deep k-step is what makes the padded layout conflict-free;
+//   * a tile (two rows) needs input rows y - 1 .. y + 2 and fetches only the two new ones, one tile ahead, through registers (the padded
+//     layout rules LDS-DMA out; 7 loads + 14 ds_write_b64 per thread per 1008 MFMAs); rows outside the image read a seventh, permanently
+//     zero slot (an address select per tile, no branch in the loop);
+//   * operands are read one k-step ahead by asm ds_read_b32, one read behind each MFMA, with a counted wait per MFMA written out by hand
+//     (hipcc sinks C++-level reads next to their MFMAs behind lgkmcnt(0)); the accumulators (co = rows, pixels = columns) leave as one
+//     16-byte store per lane and block.
+#include <type_traits>
+#include "common.h"
+#include "../../include/relpose_hip.h"
+
+namespace {
+
+constexpr int C = 64, IW = 56, IH = 56;
+constexpr int PS = 66;                         // floats per pixel position in LDS: 2 (mod 32) -- the LDS has 32 banks and serves 32 lanes per
+                                               // cycle: lanes 0-31 = 16 pixels x k in {0, 1} land on banks 2 px + k, all different (68 = 4 mod 32
+                                               // made pixels p and p + 8 collide: LDS conflict 0.49 in the counters)
+constexpr int ROWF = (IW + 2) * PS + 28;       // floats of one row slot (58 positions + pad to 16 mod 32: the block that straddles the two rows
+                                               // of a tile reads two slots)
+constexpr int NSLOT = 6;                       // ring slots; slot 6 = a row of zeros
+constexpr int TPI = IH / 2;                    // 28 tiles (row pairs) per image
+constexpr int NBLK = 7;                        // 16-pixel blocks per tile
+
+struct CvF {
+  const float* x;       // [N,56,56,64]
+  const float* w;       // [64 co][3][3][64 ci]
+  float* y;             // [N,56,56,64]
+  int ntiles;           // N * 28
+  int dgrad;            // 0: filter W[co][r][s][ci] as it lies; 1: the input gradient's filter W'[ci][r][s][co] = W[co][2 - r][2 - s][ci], read
+                        // from the SAME forward weight (strided, 144 loads per lane once per workgroup: no rotated copy, no extra launch)
+};
+
+template <int OFF> RP_DEV float rd32c(unsigned addr) {
+  float v;
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <int N, class F> RP_DEV void sforc(F&& f) {
+  if constexpr (N > 0) {
+    sforc<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void conv3x3_c64_f32_kernel(CvF p) {
+  __shared__ __attribute__((aligned(16))) float Xr[NSLOT + 1][ROWF];      // 107 968 B
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, kq = lane >> 4;
+  const int G = gridDim.x, b = blockIdx.x;
+  const int t0 = (int)((long long)p.ntiles * b / G), t1 = (int)((long long)p.ntiles * (b + 1) / G);
+  if (t0 >= t1) return;
+  const unsigned xs0 = lds_byte_addr(&Xr[0][0]);
+  // staging: the two rows g, g + 1 (flattened (image, row) index) = 1792 float4, 7 per thread: float4 f -> row f / 896, pixel (f % 896) / 16
+  float4 pre[7], pre2[7];
+  auto gload = [&](float4 (&r)[7], int g) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int f = tid + 256 * i;
+      const int row = min(g + f / 896, p.ntiles * 2 - 1);      // (clamped re-fetch at the very end: harmless)
+      r[i] = ld4(p.x + ((long long)row * IW) * C + (f % 896) * 4);
+    }
+  };
+  auto sstore = [&](const float4 (&v)[7], int g) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int f = tid + 256 * i, r = f / 896, rem = f % 896;
+      float2* d = reinterpret_cast<float2*>(&Xr[(g + r) % NSLOT][((rem >> 4) + 1) * PS + (rem & 15) * 4]);      // (8-byte aligned: PS is even)
+      d[0] = make_float2(v[i].x, v[i].y);
+      d[1] = make_float2(v[i].z, v[i].w);
+    }
+  };
+  // prologue, every request out before anything is waited for (the launch's fixed cost is what separates 128 images from the kernel's
+  // steady state): rows 2 t0 - 1 .. 2 t0 + 2 (0 .. 3 for the very first tile: row 3 is then simply early), the filter, the zeros
+  const int a0 = max(2 * t0 - 1, 0);
+  gload(pre, a0);
+  gload(pre2, a0 + 2);
+  // the filter of this wave's 16 output channels: A operand of k-step (tap, kk) = W[16 wave + l15][tap][4 kk + kq]
+  float wreg[9][16];
+  {
+    // A[m = output channel 16 wave + l15][k = input channel 4 kk + kq] of tap (r, s)
+    const int so = p.dgrad ? 1 : 9 * C, si = p.dgrad ? 9 * C : 1;
+    const float* wp = p.w + (long long)(16 * wave + l15) * so + (long long)kq * si;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) wreg[tap][kk] = wp[(p.dgrad ? 8 - tap : tap) * C + (long long)(4 * kk) * si];
+  }
+  // zero padding of the ring slots (staging only ever writes positions 1 .. 56) and the zero row
+  for (int i = tid; i < NSLOT * 2 * PS; i += 256) Xr[i / (2 * PS)][((i / PS) & 1) * (IW + 1) * PS + (i % PS)] = 0.f;
+  for (int i = tid; i < ROWF; i += 256) Xr[NSLOT][i] = 0.f;
+  sstore(pre, a0);
+  sstore(pre2, a0 + 2);
+  __syncthreads();
+
+  // per-lane pixel of each 16-pixel block: flattened index 16 j + l15 of the two rows -> (row 0 / 1, column)
+  int orow[NBLK], ocol[NBLK];
+#pragma unroll
+  for (int j = 0; j < NBLK; ++j) {
+    const int pxi = 16 * j + l15;
+    orow[j] = pxi >= IW ? 1 : 0;
+    ocol[j] = pxi - IW * orow[j];
+  }
+
+  for (int t = t0; t < t1; ++t) {
+    const int y = 2 * (t % TPI), g0 = 2 * t;
+    if (t + 1 < t1) gload(pre, g0 + 3);                  // next tile's two new rows
+    // operand addresses: block j, tap row r -> slot of input row g0 + orow + r - 1 (zero slot outside the image) + column * PS + kq
+    unsigned xa[NBLK][3];
+    const int m0 = (g0 + NSLOT - 1) % NSLOT;             // slot of row g0 - 1
+#pragma unroll
+    for (int j = 0; j < NBLK; ++j)
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int yin = y + orow[j] + r - 1;
+        int slot = m0 + orow[j] + r;
+        slot = slot >= NSLOT ? slot - NSLOT : slot;
+        slot = (yin < 0 || yin >= IH) ? NSLOT : slot;
+        xa[j][r] = xs0 + (unsigned)(slot * ROWF + ocol[j] * PS + kq) * 4u;
+      }
+    f32x4 acc[NBLK];
+#pragma unroll
+    for (int j = 0; j < NBLK; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // Two operand register sets, picked by the k-step's parity at compile time.  The seven reads of k-step k + 1 go out ONE BEHIND EACH
+    // MFMA of k-step k (a block of seven reads per k-step left the matrix pipe drained while they issued: 19 % of the tile), and each MFMA
+    // waits only for ITS operand: the LDS queue retires in order and exactly six younger reads are in flight in front of it -- lgkmcnt(6).
+    float b0[NBLK], b1[NBLK];
+#pragma unroll
+    for (int j = 0; j < NBLK; ++j) b0[j] = rd32c<0>(xa[j][0]);
+    sforc<144>([&](auto kc) {
+      constexpr int k = kc, tap = k / 16, kk = k % 16;
+      float (&bc)[NBLK] = (k & 1) ? b1 : b0;
+      float (&bn)[NBLK] = (k & 1) ? b0 : b1;
+      sforc<NBLK>([&](auto jc) {
+        constexpr int j = jc;
+        if constexpr (k + 1 < 144) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(bc[j]));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bc[j]));
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[tap][kk], bc[j], acc[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (k + 1 < 144) {
+          constexpr int k1 = k + 1, tap1 = k1 / 16, kk1 = k1 % 16, r1 = tap1 / 3, s1 = tap1 % 3;
+          constexpr int off = (s1 * PS + 4 * kk1) * 4;
+          bn[j] = rd32c<off>(xa[j][r1]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
+    });
+    // D[m = co 4 kq + e][n = pixel l15]: four consecutive output channels of one pixel per lane
+#pragma unroll
+    for (int j = 0; j < NBLK; ++j) {
+      float* o = p.y + (((long long)g0 + orow[j]) * IW + ocol[j]) * C + 16 * wave + 4 * kq;
+      st4(o, make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]));
+    }
+    if (t + 1 < t1) sstore(pre, g0 + 3);                      // slots of rows g0 + 3, g0 + 4: not among this tile's g0 - 1 .. g0 + 2
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+extern "C" int rp_conv3x3_c64_f32_blocks(int N) {
+  const int tiles = N * TPI;
+  return tiles < 256 ? tiles : 256;
+}
+
+/* y [N,56,56,64] = conv3x3(x [N,56,56,64], w [64][3][3][64]), stride 1, pad 1, exact fp32 (NHWC memory; w = the memory of a channels-last
+ * [64,64,3,3] weight).  input_gradient != 0: x is dY and the result is dX of the same convolution -- the filter w'[ci][r][s][co] =
+ * w[co][2 - r][2 - s][ci] is read out of the forward weight w. */
+extern "C" int rp_conv3x3_c64_f32(const float* x, const float* w, float* y, int N, int H, int W, int input_gradient, void* stream) {
+  if (!x || !w || !y || N <= 0) return RP_EBADSHAPE;
+  if (H != IH || W != IW) return RP_EUNSUPPORTED;
+  if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) return RP_EALIGN;
+  CvF p{x, w, y, N * TPI, input_gradient ? 1 : 0};
+  hipLaunchKernelGGL(conv3x3_c64_f32_kernel, dim3(rp_conv3x3_c64_f32_blocks(N)), dim3(256), 0, (hipStream_t)stream, p);
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}

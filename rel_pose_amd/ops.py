@@ -1982,10 +1982,40 @@ CONV3X3_WGRAD_F32 = os.environ.get("RP_CONV3X3_WGRAD_F32", "1") != "0"
 CONV3X3_WGRAD_F32_MIN_N = int(os.environ.get("RP_CONV3X3_WGRAD_F32_MIN_N", "56"))
 
 
+# ... and, from CONV3X3_F32_MIN_N images up, their forward and input gradient on csrc/conv3x3_f32.hip (filter in registers, padded LDS
+# ring): 128 images: forward MIOpen 267 us, input gradient 307 us (profiles/r2_conv_probe.txt).  A persistent workgroup per CU: small
+# batches leave CUs idle, MIOpen's tiling wins there.
+CONV3X3_F32 = os.environ.get("RP_CONV3X3_F32", "1") != "0"
+CONV3X3_F32_MIN_N = int(os.environ.get("RP_CONV3X3_F32_MIN_N", "56"))
+
+
+def conv3x3_c64_f32(x_nhwc, w_ohwi, input_gradient=False):
+    """rp_conv3x3_c64_f32: y = conv3x3(x, w), stride 1, pad 1, exact fp32, for x [N,56,56,64] (NHWC memory) and w [64,3,3,64] (the memory
+    of a channels-last [64,64,3,3] weight) -> y [N,56,56,64].  input_gradient: x is dY, the result dX of that convolution (the rotated,
+    channel-swapped filter is read out of the forward weight by the kernel)."""
+    lib = _lib.load()
+    if not (x_nhwc.is_cuda and x_nhwc.is_contiguous() and x_nhwc.dtype == torch.float32 and tuple(x_nhwc.shape[1:]) == (56, 56, 64)):
+        raise RuntimeError("conv3x3_c64_f32: contiguous fp32 [N,56,56,64] GPU tensor expected")
+    if not (w_ohwi.is_cuda and w_ohwi.is_contiguous() and w_ohwi.dtype == torch.float32 and tuple(w_ohwi.shape) == (64, 3, 3, 64)):
+        raise RuntimeError("conv3x3_c64_f32: contiguous fp32 [64,3,3,64] GPU filter expected")
+    N = x_nhwc.shape[0]
+    y = torch.empty_like(x_nhwc)
+    with timed("conv3x3_c64_f32", 2.0 * N * 56 * 56 * 64 * 64 * 9, 4.0 * N * 56 * 56 * 128):
+        _lib.check(lib.rp_conv3x3_c64_f32(_p(x_nhwc), _p(w_ohwi), _p(y), N, 56, 56, 1 if input_gradient else 0, _st()), "rp_conv3x3_c64_f32")
+    return y
+
+
+def _nhwc(t):
+    r = t.permute(0, 2, 3, 1)
+    return r if r.is_contiguous() else r.contiguous()
+
+
 class Conv3x3C64F32Fn(_Fn):
     @staticmethod
     def forward(ctx, x, w):
         ctx.save_for_backward(x, w)
+        if CONV3X3_F32 and x.shape[0] >= CONV3X3_F32_MIN_N:
+            return conv3x3_c64_f32(_nhwc(x), _nhwc(w)).permute(0, 3, 1, 2)        # (channels-last NCHW view of the NHWC result)
         return torch.nn.functional.conv2d(x, w, None, 1, 1)
 
     @staticmethod
@@ -1994,7 +2024,11 @@ class Conv3x3C64F32Fn(_Fn):
         dx = dw = None
         dy = dy.contiguous(memory_format=torch.channels_last)
         if ctx.needs_input_grad[0]:
-            dx = torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+            if CONV3X3_F32 and x.shape[0] >= CONV3X3_F32_MIN_N:
+                # dX = conv3x3(dY, w') with w'[ci][r][s][co] = w[co][2 - r][2 - s][ci], read out of w by the kernel
+                dx = conv3x3_c64_f32(_nhwc(dy), _nhwc(w), input_gradient=True).permute(0, 3, 1, 2)
+            else:
+                dx = torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0]
         if ctx.needs_input_grad[1]:
             xr = x.permute(0, 2, 3, 1)
             dw = conv3x3_c64_wgrad_f32(xr if xr.is_contiguous() else xr.contiguous(), dy.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)

@@ -2030,8 +2030,10 @@ class Conv3x3C64F32Fn(_Fn):
             else:
                 dx = torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0]
         if ctx.needs_input_grad[1]:
-            xr = x.permute(0, 2, 3, 1)
-            dw = conv3x3_c64_wgrad_f32(xr if xr.is_contiguous() else xr.contiguous(), dy.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
+            if CONV3X3_WGRAD_F32 and x.shape[0] >= CONV3X3_WGRAD_F32_MIN_N:
+                dw = conv3x3_c64_wgrad_f32(_nhwc(x), dy.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
+            else:
+                dw = torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
         return dx, dw
 
 
@@ -2040,6 +2042,13 @@ def conv3x3_wgrad_f32_ok(m, x):
             and m.weight.requires_grad and tuple(m.weight.shape) == (64, 64, 3, 3) and m.bias is None and m.stride == (1, 1)
             and m.padding == (1, 1) and m.dilation == (1, 1) and m.groups == 1 and tuple(x.shape[1:]) == (64, 56, 56)
             and x.shape[0] >= CONV3X3_WGRAD_F32_MIN_N)
+
+
+def conv3x3_f32_ok(m, x):
+    """the hand-written exact-fp32 forward / input gradient applies (training or inference)"""
+    return (CONV3X3_F32 and CNN_PRECISION == 0 and x.is_cuda and x.dtype == torch.float32 and tuple(m.weight.shape) == (64, 64, 3, 3)
+            and m.bias is None and m.stride == (1, 1) and m.padding == (1, 1) and m.dilation == (1, 1) and m.groups == 1
+            and tuple(x.shape[1:]) == (64, 56, 56) and x.shape[0] >= CONV3X3_F32_MIN_N)
 
 
 def conv3x3_own_ok(m, x):
@@ -2056,7 +2065,7 @@ def conv2d(m, x, want_stats=False):
             return Conv3x3C64Fn.apply(xb, m._rp_bf16[0], True)
         return conv2d(m, x), None
     if CNN_PRECISION == 0 or not x.is_cuda:
-        if conv3x3_wgrad_f32_ok(m, x):
+        if conv3x3_wgrad_f32_ok(m, x) or conv3x3_f32_ok(m, x):
             return Conv3x3C64F32Fn.apply(x, m.weight)
         return m(x)
     bf = torch.bfloat16

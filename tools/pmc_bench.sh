@@ -16,7 +16,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for f in glob.glob('/tmp/pmc_%s/**/*counter_collection.csv' % c, recursive=True):
         for r in csv.DictReader(open(f)):
             k = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('rpgemm::', '').replace('void ', '').split('(')[0]
-            if not any(s in k for s in ('gemm_', 'attn_', 'emm_', 'colsum', 'ln_', 'splitk', 'tokens', 'rowdot', 'mlp_', 'linear_', 'ds_matmul', 'dw192', 'conv3x3', 'dx_lnbwd')):
+            if not any(s in k for s in ('gemm_', 'attn_', 'emm_', 'colsum', 'ln_', 'splitk', 'tokens', 'rowdot', 'mlp_', 'linear_', 'ds_matmul', 'dw192', 'conv3x3', 'conv_stem', 'dx_lnbwd')):
                 continue
             acc[k][c] += float(r['Counter_Value']); n[k] += 1
     for k, v in n.items():

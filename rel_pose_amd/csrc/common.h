@@ -208,13 +208,16 @@ RP_DEV float4 widen4(uint2 w) {          // 4 bf16 -> fp32 (exact)
 }
 // lane (j, q) holds units 4q..4q+3 of a 32-unit chunk's first 16 (v0) and second 16 (v1); after swapping halves with lane q ^ 1
 // (lane ^ 16) it stores 8 consecutive bf16: even q -> [own v0 | partner's v0], odd q -> [partner's v1 | own v1]
+template <bool NTS = false>      // NTS: non-temporal store (a LATER kernel reads the row)
 RP_DEV void st_bf16x8(unsigned short* dst, float4 v0, float4 v1, int q) {
   const unsigned a0 = pk_bf16(v0.x, v0.y), a1 = pk_bf16(v0.z, v0.w), b0 = pk_bf16(v1.x, v1.y), b1 = pk_bf16(v1.z, v1.w);
   const bool odd = q & 1;
   const unsigned s0 = odd ? a0 : b0, s1 = odd ? a1 : b1;
   const unsigned r0 = __shfl_xor(s0, 16, 64), r1 = __shfl_xor(s1, 16, 64);
-  const uint4 w = odd ? make_uint4(r0, r1, b0, b1) : make_uint4(a0, a1, r0, r1);
-  *reinterpret_cast<uint4*>(dst) = w;
+  typedef unsigned u4v __attribute__((ext_vector_type(4)));
+  const u4v w = odd ? u4v{r0, r1, b0, b1} : u4v{a0, a1, r0, r1};
+  if (NTS) __builtin_nontemporal_store(w, reinterpret_cast<u4v*>(dst));
+  else *reinterpret_cast<u4v*>(dst) = w;
 }
 // the inverse for a bf16 aux row: one 16-byte load of 8 consecutive units per lane, halves swapped back into (v0, v1)
 RP_DEV void ld_bf16x8(const unsigned short* src, float4& v0, float4& v1, int q) {
@@ -257,6 +260,10 @@ RP_DEV const float* uniform_ptr(const float* p) {      // SGPR pair for the DMA 
 
 RP_DEV float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 RP_DEV void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+RP_DEV void st4_nt(float* p, float4 v) {      // non-temporal: for data a LATER kernel reads (it would only displace what this one re-reads)
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  __builtin_nontemporal_store(f4v{v.x, v.y, v.z, v.w}, reinterpret_cast<f4v*>(p));
+}
 
 #define RP_CHECK_LAUNCH()                         \
   do {                                            \

@@ -409,15 +409,17 @@ __global__ __launch_bounds__(NW * 64, WPS) void mlp_fused_kernel(MlpP p) {
         if (it + 1 < end) issue_w1(((it + 1) % NCHUNK));
       }
       if (TRAIN && live) {      // (after the DMA issue, like MODE 1's stores)
+        // h and h_pre are read by the BACKWARD, long after they have left every cache (590 MB per launch in fp32): non-temporal stores,
+        // so that their lines do not displace the weight tiles this kernel keeps re-reading from L2 (round 6, like the stored-P tiles)
         if (dhp_bf) {           // bf16 configuration: the hidden tensors live in bf16
-          st_bf16x8(reinterpret_cast<unsigned short*>(p.dhp) + ho + bfo, pre0, pre1, q);
-          st_bf16x8(reinterpret_cast<unsigned short*>(p.h_out) + ho + bfo, make_float4(h0[0], h0[1], h0[2], h0[3]),
-                    make_float4(h1[0], h1[1], h1[2], h1[3]), q);
+          st_bf16x8<true>(reinterpret_cast<unsigned short*>(p.dhp) + ho + bfo, pre0, pre1, q);
+          st_bf16x8<true>(reinterpret_cast<unsigned short*>(p.h_out) + ho + bfo, make_float4(h0[0], h0[1], h0[2], h0[3]),
+                          make_float4(h1[0], h1[1], h1[2], h1[3]), q);
         } else {
-          st4(p.dhp + ho, pre0);
-          st4(p.dhp + ho + 16, pre1);
-          st4(p.h_out + ho, make_float4(h0[0], h0[1], h0[2], h0[3]));
-          st4(p.h_out + ho + 16, make_float4(h1[0], h1[1], h1[2], h1[3]));
+          st4_nt(p.dhp + ho, pre0);
+          st4_nt(p.dhp + ho + 16, pre1);
+          st4_nt(p.h_out + ho, make_float4(h0[0], h0[1], h0[2], h0[3]));
+          st4_nt(p.h_out + ho + 16, make_float4(h1[0], h1[1], h1[2], h1[3]));
         }
       }
       if (MODE == 1) {          // after the DMA issue: these stores have the whole of GEMM2 to retire before the next vmcnt(0)

@@ -263,7 +263,7 @@ TAG_SYMBOLS = {
     "emm_apply": "emm_apply_kernel<false>", "emm_grad_ds": "emm_grad_kernel<false, false>",
     "emm_apply_s": "emm_apply_s_kernel", "emm_grad_ds_s": "emm_grad_kernel<false, true>",
     "linear_rows_ln": "linear_rows_kernel<true, false>", "linear_rows": "linear_rows_kernel<false, false>",
-    "dw192_bf16": "dw192_bf16_kernel<false>", "dw192_bf16_f32b": "dw192_bf16_kernel<true>", "dw192_f32": "dw192_f32_kernel",
+    "dw192_bf16": "dw192_bf16_kernel<false>", "dw192_bf16_f32b": "dw192_bf16_kernel<true>", "dw192_f32": "dw192_f32_kernel", "dw192_split3": "dw192_split3_kernel",
     "attn_fwd_bf16": "attn_fwd_bf16_kernel<2, false, 1>", "attn_stats_bf16": "attn_fwd_bf16_kernel<3, true, 1>", "attn_bwd_bf16": "attn_bwd_dkdv_bf16_kernel + attn_bwd_dq_bf16_kernel",
     "dx_lnbwd_bf16": "dx_lnbwd_bf16_kernel",
     "emm_apply_bf16": "emm_apply_bf16_kernel", "emm_grad_bf16": "emm_grad_bf16_kernel",

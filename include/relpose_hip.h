@@ -36,8 +36,8 @@ extern "C" {
  * functions this header declares.  rp_abi_version() / rp_abi_export_count() return the values the library was COMPILED with, so a
  * binding (rel_pose_amd/_lib.py parses both macros and counts the declarations) rejects a stale .so at load time instead of
  * failing later on a missing symbol. */
-#define RP_ABI_VERSION 21
-#define RP_ABI_EXPORTS 106
+#define RP_ABI_VERSION 22
+#define RP_ABI_EXPORTS 107
 int rp_abi_version(void);
 int rp_abi_export_count(void);
 const char* rp_target_arch(void);
@@ -449,6 +449,11 @@ size_t rp_dw192_f32_workspace_bytes(int M, int N);
 /* the same product in EXACT fp32 (csrc/dw192_f32.hip; A and B fp32, M a multiple of 32): output-stationary [192 x 192] tiles, one wave
  * per SIMD on v_mfma_f32_32x32x2_f32, LDS-DMA stages -- the parity path's weight gradients (replaces rp_gemm's split-K form for them) */
 int rp_dw192_f32(const float* a, int lda, const float* b, int M, int N, void* workspace, size_t workspace_bytes, void* stream);
+/* the same product, same arguments, same slabs (rp_dw192_f32_splits / _workspace_bytes), on the BF16 matrix pipe at fp32 grade
+ * (csrc/dw192_split3.hip): each fp32 operand is split on chip into three round-to-nearest bf16 limbs (error-free: 3 x 8 bits = 24) and six
+ * of the nine limb products are accumulated in fp32 on v_mfma_f32_32x32x16_bf16; the dropped terms are <= 2^-26 of each product.  OPT-IN
+ * (RP_DW_SPLIT3=1): the default weight gradients stay on rp_dw192_f32's exact fp32 MFMAs.  An Inf operand gives NaN. */
+int rp_dw192_split3(const float* a, int lda, const float* b, int M, int N, void* workspace, size_t workspace_bytes, void* stream);
 int rp_dw192_bf16_splits(int M, int N);
 size_t rp_dw192_bf16_workspace_bytes(int M, int N);
 int rp_dw192_bf16(const void* a, int lda, const void* b, int b_is_f32, int M, int N, void* workspace, size_t workspace_bytes, void* stream);

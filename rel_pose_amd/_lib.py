@@ -105,6 +105,7 @@ _SIGS = {
     "rp_dw192_f32_splits": (c_int, [I, I]),
     "rp_dw192_f32_workspace_bytes": (c_size_t, [I, I]),
     "rp_dw192_f32": (c_int, [P, I, P, I, I, P, c_size_t, P]),
+    "rp_dw192_split3": (c_int, [P, I, P, I, I, P, c_size_t, P]),
     "rp_dw192_bf16_splits": (c_int, [I, I]),
     "rp_dw192_bf16_workspace_bytes": (c_size_t, [I, I]),
     "rp_dw192_bf16": (c_int, [P, I, P, I, I, I, P, c_size_t, P]),

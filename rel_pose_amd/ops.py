@@ -719,6 +719,9 @@ DW192 = os.environ.get("RP_DW192", "1") == "1"      # A/B aid: the streaming bf1
 
 
 DW192_F32 = os.environ.get("RP_DW192_F32", "1") == "1"      # A/B aid: the output-stationary exact-fp32 weight-gradient kernel
+# OPT-IN (the split-bf16x3 gate): the same weight gradients on the bf16 matrix pipe from on-chip 3-limb splits of the
+# fp32 operands (csrc/dw192_split3.hip; error vs fp64 <= the fp32 MFMA kernel's).  The default stays exact fp32 MFMA.
+DW_SPLIT3 = os.environ.get("RP_DW_SPLIT3", "0") == "1"
 
 
 def _dw192(a, b, out, trans):
@@ -732,7 +735,10 @@ def _dw192(a, b, out, trans):
     nbytes = (lib.rp_dw192_f32_workspace_bytes if f32 else lib.rp_dw192_bf16_workspace_bytes)(M, N)
     deferred = (_sk_batch() is not None and torch.cuda.current_stream(a.device).cuda_stream == _sk_batch()[2])
     ws = _arena_take(nbytes, a.device, _sk_batch()[1]) if deferred else _workspace(nbytes, a.device)
-    if f32:
+    if f32 and DW_SPLIT3:
+        with timed("dw192_split3", 2.0 * M * N * DIM, 4.0 * (M * (N + DIM) + sk * N * DIM)):
+            _lib.check(lib.rp_dw192_split3(_p(a), N, _p(b), M, N, _p(ws), nbytes, _st()), "rp_dw192_split3")
+    elif f32:
         with timed("dw192_f32", 2.0 * M * N * DIM, 4.0 * (M * (N + DIM) + sk * N * DIM)):
             _lib.check(lib.rp_dw192_f32(_p(a), N, _p(b), M, N, _p(ws), nbytes, _st()), "rp_dw192_f32")
     else:

@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librelpose_hip.so")
-SOURCES = ["gemm.hip", "gemm_dma.hip", "rowwise.hip", "attention.hip", "attention_bf16.hip", "dw192_bf16.hip", "dw192_f32.hip", "dw192_split3.hip", "dx_lnbwd_bf16.hip", "emm.hip", "emm_bf16.hip", "batchnorm.hip", "se3loss.hip", "geom.hip", "augment.hip", "mlp_fused.hip", "linear_rows.hip", "conv_stem.hip", "conv_stem_bf16.hip", "conv_stem_wgrad_bf16.hip", "conv_stem_wgrad_f32.hip", "conv3x3_bf16.hip", "conv3x3_wgrad_bf16.hip", "conv3x3_wgrad_f32.hip", "conv3x3_f32.hip"]
+SOURCES = ["gemm.hip", "gemm_dma.hip", "rowwise.hip", "attention.hip", "attention_bf16.hip", "dw192_bf16.hip", "dw192_f32.hip", "dw192_split3.hip", "dx_lnbwd_bf16.hip", "emm.hip", "emm_bf16.hip", "batchnorm.hip", "se3loss.hip", "geom.hip", "augment.hip", "mlp_fused.hip", "linear_rows.hip", "conv_stem.hip", "conv_stem_bf16.hip", "conv_stem_wgrad_bf16.hip", "conv_stem_wgrad_f32.hip", "conv3x3_bf16.hip", "conv3x3_wgrad_bf16.hip", "conv3x3_wgrad_f32.hip", "conv3x3_f32.hip", "conv3x3_c128_f32.hip"]
 ARCH = "gfx950"
 
 

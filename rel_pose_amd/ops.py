@@ -2043,6 +2043,69 @@ class Conv3x3C64F32Fn(_Fn):
         return dx, dw
 
 
+# The 128-input-channel 3x3 convolutions on 28 x 28 maps (resnet.layer2's 128 -> 128 convolutions forward and input gradient, the forward of
+# extractor_final_conv.conv1 128 -> 192) on csrc/conv3x3_c128_f32.hip from CONV3X3_C128_F32_MIN_N images up; their weight (and bias)
+# gradients stay on MIOpen.  RP_CONV3X3_C128_F32=0: MIOpen for all of it (A/B aid).
+CONV3X3_C128_F32 = os.environ.get("RP_CONV3X3_C128_F32", "1") != "0"
+CONV3X3_C128_F32_MIN_N = int(os.environ.get("RP_CONV3X3_C128_F32_MIN_N", "56"))
+
+
+def conv3x3_c128_f32(x_nhwc, w_ohwi, bias=None, input_gradient=False):
+    """rp_conv3x3_c128_f32: y = bias + conv3x3(x, w), stride 1, pad 1, exact fp32, for x [N,28,28,128] (NHWC memory) and w [CO,3,3,128]
+    (the memory of a channels-last [CO,128,3,3] weight), CO = 128 or 192 -> y [N,28,28,CO].  input_gradient (CO = 128, no bias): x is dY,
+    the result dX of the convolution whose forward weight is w."""
+    lib = _lib.load()
+    if not (x_nhwc.is_cuda and x_nhwc.is_contiguous() and x_nhwc.dtype == torch.float32 and tuple(x_nhwc.shape[1:]) == (28, 28, 128)):
+        raise RuntimeError("conv3x3_c128_f32: contiguous fp32 [N,28,28,128] GPU tensor expected")
+    CO = w_ohwi.shape[0]
+    if not (w_ohwi.is_cuda and w_ohwi.is_contiguous() and w_ohwi.dtype == torch.float32 and tuple(w_ohwi.shape[1:]) == (3, 3, 128)
+            and CO in (128, 192)):
+        raise RuntimeError("conv3x3_c128_f32: contiguous fp32 [128 | 192,3,3,128] GPU filter expected")
+    if input_gradient and (CO != 128 or bias is not None):
+        raise RuntimeError("conv3x3_c128_f32: the input gradient needs the square 128 -> 128 filter and takes no bias")
+    if bias is not None and not (bias.is_cuda and bias.is_contiguous() and bias.dtype == torch.float32 and tuple(bias.shape) == (CO,)):
+        raise RuntimeError("conv3x3_c128_f32: contiguous fp32 [CO] GPU bias expected")
+    N = x_nhwc.shape[0]
+    y = torch.empty(N, 28, 28, CO, device=x_nhwc.device, dtype=torch.float32)
+    with timed("conv3x3_c128_f32", 2.0 * N * 28 * 28 * 128 * CO * 9, 4.0 * N * 28 * 28 * (128 + CO)):
+        _lib.check(lib.rp_conv3x3_c128_f32(_p(x_nhwc), _p(w_ohwi), _p(bias), _p(y), N, 28, 28, CO, 1 if input_gradient else 0, _st()),
+                   "rp_conv3x3_c128_f32")
+    return y
+
+
+class Conv3x3C128F32Fn(_Fn):
+    """forward (and, for the square filter, input gradient) on rp_conv3x3_c128_f32; weight / bias gradients on MIOpen"""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return conv3x3_c128_f32(_nhwc(x), _nhwc(w), bias).permute(0, 3, 1, 2)        # (channels-last NCHW view of the NHWC result)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx = dw = db = None
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        CO = w.shape[0]
+        own_dx = ctx.needs_input_grad[0] and CO == 128
+        if own_dx:
+            dx = conv3x3_c128_f32(_nhwc(dy), _nhwc(w), input_gradient=True).permute(0, 3, 1, 2)
+        mask = [bool(ctx.needs_input_grad[0]) and not own_dx, bool(ctx.needs_input_grad[1]), ctx.has_bias and bool(ctx.needs_input_grad[2])]
+        if any(mask):
+            g = torch.ops.aten.convolution_backward(dy, x, w, [CO] if ctx.has_bias else None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, mask)
+            dx = g[0] if mask[0] else dx
+            dw = g[1] if mask[1] else None
+            db = g[2] if mask[2] else None
+        return dx, dw, db
+
+
+def conv3x3_c128_f32_ok(m, x):
+    return (CONV3X3_C128_F32 and CNN_PRECISION == 0 and x.is_cuda and x.dtype == torch.float32 and tuple(m.weight.shape[1:]) == (128, 3, 3)
+            and m.weight.shape[0] in (128, 192) and m.stride == (1, 1) and m.padding == (1, 1) and m.dilation == (1, 1) and m.groups == 1
+            and getattr(m, "padding_mode", "zeros") == "zeros" and tuple(x.shape[1:]) == (128, 28, 28) and x.shape[0] >= CONV3X3_C128_F32_MIN_N)
+
+
 def conv3x3_wgrad_f32_ok(m, x):
     return (CONV3X3_WGRAD_F32 and CNN_PRECISION == 0 and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
             and m.weight.requires_grad and tuple(m.weight.shape) == (64, 64, 3, 3) and m.bias is None and m.stride == (1, 1)
@@ -2073,6 +2136,8 @@ def conv2d(m, x, want_stats=False):
     if CNN_PRECISION == 0 or not x.is_cuda:
         if conv3x3_wgrad_f32_ok(m, x) or conv3x3_f32_ok(m, x):
             return Conv3x3C64F32Fn.apply(x, m.weight)
+        if conv3x3_c128_f32_ok(m, x):
+            return Conv3x3C128F32Fn.apply(x, m.weight, m.bias)
         return m(x)
     bf = torch.bfloat16
     ready = getattr(m, "_rp_bf16", None)

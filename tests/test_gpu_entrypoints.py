@@ -444,7 +444,7 @@ def test_evaluation_scripts_reproduce_the_references_runs(tmp_path, monkeypatch)
 FP32_SWITCHES = ["SPLITK_BATCHING", "ROWS_LINEAR", "ROWS_DX", "FUSE_LN_BWD", "DW192_F32", "COLSUM_BATCHING", "ATTN_BWD_STORE_DS",
                  "EMM_BWD_STORE_DS", "QKV_BIAS_FROM_PRODUCERS", "EMM_STATS_ONE_PASS", "FUSE_MLP", "FUSE_MLP_TRAIN", "FUSE_MLP_BWD", "MLP_BWD_LN",
                  "USE_SIDE_STREAM", "STEM_CONV", "STEM_STATS", "FUSE_STEM_POOL", "CONV3X3_WGRAD_F32_MIN_N", "STEM_WGRAD", "ATTN_STORE_P",
-                 "EMM_STORE_S", "CONV3X3_F32_MIN_N"]
+                 "EMM_STORE_S", "CONV3X3_F32_MIN_N", "CONV3X3_C128_F32_MIN_N"]
 BF16_SWITCHES = ["ACT_BF16", "BF16_PATH", "DX_LNBWD_BF16", "DW192", "MLP_W2_CHUNK_MAJOR", "MLP_BWD_LN", "CONV3X3_OWN", "CONV3X3_OWN_WGRAD", "STEM_CONV",
                  "STEM_WGRAD", "STEM_STATS", "CONV_BWD_AS_FWD_MIN_K"]
 
@@ -494,7 +494,7 @@ def test_every_kernel_path_switch_has_a_working_alternative(precision):
         bad = {}
         for name in (BF16_SWITCHES if bf else FP32_SWITCHES):
             old = getattr(ops, name)
-            setattr(ops, name, (99 if name == "CONV_BWD_AS_FWD_MIN_K" else 0 if name in ("CONV3X3_WGRAD_F32_MIN_N", "CONV3X3_F32_MIN_N") else 2 if (name == "MLP_BWD_LN" and not bf) else (not old)))      # (MLP_BWD_LN = 2: the fold with fp32 operands too; CONV3X3_WGRAD_F32_MIN_N / CONV3X3_F32_MIN_N = 0: the own fp32 layer1 kernels at this 4-image batch)
+            setattr(ops, name, (99 if name == "CONV_BWD_AS_FWD_MIN_K" else 0 if name in ("CONV3X3_WGRAD_F32_MIN_N", "CONV3X3_F32_MIN_N", "CONV3X3_C128_F32_MIN_N") else 2 if (name == "MLP_BWD_LN" and not bf) else (not old)))      # (MLP_BWD_LN = 2: the fold with fp32 operands too; CONV3X3_WGRAD_F32_MIN_N / CONV3X3_F32_MIN_N = 0: the own fp32 layer1 kernels at this 4-image batch)
             try:
                 out, g = _step_outputs(model, images, Gs, intr)
             finally:

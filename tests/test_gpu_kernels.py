@@ -356,6 +356,56 @@ def test_conv3x3_c64_forward_and_input_gradient_exact_fp32(ops, N):
         ops.conv3x3_c64_f32(xr[:, :28].contiguous(), wr)
 
 
+@pytest.mark.parametrize("N", [1, 3, 37, 128])
+@pytest.mark.parametrize("CO", [128, 192])
+def test_conv3x3_c128_forward_and_input_gradient_exact_fp32(ops, N, CO):
+    """rp_conv3x3_c128_f32 (csrc/conv3x3_c128_f32.hip: resnet.layer2's 3x3 / 128 -> 128 convolutions, src/model.py:132, forward and input
+    gradient; extractor_final_conv.conv1 3x3 / 128 -> 192 with bias, src/modules/extractor.py:9,51, forward) against fp64 F.conv2d / its
+    autograd on EVERY output element: 2e-6 of the maximum (1152 exact fp32 products per element, fp32 accumulation).  N = 1 / 3 / 37: fewer
+    tiles than workgroup slots and chunks that start and end inside an image (zero slot above row 0 and below row 27, the ring wrap, the
+    two-barrier refill); N = 128: the headline size, checked in chunks.  Deterministic.  ops.Conv3x3C128F32Fn (own forward / square input
+    gradient, MIOpen weight and bias gradients) against plain autograd of F.conv2d."""
+    import torch.nn.functional as F
+    CL = torch.channels_last
+    x = rnd(N, 128, 28, 28, seed=21).contiguous(memory_format=CL)
+    w = rnd(CO, 128, 3, 3, seed=22, scale=(128 * 9) ** -0.5).contiguous(memory_format=CL)
+    b = rnd(CO, seed=23, scale=0.3) if CO == 192 else None
+    dy = rnd(N, CO, 28, 28, seed=25).contiguous(memory_format=CL)
+    xr, wr, dyr = x.permute(0, 2, 3, 1), w.permute(0, 2, 3, 1), dy.permute(0, 2, 3, 1)
+    assert xr.is_contiguous() and wr.is_contiguous() and dyr.is_contiguous()
+    y = ops.conv3x3_c128_f32(xr, wr, b)
+    assert torch.equal(y, ops.conv3x3_c128_f32(xr, wr, b))
+    dx = None
+    if CO == 128:
+        dx = ops.conv3x3_c128_f32(dyr, wr, input_gradient=True)
+        assert torch.equal(dx, ops.conv3x3_c128_f32(dyr, w.flip(2, 3).permute(1, 2, 3, 0).contiguous()))      # = the forward kernel on the rotated, swapped filter
+    e_y = e_dx = 0.0
+    w64 = w.double()
+    for i in range(0, N, 16):
+        xs = x[i:i + 16].double().requires_grad_(True)
+        ys = F.conv2d(xs, w64, None if b is None else b.double(), 1, 1)
+        ys.backward(dy[i:i + 16].double())
+        e_y = max(e_y, float((y[i:i + 16].permute(0, 3, 1, 2).double() - ys).abs().max() / ys.abs().max()))
+        if dx is not None:
+            e_dx = max(e_dx, float((dx[i:i + 16].permute(0, 3, 1, 2).double() - xs.grad).abs().max() / xs.grad.abs().max()))
+    x1, w1 = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    b1 = None if b is None else b.clone().requires_grad_(True)
+    ops.Conv3x3C128F32Fn.apply(x1, w1, b1).backward(dy)
+    x2, w2 = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    b2 = None if b is None else b.clone().requires_grad_(True)
+    F.conv2d(x2, w2, b2, 1, 1).backward(dy)
+    e_fn = dict(dx=rel(x1.grad, x2.grad.double()), dw=rel(w1.grad, w2.grad.double()), db=0.0 if b is None else rel(b1.grad, b2.grad.double()))
+    report("conv3x3_c128_f32[N=%d,CO=%d]" % (N, CO), y=e_y, dx=e_dx, **{"fn_" + k: v for k, v in e_fn.items()})
+    assert e_y < 2e-6 and e_dx < 2e-6 and e_fn["dx"] < 3e-6 and e_fn["dw"] < 2e-5 and e_fn["db"] < 2e-5, (e_y, e_dx, e_fn)
+    with pytest.raises(RuntimeError):
+        ops.conv3x3_c128_f32(xr.to(torch.bfloat16), wr)
+    with pytest.raises(RuntimeError):
+        ops.conv3x3_c128_f32(xr[:, :14].contiguous(), wr)
+    if CO == 192:
+        with pytest.raises(RuntimeError):
+            ops.conv3x3_c128_f32(xr, wr, input_gradient=True)
+
+
 @pytest.mark.parametrize("ci,co,k,pad,h", [(128, 192, 5, 0, 28), (192, 192, 5, 0, 28), (64, 96, 3, 1, 20)])
 def test_bf16_convolution_input_gradient_as_forward_convolution(ops, ci, co, k, pad, h):
     """ops.ConvBf16Fn (bf16 configuration, the CNN tail's 5x5 valid convolutions, src/modules/extractor.py:51-65): the input gradient

@@ -40,6 +40,8 @@ struct CvG {
   const float* w;       // forward: [CO][3][3][128]; input gradient: the forward weight [128 (= this kernel's K)][3][3][CO = 128]
   const float* bias;    // [CO] or null
   float* y;             // [N,28,28,CO]
+  double* stats;        // null, or [tile chunks][2][CO]: per-chunk sums of y and y^2 per output channel (BatchNorm statistics of the output for
+                        // rp_bn_stats_from_partials; a workgroup writes the 64 channels of its group)
   int ntiles;           // N * 7
   int CO;               // 128 or 192 (multiple of 64)
   int dgrad;            // 1: the filter W'[ci][r][s][co] = W[co][2 - r][2 - s][ci] is read out of the forward weight (CO == 128 only)
@@ -65,7 +67,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c128_f32_kernel(CvG p) {
   const int cg = q % ncg, chunk = (q / ncg) * 8 + (blockIdx.x & 7), nchunk = (gridDim.x >> 3) / ncg * 8;
   if (chunk >= nchunk) return;
   const int t0 = (int)((long long)p.ntiles * chunk / nchunk), t1 = (int)((long long)p.ntiles * (chunk + 1) / nchunk);
-  if (t0 >= t1) return;
+  if (t0 >= t1) {
+    if (p.stats && tid < 128) p.stats[((long long)chunk * 2 + (tid >> 6)) * p.CO + 64 * cg + (tid & 63)] = 0.0;
+    return;
+  }
+  double sd1[4] = {0.0, 0.0, 0.0, 0.0}, sd2[4] = {0.0, 0.0, 0.0, 0.0};      // this lane's sums of y, y^2 over its pixels, channels 16 wave + 4 kq + e
   const unsigned xs0 = lds_byte_addr(&Xr[0][0]);
   const int lastrow = p.ntiles * RT - 1;
   // staging: NR consecutive rows from flattened (image, row) index g = NR * 896 float4, 3.5 NR per thread: float4 f -> row f / 896, pixel
@@ -206,17 +212,46 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c128_f32_kernel(CvG p) {
       float* o = p.y + (((long long)g0 + orow[j]) * IW + ocol[j]) * p.CO + 64 * cg + 16 * wave + 4 * kq;
       st4(o, make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]));
     }
+    if (p.stats) {                                            // (wave-uniform) fp32 over the tile's seven pixels, double across tiles
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a = 0.f, q = 0.f;
+#pragma unroll
+        for (int j = 0; j < NBLK; ++j) { a += acc[j][e]; q = fmaf(acc[j][e], acc[j][e], q); }
+        sd1[e] += (double)a;
+        sd2[e] += (double)q;
+      }
+    }
     if (t + 1 < t1) {
       __syncthreads();                                        // rows g0 - 1 .. g0 + 2 are dead for everybody: their slots take g0 + 5 .. g0 + 8
       sstore4(g0 + RT + 1);
     }
     __syncthreads();
   }
+  if (p.stats) {
+    // the 16 pixel lanes of a (wave, kq) group are summed in a fixed order through LDS (the ring is dead: everybody is past the last barrier)
+    double* red = reinterpret_cast<double*>(&Xr[0][0]);       // [2][64 channels][16 lanes]
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int ch = 16 * wave + 4 * kq + e;
+      red[ch * 16 + l15] = sd1[e];
+      red[1024 + ch * 16 + l15] = sd2[e];
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const double* r = red + (tid >> 6) * 1024 + (tid & 63) * 16;
+      double a = r[0];
+#pragma unroll
+      for (int l = 1; l < 16; ++l) a += r[l];
+      p.stats[((long long)chunk * 2 + (tid >> 6)) * p.CO + 64 * cg + (tid & 63)] = a;
+    }
+  }
 }
 
 }  // namespace
 
-/* workgroups of a launch: CO / 64 channel groups x tile chunks, whole groups of 8 (one per XCD), at most one workgroup per CU */
+/* workgroups of a launch: CO / 64 channel groups x tile chunks, whole groups of 8 (one per XCD), at most one workgroup per CU; the number of
+ * tile chunks (= rows of the statistics partials) is blocks / (CO / 64) */
 extern "C" int rp_conv3x3_c128_f32_blocks(int N, int CO) {
   if (N <= 0 || CO <= 0 || CO % 64) return 0;
   const int ncg = CO / 64, tiles = N * TPI;
@@ -227,13 +262,14 @@ extern "C" int rp_conv3x3_c128_f32_blocks(int N, int CO) {
 
 /* y [N,28,28,CO] = bias + conv3x3(x [N,28,28,128], w [CO][3][3][128]), stride 1, pad 1, exact fp32 (NHWC memory; w = the memory of a
  * channels-last [CO,128,3,3] weight; CO = 128 or 192; bias [CO] or null).  input_gradient != 0 (CO == 128): x is dY and the result is dX of
- * the 128 -> 128 convolution whose FORWARD weight is w -- the filter w'[ci][r][s][co] = w[co][2 - r][2 - s][ci] is read out of it. */
-extern "C" int rp_conv3x3_c128_f32(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int CO, int input_gradient,
-                                   void* stream) {
+ * the 128 -> 128 convolution whose FORWARD weight is w -- the filter w'[ci][r][s][co] = w[co][2 - r][2 - s][ci] is read out of it.  stats: NULL,
+ * or [rp_conv3x3_c128_f32_blocks(N, CO) / (CO / 64)][2][CO] doubles = per-chunk sums of y and y^2 per channel (rp_bn_stats_from_partials). */
+extern "C" int rp_conv3x3_c128_f32(const float* x, const float* w, const float* bias, float* y, double* stats, int N, int H, int W, int CO,
+                                   int input_gradient, void* stream) {
   if (!x || !w || !y || N <= 0) return RP_EBADSHAPE;
   if (H != IH || W != IW || (CO != 128 && CO != 192) || (input_gradient && (CO != 128 || bias))) return RP_EUNSUPPORTED;
-  if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)bias) & 15) return RP_EALIGN;
-  CvG p{x, w, bias, y, N * TPI, CO, input_gradient ? 1 : 0};
+  if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)bias | (uintptr_t)stats) & 15) return RP_EALIGN;
+  CvG p{x, w, bias, y, stats, N * TPI, CO, input_gradient ? 1 : 0};
   hipLaunchKernelGGL(conv3x3_c128_f32_kernel, dim3(rp_conv3x3_c128_f32_blocks(N, CO)), dim3(256), 0, (hipStream_t)stream, p);
   RP_CHECK_LAUNCH();
   return RP_OK;

@@ -41,6 +41,8 @@ struct CvF {
   const float* w;       // [64 co][3][3][64 ci]
   float* y;             // [N,56,56,64]
   int ntiles;           // N * 28
+  double* stats;        // null, or [gridDim][2][64]: per-workgroup sums of y and y^2 per output channel (the BatchNorm statistics of the
+                        // OUTPUT, csrc/batchnorm.hip: rp_bn_stats_from_partials) -- the statistics pass over y is then not needed
   int dgrad;            // 0: filter W[co][r][s][ci] as it lies; 1: the input gradient's filter W'[ci][r][s][co] = W[co][2 - r][2 - s][ci], read
                         // from the SAME forward weight (strided, 144 loads per lane once per workgroup: no rotated copy, no extra launch)
 };
@@ -62,7 +64,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_f32_kernel(CvF p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, kq = lane >> 4;
   const int G = gridDim.x, b = blockIdx.x;
   const int t0 = (int)((long long)p.ntiles * b / G), t1 = (int)((long long)p.ntiles * (b + 1) / G);
-  if (t0 >= t1) return;
+  if (t0 >= t1) {
+    if (p.stats && tid < 2 * C) p.stats[(long long)b * 2 * C + tid] = 0.0;
+    return;
+  }
+  double sd1[4] = {0.0, 0.0, 0.0, 0.0}, sd2[4] = {0.0, 0.0, 0.0, 0.0};      // this lane's sums of y, y^2 over its pixels, channels 16 wave + 4 kq + e
   const unsigned xs0 = lds_byte_addr(&Xr[0][0]);
   // staging: the two rows g, g + 1 (flattened (image, row) index) = 1792 float4, 7 per thread: float4 f -> row f / 896, pixel (f % 896) / 16
   float4 pre[7], pre2[7];
@@ -164,8 +170,36 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_f32_kernel(CvF p) {
       float* o = p.y + (((long long)g0 + orow[j]) * IW + ocol[j]) * C + 16 * wave + 4 * kq;
       st4(o, make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]));
     }
+    if (p.stats) {                                            // (wave-uniform) fp32 over the tile's seven pixels, double across tiles
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a = 0.f, q = 0.f;
+#pragma unroll
+        for (int j = 0; j < NBLK; ++j) { a += acc[j][e]; q = fmaf(acc[j][e], acc[j][e], q); }
+        sd1[e] += (double)a;
+        sd2[e] += (double)q;
+      }
+    }
     if (t + 1 < t1) sstore(pre, g0 + 3);                      // slots of rows g0 + 3, g0 + 4: not among this tile's g0 - 1 .. g0 + 2
     __syncthreads();
+  }
+  if (p.stats) {
+    // the 16 pixel lanes of a (wave, kq) group are summed in a fixed order through LDS (the ring is dead: everybody is past the last barrier)
+    double* red = reinterpret_cast<double*>(&Xr[0][0]);       // [2][64 channels][16 lanes]
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int ch = 16 * wave + 4 * kq + e;
+      red[ch * 16 + l15] = sd1[e];
+      red[1024 + ch * 16 + l15] = sd2[e];
+    }
+    __syncthreads();
+    if (tid < 2 * C) {
+      const double* r = red + (tid >> 6) * 1024 + (tid & 63) * 16;
+      double a = r[0];
+#pragma unroll
+      for (int l = 1; l < 16; ++l) a += r[l];
+      p.stats[(long long)b * 2 * C + tid] = a;                // [which][channel]
+    }
   }
 }
 
@@ -178,12 +212,13 @@ extern "C" int rp_conv3x3_c64_f32_blocks(int N) {
 
 /* y [N,56,56,64] = conv3x3(x [N,56,56,64], w [64][3][3][64]), stride 1, pad 1, exact fp32 (NHWC memory; w = the memory of a channels-last
  * [64,64,3,3] weight).  input_gradient != 0: x is dY and the result is dX of the same convolution -- the filter w'[ci][r][s][co] =
- * w[co][2 - r][2 - s][ci] is read out of the forward weight w. */
-extern "C" int rp_conv3x3_c64_f32(const float* x, const float* w, float* y, int N, int H, int W, int input_gradient, void* stream) {
+ * w[co][2 - r][2 - s][ci] is read out of the forward weight w.  stats: NULL, or [rp_conv3x3_c64_f32_blocks(N)][2][64] doubles that receive the
+ * per-workgroup sums of y and y^2 per channel (BatchNorm statistics of the output, finished by rp_bn_stats_from_partials with a zero pivot). */
+extern "C" int rp_conv3x3_c64_f32(const float* x, const float* w, float* y, double* stats, int N, int H, int W, int input_gradient, void* stream) {
   if (!x || !w || !y || N <= 0) return RP_EBADSHAPE;
   if (H != IH || W != IW) return RP_EUNSUPPORTED;
-  if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) return RP_EALIGN;
-  CvF p{x, w, y, N * TPI, input_gradient ? 1 : 0};
+  if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)stats) & 15) return RP_EALIGN;
+  CvF p{x, w, y, N * TPI, stats, input_gradient ? 1 : 0};
   hipLaunchKernelGGL(conv3x3_c64_f32_kernel, dim3(rp_conv3x3_c64_f32_blocks(N)), dim3(256), 0, (hipStream_t)stream, p);
   RP_CHECK_LAUNCH();
   return RP_OK;

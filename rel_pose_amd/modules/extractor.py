@@ -29,7 +29,8 @@ class ResidualBlock(nn.Module):
             self.downsample = nn.Sequential(nn.Conv2d(in_planes, planes, kernel_size), self.norm3)
 
     def forward(self, x):
-        y = bn_act(self.norm1, conv2d(self.conv1, x))
+        y, st = conv2d(self.conv1, x, want_stats=True)          # (exact fp32: the own 128 -> 192 convolution hands norm1 its batch statistics)
+        y = bn_act(self.norm1, y, stats=st)
         y = bn_act(self.norm2, conv2d(self.conv2, y))
         if self.downsample is not None:           # relu(norm3(conv(x)) + y): the add and the ReLU ride on norm3's pass
             return bn_act(self.downsample[1], conv2d(self.downsample[0], x), residual=y)

@@ -1995,10 +1995,11 @@ CONV3X3_F32 = os.environ.get("RP_CONV3X3_F32", "1") != "0"
 CONV3X3_F32_MIN_N = int(os.environ.get("RP_CONV3X3_F32_MIN_N", "56"))
 
 
-def conv3x3_c64_f32(x_nhwc, w_ohwi, input_gradient=False):
+def conv3x3_c64_f32(x_nhwc, w_ohwi, input_gradient=False, want_stats=False):
     """rp_conv3x3_c64_f32: y = conv3x3(x, w), stride 1, pad 1, exact fp32, for x [N,56,56,64] (NHWC memory) and w [64,3,3,64] (the memory
     of a channels-last [64,64,3,3] weight) -> y [N,56,56,64].  input_gradient: x is dY, the result dX of that convolution (the rotated,
-    channel-swapped filter is read out of the forward weight by the kernel)."""
+    channel-swapped filter is read out of the forward weight by the kernel).  want_stats: also returns the per-workgroup sums of y and
+    y^2 per channel [blocks,2,64] float64 from the kernel's epilogue (BnActFn's `stats`)."""
     lib = _lib.load()
     if not (x_nhwc.is_cuda and x_nhwc.is_contiguous() and x_nhwc.dtype == torch.float32 and tuple(x_nhwc.shape[1:]) == (56, 56, 64)):
         raise RuntimeError("conv3x3_c64_f32: contiguous fp32 [N,56,56,64] GPU tensor expected")
@@ -2006,9 +2007,10 @@ def conv3x3_c64_f32(x_nhwc, w_ohwi, input_gradient=False):
         raise RuntimeError("conv3x3_c64_f32: contiguous fp32 [64,3,3,64] GPU filter expected")
     N = x_nhwc.shape[0]
     y = torch.empty_like(x_nhwc)
+    stats = torch.empty(lib.rp_conv3x3_c64_f32_blocks(N), 2, 64, device=x_nhwc.device, dtype=torch.float64) if want_stats else None
     with timed("conv3x3_c64_f32", 2.0 * N * 56 * 56 * 64 * 64 * 9, 4.0 * N * 56 * 56 * 128):
-        _lib.check(lib.rp_conv3x3_c64_f32(_p(x_nhwc), _p(w_ohwi), _p(y), N, 56, 56, 1 if input_gradient else 0, _st()), "rp_conv3x3_c64_f32")
-    return y
+        _lib.check(lib.rp_conv3x3_c64_f32(_p(x_nhwc), _p(w_ohwi), _p(y), _p(stats), N, 56, 56, 1 if input_gradient else 0, _st()), "rp_conv3x3_c64_f32")
+    return (y, stats) if want_stats else y
 
 
 def _nhwc(t):
@@ -2018,14 +2020,19 @@ def _nhwc(t):
 
 class Conv3x3C64F32Fn(_Fn):
     @staticmethod
-    def forward(ctx, x, w):
+    def forward(ctx, x, w, want_stats=False):
+        """want_stats: returns (y, stats) with the output's BatchNorm partial sums from the kernel's epilogue (None when MIOpen ran)"""
         ctx.save_for_backward(x, w)
-        if CONV3X3_F32 and x.shape[0] >= CONV3X3_F32_MIN_N:
-            return conv3x3_c64_f32(_nhwc(x), _nhwc(w)).permute(0, 3, 1, 2)        # (channels-last NCHW view of the NHWC result)
-        return torch.nn.functional.conv2d(x, w, None, 1, 1)
+        own = CONV3X3_F32 and x.shape[0] >= CONV3X3_F32_MIN_N
+        if want_stats and own and CONV_F32_STATS:
+            y, stats = conv3x3_c64_f32(_nhwc(x), _nhwc(w), want_stats=True)
+            ctx.mark_non_differentiable(stats)
+            return y.permute(0, 3, 1, 2), stats
+        y = conv3x3_c64_f32(_nhwc(x), _nhwc(w)).permute(0, 3, 1, 2) if own else torch.nn.functional.conv2d(x, w, None, 1, 1)
+        return (y, None) if want_stats else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *_):
         x, w = ctx.saved_tensors
         dx = dw = None
         dy = dy.contiguous(memory_format=torch.channels_last)
@@ -2040,20 +2047,23 @@ class Conv3x3C64F32Fn(_Fn):
                 dw = conv3x3_c64_wgrad_f32(_nhwc(x), dy.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
             else:
                 dw = torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
-        return dx, dw
+        return dx, dw, None
 
 
 # The 128-input-channel 3x3 convolutions on 28 x 28 maps (resnet.layer2's 128 -> 128 convolutions forward and input gradient, the forward of
 # extractor_final_conv.conv1 128 -> 192) on csrc/conv3x3_c128_f32.hip from CONV3X3_C128_F32_MIN_N images up; their weight (and bias)
 # gradients stay on MIOpen.  RP_CONV3X3_C128_F32=0: MIOpen for all of it (A/B aid).
 CONV3X3_C128_F32 = os.environ.get("RP_CONV3X3_C128_F32", "1") != "0"
+# the own fp32 convolutions hand the BatchNorm behind them its batch statistics from their epilogue (no statistics pass over y); A/B aid
+CONV_F32_STATS = os.environ.get("RP_CONV_F32_STATS", "1") != "0"
 CONV3X3_C128_F32_MIN_N = int(os.environ.get("RP_CONV3X3_C128_F32_MIN_N", "56"))
 
 
-def conv3x3_c128_f32(x_nhwc, w_ohwi, bias=None, input_gradient=False):
+def conv3x3_c128_f32(x_nhwc, w_ohwi, bias=None, input_gradient=False, want_stats=False):
     """rp_conv3x3_c128_f32: y = bias + conv3x3(x, w), stride 1, pad 1, exact fp32, for x [N,28,28,128] (NHWC memory) and w [CO,3,3,128]
     (the memory of a channels-last [CO,128,3,3] weight), CO = 128 or 192 -> y [N,28,28,CO].  input_gradient (CO = 128, no bias): x is dY,
-    the result dX of the convolution whose forward weight is w."""
+    the result dX of the convolution whose forward weight is w.  want_stats: also returns the per-chunk sums of y and y^2 per channel
+    [chunks,2,CO] float64 from the kernel's epilogue (BnActFn's `stats`)."""
     lib = _lib.load()
     if not (x_nhwc.is_cuda and x_nhwc.is_contiguous() and x_nhwc.dtype == torch.float32 and tuple(x_nhwc.shape[1:]) == (28, 28, 128)):
         raise RuntimeError("conv3x3_c128_f32: contiguous fp32 [N,28,28,128] GPU tensor expected")
@@ -2067,23 +2077,30 @@ def conv3x3_c128_f32(x_nhwc, w_ohwi, bias=None, input_gradient=False):
         raise RuntimeError("conv3x3_c128_f32: contiguous fp32 [CO] GPU bias expected")
     N = x_nhwc.shape[0]
     y = torch.empty(N, 28, 28, CO, device=x_nhwc.device, dtype=torch.float32)
+    stats = (torch.empty(lib.rp_conv3x3_c128_f32_blocks(N, CO) // (CO // 64), 2, CO, device=x_nhwc.device, dtype=torch.float64)
+             if want_stats else None)
     with timed("conv3x3_c128_f32", 2.0 * N * 28 * 28 * 128 * CO * 9, 4.0 * N * 28 * 28 * (128 + CO)):
-        _lib.check(lib.rp_conv3x3_c128_f32(_p(x_nhwc), _p(w_ohwi), _p(bias), _p(y), N, 28, 28, CO, 1 if input_gradient else 0, _st()),
-                   "rp_conv3x3_c128_f32")
-    return y
+        _lib.check(lib.rp_conv3x3_c128_f32(_p(x_nhwc), _p(w_ohwi), _p(bias), _p(y), _p(stats), N, 28, 28, CO, 1 if input_gradient else 0,
+                                           _st()), "rp_conv3x3_c128_f32")
+    return (y, stats) if want_stats else y
 
 
 class Conv3x3C128F32Fn(_Fn):
     """forward (and, for the square filter, input gradient) on rp_conv3x3_c128_f32; weight / bias gradients on MIOpen"""
 
     @staticmethod
-    def forward(ctx, x, w, bias):
+    def forward(ctx, x, w, bias, want_stats=False):
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
-        return conv3x3_c128_f32(_nhwc(x), _nhwc(w), bias).permute(0, 3, 1, 2)        # (channels-last NCHW view of the NHWC result)
+        if want_stats and CONV_F32_STATS:
+            y, stats = conv3x3_c128_f32(_nhwc(x), _nhwc(w), bias, want_stats=True)
+            ctx.mark_non_differentiable(stats)
+            return y.permute(0, 3, 1, 2), stats
+        y = conv3x3_c128_f32(_nhwc(x), _nhwc(w), bias).permute(0, 3, 1, 2)           # (channels-last NCHW view of the NHWC result)
+        return (y, None) if want_stats else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *_):
         x, w = ctx.saved_tensors
         dx = dw = db = None
         dy = dy.contiguous(memory_format=torch.channels_last)
@@ -2097,7 +2114,7 @@ class Conv3x3C128F32Fn(_Fn):
             dx = g[0] if mask[0] else dx
             dw = g[1] if mask[1] else None
             db = g[2] if mask[2] else None
-        return dx, dw, db
+        return dx, dw, db, None
 
 
 def conv3x3_c128_f32_ok(m, x):
@@ -2132,12 +2149,18 @@ def conv2d(m, x, want_stats=False):
         if conv3x3_own_ok(m, x) and getattr(m, "_rp_bf16", None) is not None:
             xb = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
             return Conv3x3C64Fn.apply(xb, m._rp_bf16[0], True)
+        if CNN_PRECISION == 0 and x.is_cuda and torch.is_grad_enabled():
+            # exact-fp32 configuration: the own convolutions write the statistics partials in their epilogue
+            if conv3x3_f32_ok(m, x):
+                return Conv3x3C64F32Fn.apply(x, m.weight, True)
+            if conv3x3_c128_f32_ok(m, x):
+                return Conv3x3C128F32Fn.apply(x, m.weight, m.bias, True)
         return conv2d(m, x), None
     if CNN_PRECISION == 0 or not x.is_cuda:
         if conv3x3_wgrad_f32_ok(m, x) or conv3x3_f32_ok(m, x):
-            return Conv3x3C64F32Fn.apply(x, m.weight)
+            return Conv3x3C64F32Fn.apply(x, m.weight, False)
         if conv3x3_c128_f32_ok(m, x):
-            return Conv3x3C128F32Fn.apply(x, m.weight, m.bias)
+            return Conv3x3C128F32Fn.apply(x, m.weight, m.bias, False)
         return m(x)
     bf = torch.bfloat16
     ready = getattr(m, "_rp_bf16", None)

@@ -306,7 +306,7 @@ def test_conv3x3_c64_weight_gradient_exact_fp32(ops, N):
         e = rel(dw.permute(0, 3, 1, 2), ref.double())
         bound = 2e-5
     x1, w1 = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
-    y1 = ops.Conv3x3C64F32Fn.apply(x1, w1)
+    y1 = ops.Conv3x3C64F32Fn.apply(x1, w1, False)
     y1.backward(dy)
     x2, w2 = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
     y2 = F.conv2d(x2, w2, None, 1, 1)
@@ -348,8 +348,15 @@ def test_conv3x3_c64_forward_and_input_gradient_exact_fp32(ops, N):
         ys.backward(dy[i:i + 16].double())
         e_y = max(e_y, float((y[i:i + 16].permute(0, 3, 1, 2).double() - ys).abs().max() / ys.abs().max()))
         e_dx = max(e_dx, float((dx[i:i + 16].permute(0, 3, 1, 2).double() - xs.grad).abs().max() / xs.grad.abs().max()))
-    report("conv3x3_c64_f32[N=%d]" % N, y=e_y, dx=e_dx)
+    # the epilogue's BatchNorm partials: same y, per-channel sums of y and y^2 over all pixels (fp32 over a tile's 7 pixels per lane,
+    # double above that: 2e-7 of sum |y| / sum y^2), and the mean / rstd BnActFn derives from them against the statistics pass
+    y2, st = ops.conv3x3_c64_f32(xr, wr, want_stats=True)
+    yd = y.double().reshape(-1, 64)
+    e_s1 = float(((st[:, 0].sum(0) - yd.sum(0)).abs() / yd.abs().sum(0)).max())
+    e_s2 = float(((st[:, 1].sum(0) - yd.square().sum(0)).abs() / yd.square().sum(0)).max())
+    report("conv3x3_c64_f32[N=%d]" % N, y=e_y, dx=e_dx, stats_sum=e_s1, stats_sumsq=e_s2)
     assert e_y < 2e-6 and e_dx < 2e-6, (e_y, e_dx)
+    assert torch.equal(y2, y) and st.shape[1:] == (2, 64) and e_s1 < 2e-7 and e_s2 < 2e-7, (e_s1, e_s2)
     with pytest.raises(RuntimeError):
         ops.conv3x3_c64_f32(xr.to(torch.bfloat16), wr)
     with pytest.raises(RuntimeError):
@@ -390,12 +397,17 @@ def test_conv3x3_c128_forward_and_input_gradient_exact_fp32(ops, N, CO):
             e_dx = max(e_dx, float((dx[i:i + 16].permute(0, 3, 1, 2).double() - xs.grad).abs().max() / xs.grad.abs().max()))
     x1, w1 = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
     b1 = None if b is None else b.clone().requires_grad_(True)
-    ops.Conv3x3C128F32Fn.apply(x1, w1, b1).backward(dy)
+    ops.Conv3x3C128F32Fn.apply(x1, w1, b1, False).backward(dy)
     x2, w2 = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
     b2 = None if b is None else b.clone().requires_grad_(True)
     F.conv2d(x2, w2, b2, 1, 1).backward(dy)
     e_fn = dict(dx=rel(x1.grad, x2.grad.double()), dw=rel(w1.grad, w2.grad.double()), db=0.0 if b is None else rel(b1.grad, b2.grad.double()))
-    report("conv3x3_c128_f32[N=%d,CO=%d]" % (N, CO), y=e_y, dx=e_dx, **{"fn_" + k: v for k, v in e_fn.items()})
+    y2, st = ops.conv3x3_c128_f32(xr, wr, b, want_stats=True)      # the epilogue's BatchNorm partials (see the 64-channel test)
+    yd = y.double().reshape(-1, CO)
+    e_s1 = float(((st[:, 0].sum(0) - yd.sum(0)).abs() / yd.abs().sum(0)).max())
+    e_s2 = float(((st[:, 1].sum(0) - yd.square().sum(0)).abs() / yd.square().sum(0)).max())
+    assert torch.equal(y2, y) and st.shape[1:] == (2, CO) and e_s1 < 2e-7 and e_s2 < 2e-7, (e_s1, e_s2)
+    report("conv3x3_c128_f32[N=%d,CO=%d]" % (N, CO), y=e_y, dx=e_dx, stats_sum=e_s1, stats_sumsq=e_s2, **{"fn_" + k: v for k, v in e_fn.items()})
     assert e_y < 2e-6 and e_dx < 2e-6 and e_fn["dx"] < 3e-6 and e_fn["dw"] < 2e-5 and e_fn["db"] < 2e-5, (e_y, e_dx, e_fn)
     with pytest.raises(RuntimeError):
         ops.conv3x3_c128_f32(xr.to(torch.bfloat16), wr)

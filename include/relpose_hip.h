@@ -36,7 +36,7 @@ extern "C" {
  * functions this header declares.  rp_abi_version() / rp_abi_export_count() return the values the library was COMPILED with, so a
  * binding (rel_pose_amd/_lib.py parses both macros and counts the declarations) rejects a stale .so at load time instead of
  * failing later on a missing symbol. */
-#define RP_ABI_VERSION 24
+#define RP_ABI_VERSION 25
 #define RP_ABI_EXPORTS 109
 int rp_abi_version(void);
 int rp_abi_export_count(void);
@@ -233,7 +233,8 @@ int rp_conv3x3_c64_wgrad_f32(const float* x, const float* dy, float* dw, void* w
  * workgroup per CU (rp_conv3x3_c64_f32_blocks).  input_gradient != 0: x is dY and y is dX of the same convolution -- the filter
  * w'[ci][r][s][co] = w[co][2 - r][2 - s][ci] is read out of the forward weight w (no rotated copy). */
 int rp_conv3x3_c64_f32_blocks(int N);
-int rp_conv3x3_c64_f32(const float* x, const float* w, float* y, double* stats, int N, int H, int W, int input_gradient, void* stream);
+int rp_conv3x3_c64_f32(const float* x, const float* w, float* y, double* stats, const float* res, int N, int H, int W, int input_gradient,
+                       void* stream);
 /* The 3x3 / stride 1 / pad 1 convolutions with 128 INPUT channels on 28 x 28 maps in exact fp32 (csrc/conv3x3_c128_f32.hip): resnet.layer2's
  * 128 -> 128 convolutions (reference src/model.py:132, torchvision BasicBlock.conv1/conv2 through cuDNN), forward and input gradient, and the
  * forward of extractor_final_conv.conv1, 128 -> 192 with bias (src/modules/extractor.py:9,51).  y [N,28,28,CO] = bias + conv3x3(x [N,28,28,128],
@@ -241,10 +242,12 @@ int rp_conv3x3_c64_f32(const float* x, const float* w, float* y, double* stats, 
  * registers (a wave owns 16 output channels: 288 VGPRs of 16x16x4 A operands), CO / 64 channel groups of workgroups per tile of four image
  * rows, padded 6-slot LDS row ring.  stats (both kernels): NULL, or [blocks / channel groups][2][CO] doubles that receive per-workgroup sums of y
  * and y^2 per output channel -- the BatchNorm batch statistics of the output, finished by rp_bn_stats_from_partials with a zero pivot, so
- * the statistics pass over y is not needed (reference: nn.BatchNorm2d behind every one of these convolutions).  input_gradient != 0 (CO == 128, no bias): x is dY and y is dX of the convolution whose FORWARD weight is w. */
+ * the statistics pass over y is not needed (reference: nn.BatchNorm2d behind every one of these convolutions).  res (both kernels): NULL, or a
+ * tensor of y's shape that is added to the result in the epilogue -- used for the input gradient of a BasicBlock's first convolution, where
+ * autograd would add the gradient arriving over the identity path (torchvision BasicBlock: out += identity) in a pass of its own.  input_gradient != 0 (CO == 128, no bias): x is dY and y is dX of the convolution whose FORWARD weight is w. */
 int rp_conv3x3_c128_f32_blocks(int N, int CO);
-int rp_conv3x3_c128_f32(const float* x, const float* w, const float* bias, float* y, double* stats, int N, int H, int W, int CO,
-                        int input_gradient, void* stream);
+int rp_conv3x3_c128_f32(const float* x, const float* w, const float* bias, float* y, double* stats, const float* res, int N, int H, int W,
+                        int CO, int input_gradient, void* stream);
 
 /* The stem's BatchNorm -> ReLU -> MaxPool2d(3, 2, 1) chain (src/model.py:127-130 on torchvision's resnet.bn1 / relu / maxpool) without
  * the [N,H,W,C] intermediates.  Forward (after rp_bn_stats, or with the running statistics in eval): y [N,OH,OW,C], idx = window

@@ -147,9 +147,9 @@ _SIGS = {
     "rp_conv3x3_c64_wgrad_f32_workspace_bytes": (c_size_t, [I]),
     "rp_conv3x3_c64_wgrad_f32": (c_int, [P, P, P, P, c_size_t, I, I, I, P]),
     "rp_conv3x3_c64_f32_blocks": (c_int, [I]),
-    "rp_conv3x3_c64_f32": (c_int, [P, P, P, P, I, I, I, I, P]),
+    "rp_conv3x3_c64_f32": (c_int, [P, P, P, P, P, I, I, I, I, P]),
     "rp_conv3x3_c128_f32_blocks": (c_int, [I, I]),
-    "rp_conv3x3_c128_f32": (c_int, [P, P, P, P, P, I, I, I, I, I, P]),
+    "rp_conv3x3_c128_f32": (c_int, [P, P, P, P, P, P, I, I, I, I, I, P]),
     "rp_bn_stats_from_partials": (c_int, [P, I, L, I, P, P, P, P, P, F, F, P]),
     "rp_bn_relu_pool_fwd": (c_int, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "rp_bn_relu_pool_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P]),

@@ -40,6 +40,7 @@ struct CvG {
   const float* w;       // forward: [CO][3][3][128]; input gradient: the forward weight [128 (= this kernel's K)][3][3][CO = 128]
   const float* bias;    // [CO] or null
   float* y;             // [N,28,28,CO]
+  const float* res;     // null, or [N,28,28,CO]: added to the result (input gradient + the gradient over the identity path of a BasicBlock)
   double* stats;        // null, or [tile chunks][2][CO]: per-chunk sums of y and y^2 per output channel (BatchNorm statistics of the output for
                         // rp_bn_stats_from_partials; a workgroup writes the 64 channels of its group)
   int ntiles;           // N * 7
@@ -207,6 +208,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c128_f32_kernel(CvG p) {
       });
     });
     // D[m = co 4 kq + e][n = pixel l15]: four consecutive output channels of one pixel per lane
+    if (p.res) {                                              // (no registers left to request these a tile early: seven loads, one wait)
+      float4 rv[NBLK];
+#pragma unroll
+      for (int j = 0; j < NBLK; ++j) rv[j] = ld4(p.res + (((long long)g0 + orow[j]) * IW + ocol[j]) * p.CO + 64 * cg + 16 * wave + 4 * kq);
+#pragma unroll
+      for (int j = 0; j < NBLK; ++j) { acc[j][0] += rv[j].x; acc[j][1] += rv[j].y; acc[j][2] += rv[j].z; acc[j][3] += rv[j].w; }
+    }
 #pragma unroll
     for (int j = 0; j < NBLK; ++j) {
       float* o = p.y + (((long long)g0 + orow[j]) * IW + ocol[j]) * p.CO + 64 * cg + 16 * wave + 4 * kq;
@@ -263,13 +271,14 @@ extern "C" int rp_conv3x3_c128_f32_blocks(int N, int CO) {
 /* y [N,28,28,CO] = bias + conv3x3(x [N,28,28,128], w [CO][3][3][128]), stride 1, pad 1, exact fp32 (NHWC memory; w = the memory of a
  * channels-last [CO,128,3,3] weight; CO = 128 or 192; bias [CO] or null).  input_gradient != 0 (CO == 128): x is dY and the result is dX of
  * the 128 -> 128 convolution whose FORWARD weight is w -- the filter w'[ci][r][s][co] = w[co][2 - r][2 - s][ci] is read out of it.  stats: NULL,
- * or [rp_conv3x3_c128_f32_blocks(N, CO) / (CO / 64)][2][CO] doubles = per-chunk sums of y and y^2 per channel (rp_bn_stats_from_partials). */
-extern "C" int rp_conv3x3_c128_f32(const float* x, const float* w, const float* bias, float* y, double* stats, int N, int H, int W, int CO,
-                                   int input_gradient, void* stream) {
+ * or [rp_conv3x3_c128_f32_blocks(N, CO) / (CO / 64)][2][CO] doubles = per-chunk sums of y and y^2 per channel (rp_bn_stats_from_partials).
+ * res: NULL, or a tensor of y's shape that is ADDED to the result in the epilogue. */
+extern "C" int rp_conv3x3_c128_f32(const float* x, const float* w, const float* bias, float* y, double* stats, const float* res, int N, int H,
+                                   int W, int CO, int input_gradient, void* stream) {
   if (!x || !w || !y || N <= 0) return RP_EBADSHAPE;
   if (H != IH || W != IW || (CO != 128 && CO != 192) || (input_gradient && (CO != 128 || bias))) return RP_EUNSUPPORTED;
-  if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)bias | (uintptr_t)stats) & 15) return RP_EALIGN;
-  CvG p{x, w, bias, y, stats, N * TPI, CO, input_gradient ? 1 : 0};
+  if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)bias | (uintptr_t)stats | (uintptr_t)res) & 15) return RP_EALIGN;
+  CvG p{x, w, bias, y, res, stats, N * TPI, CO, input_gradient ? 1 : 0};
   hipLaunchKernelGGL(conv3x3_c128_f32_kernel, dim3(rp_conv3x3_c128_f32_blocks(N, CO)), dim3(256), 0, (hipStream_t)stream, p);
   RP_CHECK_LAUNCH();
   return RP_OK;

@@ -41,6 +41,8 @@ struct CvF {
   const float* w;       // [64 co][3][3][64 ci]
   float* y;             // [N,56,56,64]
   int ntiles;           // N * 28
+  const float* res;     // null, or [N,56,56,64]: added to the result (the input gradient of a BasicBlock's first convolution + the gradient that
+                        // arrives over the identity path: autograd's separate add pass, 309 MB, disappears)
   double* stats;        // null, or [gridDim][2][64]: per-workgroup sums of y and y^2 per output channel (the BatchNorm statistics of the
                         // OUTPUT, csrc/batchnorm.hip: rp_bn_stats_from_partials) -- the statistics pass over y is then not needed
   int dgrad;            // 0: filter W[co][r][s][ci] as it lies; 1: the input gradient's filter W'[ci][r][s][co] = W[co][2 - r][2 - s][ci], read
@@ -140,6 +142,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_f32_kernel(CvF p) {
     f32x4 acc[NBLK];
 #pragma unroll
     for (int j = 0; j < NBLK; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 rv[NBLK];                                         // the residual of this tile's outputs, requested a tile's worth of MFMAs early
+    if (p.res) {
+#pragma unroll
+      for (int j = 0; j < NBLK; ++j) rv[j] = ld4(p.res + (((long long)g0 + orow[j]) * IW + ocol[j]) * C + 16 * wave + 4 * kq);
+    }
     // Two operand register sets, picked by the k-step's parity at compile time.  The seven reads of k-step k + 1 go out ONE BEHIND EACH
     // MFMA of k-step k (a block of seven reads per k-step left the matrix pipe drained while they issued: 19 % of the tile), and each MFMA
     // waits only for ITS operand: the LDS queue retires in order and exactly six younger reads are in flight in front of it -- lgkmcnt(6).
@@ -168,6 +175,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_f32_kernel(CvF p) {
 #pragma unroll
     for (int j = 0; j < NBLK; ++j) {
       float* o = p.y + (((long long)g0 + orow[j]) * IW + ocol[j]) * C + 16 * wave + 4 * kq;
+      if (p.res) { acc[j][0] += rv[j].x; acc[j][1] += rv[j].y; acc[j][2] += rv[j].z; acc[j][3] += rv[j].w; }
       st4(o, make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]));
     }
     if (p.stats) {                                            // (wave-uniform) fp32 over the tile's seven pixels, double across tiles
@@ -213,12 +221,14 @@ extern "C" int rp_conv3x3_c64_f32_blocks(int N) {
 /* y [N,56,56,64] = conv3x3(x [N,56,56,64], w [64][3][3][64]), stride 1, pad 1, exact fp32 (NHWC memory; w = the memory of a channels-last
  * [64,64,3,3] weight).  input_gradient != 0: x is dY and the result is dX of the same convolution -- the filter w'[ci][r][s][co] =
  * w[co][2 - r][2 - s][ci] is read out of the forward weight w.  stats: NULL, or [rp_conv3x3_c64_f32_blocks(N)][2][64] doubles that receive the
- * per-workgroup sums of y and y^2 per channel (BatchNorm statistics of the output, finished by rp_bn_stats_from_partials with a zero pivot). */
-extern "C" int rp_conv3x3_c64_f32(const float* x, const float* w, float* y, double* stats, int N, int H, int W, int input_gradient, void* stream) {
+ * per-workgroup sums of y and y^2 per channel (BatchNorm statistics of the output, finished by rp_bn_stats_from_partials with a zero pivot).
+ * res: NULL, or a tensor of y's shape that is ADDED to the result in the epilogue (y = conv + res; the statistics then describe that sum). */
+extern "C" int rp_conv3x3_c64_f32(const float* x, const float* w, float* y, double* stats, const float* res, int N, int H, int W, int input_gradient,
+                                  void* stream) {
   if (!x || !w || !y || N <= 0) return RP_EBADSHAPE;
   if (H != IH || W != IW) return RP_EUNSUPPORTED;
-  if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)stats) & 15) return RP_EALIGN;
-  CvF p{x, w, y, N * TPI, stats, input_gradient ? 1 : 0};
+  if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)stats | (uintptr_t)res) & 15) return RP_EALIGN;
+  CvF p{x, w, y, N * TPI, res, stats, input_gradient ? 1 : 0};
   hipLaunchKernelGGL(conv3x3_c64_f32_kernel, dim3(rp_conv3x3_c64_f32_blocks(N)), dim3(256), 0, (hipStream_t)stream, p);
   RP_CHECK_LAUNCH();
   return RP_OK;

@@ -13,7 +13,7 @@ import os
 import torch
 import torch.nn as nn
 
-from ..ops import bn_act, conv2d
+from ..ops import bn_act, conv2d, conv2d_shared
 
 
 class BasicBlock(nn.Module):
@@ -31,9 +31,13 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         # BatchNorm + residual add + ReLU as one fused pass pair on the GPU (rel_pose_amd/csrc/batchnorm.hip)
-        idt = x if self.downsample is None else bn_act(self.downsample[1], conv2d(self.downsample[0], x), relu=False)
-        # (bf16 configuration, layer1: the hand-written 3x3 convolution hands the BatchNorm its batch statistics from its epilogue)
-        y, st = conv2d(self.conv1, x, want_stats=True)
+        # (the hand-written 3x3 convolutions hand the BatchNorm its batch statistics from their epilogue; without a downsample branch the
+        # identity path goes through conv1's autograd node, whose input-gradient kernel adds the identity gradient in its epilogue)
+        if self.downsample is None:
+            y, st, idt = conv2d_shared(self.conv1, x)
+        else:
+            idt = bn_act(self.downsample[1], conv2d(self.downsample[0], x), relu=False)
+            y, st = conv2d(self.conv1, x, want_stats=True)
         y = bn_act(self.bn1, y, stats=st)
         y, st = conv2d(self.conv2, y, want_stats=True)
         return bn_act(self.bn2, y, residual=idt, stats=st)

@@ -1995,21 +1995,24 @@ CONV3X3_F32 = os.environ.get("RP_CONV3X3_F32", "1") != "0"
 CONV3X3_F32_MIN_N = int(os.environ.get("RP_CONV3X3_F32_MIN_N", "56"))
 
 
-def conv3x3_c64_f32(x_nhwc, w_ohwi, input_gradient=False, want_stats=False):
+def conv3x3_c64_f32(x_nhwc, w_ohwi, input_gradient=False, want_stats=False, res=None):
     """rp_conv3x3_c64_f32: y = conv3x3(x, w), stride 1, pad 1, exact fp32, for x [N,56,56,64] (NHWC memory) and w [64,3,3,64] (the memory
     of a channels-last [64,64,3,3] weight) -> y [N,56,56,64].  input_gradient: x is dY, the result dX of that convolution (the rotated,
     channel-swapped filter is read out of the forward weight by the kernel).  want_stats: also returns the per-workgroup sums of y and
-    y^2 per channel [blocks,2,64] float64 from the kernel's epilogue (BnActFn's `stats`)."""
+    y^2 per channel [blocks,2,64] float64 from the kernel's epilogue (BnActFn's `stats`).  res: a tensor of y's shape added in the epilogue."""
     lib = _lib.load()
     if not (x_nhwc.is_cuda and x_nhwc.is_contiguous() and x_nhwc.dtype == torch.float32 and tuple(x_nhwc.shape[1:]) == (56, 56, 64)):
         raise RuntimeError("conv3x3_c64_f32: contiguous fp32 [N,56,56,64] GPU tensor expected")
     if not (w_ohwi.is_cuda and w_ohwi.is_contiguous() and w_ohwi.dtype == torch.float32 and tuple(w_ohwi.shape) == (64, 3, 3, 64)):
         raise RuntimeError("conv3x3_c64_f32: contiguous fp32 [64,3,3,64] GPU filter expected")
     N = x_nhwc.shape[0]
+    if res is not None and not (res.is_cuda and res.is_contiguous() and res.dtype == torch.float32 and res.shape == x_nhwc.shape):
+        raise RuntimeError("conv3x3_c64_f32: res must be a contiguous fp32 tensor of the output's shape")
     y = torch.empty_like(x_nhwc)
     stats = torch.empty(lib.rp_conv3x3_c64_f32_blocks(N), 2, 64, device=x_nhwc.device, dtype=torch.float64) if want_stats else None
-    with timed("conv3x3_c64_f32", 2.0 * N * 56 * 56 * 64 * 64 * 9, 4.0 * N * 56 * 56 * 128):
-        _lib.check(lib.rp_conv3x3_c64_f32(_p(x_nhwc), _p(w_ohwi), _p(y), _p(stats), N, 56, 56, 1 if input_gradient else 0, _st()), "rp_conv3x3_c64_f32")
+    with timed("conv3x3_c64_f32", 2.0 * N * 56 * 56 * 64 * 64 * 9, 4.0 * N * 56 * 56 * (128 if res is None else 192)):
+        _lib.check(lib.rp_conv3x3_c64_f32(_p(x_nhwc), _p(w_ohwi), _p(y), _p(stats), _p(res), N, 56, 56, 1 if input_gradient else 0, _st()),
+                   "rp_conv3x3_c64_f32")
     return (y, stats) if want_stats else y
 
 
@@ -2020,34 +2023,43 @@ def _nhwc(t):
 
 class Conv3x3C64F32Fn(_Fn):
     @staticmethod
-    def forward(ctx, x, w, want_stats=False):
-        """want_stats: returns (y, stats) with the output's BatchNorm partial sums from the kernel's epilogue (None when MIOpen ran)"""
+    def forward(ctx, x, w, want_stats=False, share_input=False):
+        """want_stats: returns (y, stats) with the output's BatchNorm partial sums from the kernel's epilogue (None when MIOpen ran).
+        share_input: additionally returns x itself as an output -- the caller uses THAT tensor for the block's identity path, so the
+        gradient of the identity path arrives here and is added in the input-gradient kernel's epilogue instead of by a pass of autograd's."""
         ctx.save_for_backward(x, w)
         own = CONV3X3_F32 and x.shape[0] >= CONV3X3_F32_MIN_N
+        stats = None
         if want_stats and own and CONV_F32_STATS:
             y, stats = conv3x3_c64_f32(_nhwc(x), _nhwc(w), want_stats=True)
             ctx.mark_non_differentiable(stats)
-            return y.permute(0, 3, 1, 2), stats
-        y = conv3x3_c64_f32(_nhwc(x), _nhwc(w)).permute(0, 3, 1, 2) if own else torch.nn.functional.conv2d(x, w, None, 1, 1)
-        return (y, None) if want_stats else y
+            y = y.permute(0, 3, 1, 2)
+        else:
+            y = conv3x3_c64_f32(_nhwc(x), _nhwc(w)).permute(0, 3, 1, 2) if own else torch.nn.functional.conv2d(x, w, None, 1, 1)
+        if share_input:
+            return y, stats, x.view_as(x)
+        return (y, stats) if want_stats else y
 
     @staticmethod
-    def backward(ctx, dy, *_):
+    def backward(ctx, dy, *rest):
         x, w = ctx.saved_tensors
         dx = dw = None
         dy = dy.contiguous(memory_format=torch.channels_last)
+        dshared = rest[1] if len(rest) > 1 else None              # gradient of the shared-input output (the identity path)
         if ctx.needs_input_grad[0]:
             if CONV3X3_F32 and x.shape[0] >= CONV3X3_F32_MIN_N:
-                # dX = conv3x3(dY, w') with w'[ci][r][s][co] = w[co][2 - r][2 - s][ci], read out of w by the kernel
-                dx = conv3x3_c64_f32(_nhwc(dy), _nhwc(w), input_gradient=True).permute(0, 3, 1, 2)
+                # dX = conv3x3(dY, w') with w'[ci][r][s][co] = w[co][2 - r][2 - s][ci], read out of w by the kernel (+ the identity path's gradient)
+                dx = conv3x3_c64_f32(_nhwc(dy), _nhwc(w), input_gradient=True, res=None if dshared is None else _nhwc(dshared)).permute(0, 3, 1, 2)
             else:
                 dx = torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+                if dshared is not None:
+                    dx = dx + dshared
         if ctx.needs_input_grad[1]:
             if CONV3X3_WGRAD_F32 and x.shape[0] >= CONV3X3_WGRAD_F32_MIN_N:
                 dw = conv3x3_c64_wgrad_f32(_nhwc(x), dy.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
             else:
                 dw = torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
-        return dx, dw, None
+        return dx, dw, None, None
 
 
 # The 128-input-channel 3x3 convolutions on 28 x 28 maps (resnet.layer2's 128 -> 128 convolutions forward and input gradient, the forward of
@@ -2059,7 +2071,7 @@ CONV_F32_STATS = os.environ.get("RP_CONV_F32_STATS", "1") != "0"
 CONV3X3_C128_F32_MIN_N = int(os.environ.get("RP_CONV3X3_C128_F32_MIN_N", "56"))
 
 
-def conv3x3_c128_f32(x_nhwc, w_ohwi, bias=None, input_gradient=False, want_stats=False):
+def conv3x3_c128_f32(x_nhwc, w_ohwi, bias=None, input_gradient=False, want_stats=False, res=None):
     """rp_conv3x3_c128_f32: y = bias + conv3x3(x, w), stride 1, pad 1, exact fp32, for x [N,28,28,128] (NHWC memory) and w [CO,3,3,128]
     (the memory of a channels-last [CO,128,3,3] weight), CO = 128 or 192 -> y [N,28,28,CO].  input_gradient (CO = 128, no bias): x is dY,
     the result dX of the convolution whose forward weight is w.  want_stats: also returns the per-chunk sums of y and y^2 per channel
@@ -2076,12 +2088,14 @@ def conv3x3_c128_f32(x_nhwc, w_ohwi, bias=None, input_gradient=False, want_stats
     if bias is not None and not (bias.is_cuda and bias.is_contiguous() and bias.dtype == torch.float32 and tuple(bias.shape) == (CO,)):
         raise RuntimeError("conv3x3_c128_f32: contiguous fp32 [CO] GPU bias expected")
     N = x_nhwc.shape[0]
+    if res is not None and not (res.is_cuda and res.is_contiguous() and res.dtype == torch.float32 and tuple(res.shape) == (N, 28, 28, CO)):
+        raise RuntimeError("conv3x3_c128_f32: res must be a contiguous fp32 [N,28,28,CO] tensor")
     y = torch.empty(N, 28, 28, CO, device=x_nhwc.device, dtype=torch.float32)
     stats = (torch.empty(lib.rp_conv3x3_c128_f32_blocks(N, CO) // (CO // 64), 2, CO, device=x_nhwc.device, dtype=torch.float64)
              if want_stats else None)
     with timed("conv3x3_c128_f32", 2.0 * N * 28 * 28 * 128 * CO * 9, 4.0 * N * 28 * 28 * (128 + CO)):
-        _lib.check(lib.rp_conv3x3_c128_f32(_p(x_nhwc), _p(w_ohwi), _p(bias), _p(y), _p(stats), N, 28, 28, CO, 1 if input_gradient else 0,
-                                           _st()), "rp_conv3x3_c128_f32")
+        _lib.check(lib.rp_conv3x3_c128_f32(_p(x_nhwc), _p(w_ohwi), _p(bias), _p(y), _p(stats), _p(res), N, 28, 28, CO,
+                                           1 if input_gradient else 0, _st()), "rp_conv3x3_c128_f32")
     return (y, stats) if want_stats else y
 
 
@@ -2089,32 +2103,40 @@ class Conv3x3C128F32Fn(_Fn):
     """forward (and, for the square filter, input gradient) on rp_conv3x3_c128_f32; weight / bias gradients on MIOpen"""
 
     @staticmethod
-    def forward(ctx, x, w, bias, want_stats=False):
+    def forward(ctx, x, w, bias, want_stats=False, share_input=False):
+        """want_stats / share_input: see Conv3x3C64F32Fn"""
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
+        stats = None
         if want_stats and CONV_F32_STATS:
             y, stats = conv3x3_c128_f32(_nhwc(x), _nhwc(w), bias, want_stats=True)
             ctx.mark_non_differentiable(stats)
-            return y.permute(0, 3, 1, 2), stats
-        y = conv3x3_c128_f32(_nhwc(x), _nhwc(w), bias).permute(0, 3, 1, 2)           # (channels-last NCHW view of the NHWC result)
-        return (y, None) if want_stats else y
+        else:
+            y = conv3x3_c128_f32(_nhwc(x), _nhwc(w), bias)
+        y = y.permute(0, 3, 1, 2)                                  # (channels-last NCHW view of the NHWC result)
+        if share_input:
+            return y, stats, x.view_as(x)
+        return (y, stats) if want_stats else y
 
     @staticmethod
-    def backward(ctx, dy, *_):
+    def backward(ctx, dy, *rest):
         x, w = ctx.saved_tensors
         dx = dw = db = None
         dy = dy.contiguous(memory_format=torch.channels_last)
+        dshared = rest[1] if len(rest) > 1 else None
         CO = w.shape[0]
         own_dx = ctx.needs_input_grad[0] and CO == 128
         if own_dx:
-            dx = conv3x3_c128_f32(_nhwc(dy), _nhwc(w), input_gradient=True).permute(0, 3, 1, 2)
+            dx = conv3x3_c128_f32(_nhwc(dy), _nhwc(w), input_gradient=True, res=None if dshared is None else _nhwc(dshared)).permute(0, 3, 1, 2)
         mask = [bool(ctx.needs_input_grad[0]) and not own_dx, bool(ctx.needs_input_grad[1]), ctx.has_bias and bool(ctx.needs_input_grad[2])]
         if any(mask):
             g = torch.ops.aten.convolution_backward(dy, x, w, [CO] if ctx.has_bias else None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, mask)
             dx = g[0] if mask[0] else dx
             dw = g[1] if mask[1] else None
             db = g[2] if mask[2] else None
-        return dx, dw, db, None
+            if mask[0] and dshared is not None:
+                dx = dx + dshared
+        return dx, dw, db, None, None
 
 
 def conv3x3_c128_f32_ok(m, x):
@@ -2152,15 +2174,15 @@ def conv2d(m, x, want_stats=False):
         if CNN_PRECISION == 0 and x.is_cuda and torch.is_grad_enabled():
             # exact-fp32 configuration: the own convolutions write the statistics partials in their epilogue
             if conv3x3_f32_ok(m, x):
-                return Conv3x3C64F32Fn.apply(x, m.weight, True)
+                return Conv3x3C64F32Fn.apply(x, m.weight, True, False)
             if conv3x3_c128_f32_ok(m, x):
-                return Conv3x3C128F32Fn.apply(x, m.weight, m.bias, True)
+                return Conv3x3C128F32Fn.apply(x, m.weight, m.bias, True, False)
         return conv2d(m, x), None
     if CNN_PRECISION == 0 or not x.is_cuda:
         if conv3x3_wgrad_f32_ok(m, x) or conv3x3_f32_ok(m, x):
-            return Conv3x3C64F32Fn.apply(x, m.weight, False)
+            return Conv3x3C64F32Fn.apply(x, m.weight, False, False)
         if conv3x3_c128_f32_ok(m, x):
-            return Conv3x3C128F32Fn.apply(x, m.weight, m.bias, False)
+            return Conv3x3C128F32Fn.apply(x, m.weight, m.bias, False, False)
         return m(x)
     bf = torch.bfloat16
     ready = getattr(m, "_rp_bf16", None)
@@ -2176,6 +2198,24 @@ def conv2d(m, x, want_stats=False):
     # only the first convolution's input and the small weights are cast
     return torch.nn.functional.conv2d(x if x.dtype == bf else x.to(bf), m.weight.to(bf), None if m.bias is None else m.bias.to(bf),
                                       m.stride, m.padding, m.dilation, m.groups)
+
+
+# A/B aid: the identity path's gradient of a BasicBlock is added in the epilogue of its first convolution's input-gradient kernel
+CONV_F32_SHARE_INPUT = os.environ.get("RP_CONV_F32_SHARE_INPUT", "1") != "0"
+
+
+def conv2d_shared(m, x):
+    """(y, stats, x') for the FIRST convolution of a residual block whose identity path is x itself: y = m(x), stats as conv2d(...,
+    want_stats=True), and x' = the tensor to use for the identity path.  With the own exact-fp32 convolutions x' is an output of the
+    convolution's autograd node, so the gradient of the identity path is handed to that node and added in its input-gradient kernel's
+    epilogue (no separate add pass); otherwise x' is x."""
+    if (CONV_F32_SHARE_INPUT and CNN_PRECISION == 0 and x.is_cuda and torch.is_grad_enabled() and x.requires_grad):
+        if conv3x3_f32_ok(m, x):
+            return Conv3x3C64F32Fn.apply(x, m.weight, True, True)
+        if conv3x3_c128_f32_ok(m, x) and m.weight.shape[0] == 128 and m.bias is None:
+            return Conv3x3C128F32Fn.apply(x, m.weight, None, True, True)
+    y, st = conv2d(m, x, want_stats=True)
+    return y, st, x
 
 
 _NBT_PENDING = None      # inside `with batches_tracked_batch():` the num_batches_tracked buffers to bump at exit

@@ -36,8 +36,8 @@ extern "C" {
  * functions this header declares.  rp_abi_version() / rp_abi_export_count() return the values the library was COMPILED with, so a
  * binding (rel_pose_amd/_lib.py parses both macros and counts the declarations) rejects a stale .so at load time instead of
  * failing later on a missing symbol. */
-#define RP_ABI_VERSION 25
-#define RP_ABI_EXPORTS 109
+#define RP_ABI_VERSION 26
+#define RP_ABI_EXPORTS 110
 int rp_abi_version(void);
 int rp_abi_export_count(void);
 const char* rp_target_arch(void);
@@ -163,6 +163,11 @@ int rp_bn_apply_fwd(const void* x, const float* mean, const float* rstd, const f
 int rp_bn_bwd(const void* dy, const void* y, const void* x, const float* mean, const float* rstd, const float* gamma,
               const float* beta, void* dx, void* dres, float* dgamma, float* dbeta, double* partial, float* c12, long long R, int C, int relu,
               int training, int bf16, void* stream);
+/* rp_bn_bwd's second and third pass for a BatchNorm whose masked incoming gradient g [R,C] fp32 and column-sum partials ([nblk][2][C]
+ * doubles: sums of g and of g * xhat over disjoint row sets) were produced elsewhere (RpBnMask epilogue of the convolution kernels):
+ * dgamma, dbeta, and dx = gamma * rstd * (g - mean(g) - xhat * mean(g * xhat)).  c12: [2 C] floats of scratch. */
+int rp_bn_bwd_from_partials(const float* g, const float* x, const float* mean, const float* rstd, const float* gamma, const double* partial,
+                            int nblk, float* dx, float* dgamma, float* dbeta, float* c12, long long R, int C, void* stream);
 
 /* 3x3 / stride 2 / pad 1 max-pool (torchvision resnet.maxpool as driven by src/model.py:130), channels-last:
  * x [N,H,W,C] -> y [N,OH,OW,C], OH = (H-1)/2+1; idx (bytes, same shape as y) = window position 0..8 of the first maximum in scan
@@ -232,9 +237,21 @@ int rp_conv3x3_c64_wgrad_f32(const float* x, const float* dy, float* dw, void* w
  * v_mfma_f32_16x16x4_f32), the input rows in a padded LDS ring read by one conflict-free ds_read_b32 per MFMA; one persistent
  * workgroup per CU (rp_conv3x3_c64_f32_blocks).  input_gradient != 0: x is dY and y is dX of the same convolution -- the filter
  * w'[ci][r][s][co] = w[co][2 - r][2 - s][ci] is read out of the forward weight w (no rotated copy). */
+/* BatchNorm-backward epilogue of the two convolution kernels below (input_gradient launches): the convolution's result is the gradient of
+ * a = relu(batch_norm(x)) (torchvision BasicBlock: out = relu(bn1(conv1(.))) feeds conv2); with `bn` given the kernel masks it,
+ * g = result * (fma(x - mean, rstd * gamma, beta) > 0) -- bit for bit rp_bn_apply_fwd's expression --, stores g instead, and `stats` receives
+ * the per-workgroup sums of g and g * (x - mean) * rstd: the column sums rp_bn_bwd's first pass would read dy and x again for.
+ * rp_bn_bwd_from_partials then finishes that BatchNorm's backward from g and the partials (second + third pass only). */
+typedef struct RpBnMask {
+  const float* x;        /* the BatchNorm's INPUT, same shape as the convolution's result */
+  const float* mean;
+  const float* rstd;
+  const float* gamma;
+  const float* beta;
+} RpBnMask;
 int rp_conv3x3_c64_f32_blocks(int N);
-int rp_conv3x3_c64_f32(const float* x, const float* w, float* y, double* stats, const float* res, int N, int H, int W, int input_gradient,
-                       void* stream);
+int rp_conv3x3_c64_f32(const float* x, const float* w, float* y, double* stats, const float* res, const RpBnMask* bn, int N, int H, int W,
+                       int input_gradient, void* stream);
 /* The 3x3 / stride 1 / pad 1 convolutions with 128 INPUT channels on 28 x 28 maps in exact fp32 (csrc/conv3x3_c128_f32.hip): resnet.layer2's
  * 128 -> 128 convolutions (reference src/model.py:132, torchvision BasicBlock.conv1/conv2 through cuDNN), forward and input gradient, and the
  * forward of extractor_final_conv.conv1, 128 -> 192 with bias (src/modules/extractor.py:9,51).  y [N,28,28,CO] = bias + conv3x3(x [N,28,28,128],
@@ -246,8 +263,8 @@ int rp_conv3x3_c64_f32(const float* x, const float* w, float* y, double* stats, 
  * tensor of y's shape that is added to the result in the epilogue -- used for the input gradient of a BasicBlock's first convolution, where
  * autograd would add the gradient arriving over the identity path (torchvision BasicBlock: out += identity) in a pass of its own.  input_gradient != 0 (CO == 128, no bias): x is dY and y is dX of the convolution whose FORWARD weight is w. */
 int rp_conv3x3_c128_f32_blocks(int N, int CO);
-int rp_conv3x3_c128_f32(const float* x, const float* w, const float* bias, float* y, double* stats, const float* res, int N, int H, int W,
-                        int CO, int input_gradient, void* stream);
+int rp_conv3x3_c128_f32(const float* x, const float* w, const float* bias, float* y, double* stats, const float* res, const RpBnMask* bn, int N,
+                        int H, int W, int CO, int input_gradient, void* stream);
 
 /* The stem's BatchNorm -> ReLU -> MaxPool2d(3, 2, 1) chain (src/model.py:127-130 on torchvision's resnet.bn1 / relu / maxpool) without
  * the [N,H,W,C] intermediates.  Forward (after rp_bn_stats, or with the running statistics in eval): y [N,OH,OW,C], idx = window

@@ -48,6 +48,10 @@ class RpColsumTask(Structure):
     _fields_ = [("in_", c_void_p), ("rows", c_int), ("cols", c_int), ("ld", c_int), ("out", c_void_p)]
 
 
+class RpBnMask(Structure):
+    _fields_ = [("x", c_void_p), ("mean", c_void_p), ("rstd", c_void_p), ("gamma", c_void_p), ("beta", c_void_p)]
+
+
 class RpSplitkTask(Structure):
     _fields_ = [("ws", c_void_p), ("C", c_void_p), ("M", c_int), ("N", c_int), ("ldc", c_int), ("split_k", c_int), ("trans_c", c_int)]
 
@@ -75,6 +79,7 @@ _SIGS = {
     "rp_bn_stats": (c_int, [P, L, I, P, P, P, P, P, F, F, I, P]),
     "rp_bn_apply_fwd": (c_int, [P, P, P, P, P, P, P, L, I, I, I, P]),
     "rp_bn_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, P]),
+    "rp_bn_bwd_from_partials": (c_int, [P, P, P, P, P, P, I, P, P, P, P, L, I, P]),
     "rp_layernorm_fwd": (c_int, [P, P, P, P, P, P, I, I, F, P]),
     "rp_layernorm_bwd_blocks": (c_int, [I]),
     "rp_layernorm_bwd": (c_int, [P, P, P, P, P, P, P, P, P, I, I, P]),
@@ -147,9 +152,9 @@ _SIGS = {
     "rp_conv3x3_c64_wgrad_f32_workspace_bytes": (c_size_t, [I]),
     "rp_conv3x3_c64_wgrad_f32": (c_int, [P, P, P, P, c_size_t, I, I, I, P]),
     "rp_conv3x3_c64_f32_blocks": (c_int, [I]),
-    "rp_conv3x3_c64_f32": (c_int, [P, P, P, P, P, I, I, I, I, P]),
+    "rp_conv3x3_c64_f32": (c_int, [P, P, P, P, P, POINTER(RpBnMask), I, I, I, I, P]),
     "rp_conv3x3_c128_f32_blocks": (c_int, [I, I]),
-    "rp_conv3x3_c128_f32": (c_int, [P, P, P, P, P, P, I, I, I, I, I, P]),
+    "rp_conv3x3_c128_f32": (c_int, [P, P, P, P, P, P, POINTER(RpBnMask), I, I, I, I, I, P]),
     "rp_bn_stats_from_partials": (c_int, [P, I, L, I, P, P, P, P, P, F, F, P]),
     "rp_bn_relu_pool_fwd": (c_int, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "rp_bn_relu_pool_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P]),

@@ -401,6 +401,22 @@ extern "C" int rp_bn_bwd(const void* dy, const void* y, const void* x, const flo
                   c12, R, C, relu, training, (hipStream_t)stream);
 }
 
+extern "C" int rp_bn_bwd_from_partials(const float* g, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                       const double* partial, int nblk, float* dx, float* dgamma, float* dbeta, float* c12, long long R, int C,
+                                       void* stream) {
+  if (int e = bn_check(R, C)) return e;
+  if (!g || !x || !partial || nblk <= 0 || !dx || !dgamma || !dbeta || !c12) return RP_EBADSHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL((bn_finalize_kernel<1, float>), dim3((C + 15) / 16), dim3(1024), 0, st, partial, nblk, C, R, dbeta, dgamma, nullptr, nullptr,
+                     0.f, 0.f, c12, nullptr);
+  RP_CHECK_LAUNCH();
+  const long long n4 = R * C / 4;
+  hipLaunchKernelGGL((bn_apply_bwd_kernel<false, float>), dim3(apply_grid(n4)), dim3(256), 0, st, g, (const float*)nullptr, g, x, mean, rstd, gamma,
+                     (const float*)nullptr, (const float*)c12, dx, n4, C / 4, 0, PoolSrc{});
+  RP_CHECK_LAUNCH();
+  return RP_OK;
+}
+
 // ---- 3x3 / stride 2 / pad 1 max-pool of the stem (torchvision resnet.maxpool), channels-last --------------------------
 // PyTorch's NHWC max-pool kernels take 139 us forward and 336 us backward on the [128,64,112,112] stem activation; both are
 // plain HBM streams (103 MB in, 26 MB out and back).  Forward stores the window position (0..8) of the FIRST maximum in

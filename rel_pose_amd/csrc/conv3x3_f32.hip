@@ -43,6 +43,7 @@ struct CvF {
   int ntiles;           // N * 28
   const float* res;     // null, or [N,56,56,64]: added to the result (the input gradient of a BasicBlock's first convolution + the gradient that
                         // arrives over the identity path: autograd's separate add pass, 309 MB, disappears)
+  RpBnMask bn;          // bn.x != null: the result is masked by the ReLU of batch_norm(bn.x) and `stats` receives sums of g and g * xhat
   double* stats;        // null, or [gridDim][2][64]: per-workgroup sums of y and y^2 per output channel (the BatchNorm statistics of the
                         // OUTPUT, csrc/batchnorm.hip: rp_bn_stats_from_partials) -- the statistics pass over y is then not needed
   int dgrad;            // 0: filter W[co][r][s][ci] as it lies; 1: the input gradient's filter W'[ci][r][s][co] = W[co][2 - r][2 - s][ci], read
@@ -114,6 +115,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_f32_kernel(CvF p) {
   sstore(pre2, a0 + 2);
   __syncthreads();
 
+  // BatchNorm-mask epilogue: this lane's four channels' mean, rstd * gamma (the forward's product), beta, rstd
+  float bmu[4] = {0.f, 0.f, 0.f, 0.f}, brg[4] = {0.f, 0.f, 0.f, 0.f}, bbe[4] = {0.f, 0.f, 0.f, 0.f}, brs[4] = {0.f, 0.f, 0.f, 0.f};
+  if (p.bn.x) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int ch = 16 * wave + 4 * kq + e;
+      bmu[e] = p.bn.mean[ch]; brs[e] = p.bn.rstd[ch]; brg[e] = p.bn.rstd[ch] * p.bn.gamma[ch]; bbe[e] = p.bn.beta[ch];
+    }
+  }
   // per-lane pixel of each 16-pixel block: flattened index 16 j + l15 of the two rows -> (row 0 / 1, column)
   int orow[NBLK], ocol[NBLK];
 #pragma unroll
@@ -142,10 +152,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_f32_kernel(CvF p) {
     f32x4 acc[NBLK];
 #pragma unroll
     for (int j = 0; j < NBLK; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float4 rv[NBLK];                                         // the residual of this tile's outputs, requested a tile's worth of MFMAs early
+    float4 rv[NBLK], bx[NBLK];                               // the residual / the BatchNorm input at this tile's outputs, requested a tile's worth of MFMAs early
     if (p.res) {
 #pragma unroll
       for (int j = 0; j < NBLK; ++j) rv[j] = ld4(p.res + (((long long)g0 + orow[j]) * IW + ocol[j]) * C + 16 * wave + 4 * kq);
+    }
+    if (p.bn.x) {
+#pragma unroll
+      for (int j = 0; j < NBLK; ++j) bx[j] = ld4(p.bn.x + (((long long)g0 + orow[j]) * IW + ocol[j]) * C + 16 * wave + 4 * kq);
     }
     // Two operand register sets, picked by the k-step's parity at compile time.  The seven reads of k-step k + 1 go out ONE BEHIND EACH
     // MFMA of k-step k (a block of seven reads per k-step left the matrix pipe drained while they issued: 19 % of the tile), and each MFMA
@@ -171,21 +185,36 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_f32_kernel(CvF p) {
         }
       });
     });
-    // D[m = co 4 kq + e][n = pixel l15]: four consecutive output channels of one pixel per lane
+    // D[m = co 4 kq + e][n = pixel l15]: four consecutive output channels of one pixel per lane.  The epilogue's two sums per channel: y and
+    // y^2 (forward: BatchNorm statistics of the output), or -- bn -- g and g * xhat of the masked gradient g (the BatchNorm's backward sums);
+    // fp32 over the tile's seven pixels, double across tiles
+    float ta[4] = {0.f, 0.f, 0.f, 0.f}, tq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < NBLK; ++j) {
-      float* o = p.y + (((long long)g0 + orow[j]) * IW + ocol[j]) * C + 16 * wave + 4 * kq;
+      const long long off = (((long long)g0 + orow[j]) * IW + ocol[j]) * C + 16 * wave + 4 * kq;
       if (p.res) { acc[j][0] += rv[j].x; acc[j][1] += rv[j].y; acc[j][2] += rv[j].z; acc[j][3] += rv[j].w; }
-      st4(o, make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]));
+      if (p.bn.x) {
+        const float4 xv = bx[j];
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = xs[e] - bmu[e];
+          const float yv = __builtin_fmaf(d, brg[e], bbe[e]);          // = bn_affine (csrc/batchnorm.hip), bit for bit
+          acc[j][e] = yv > 0.f ? acc[j][e] : 0.f;
+          ta[e] += acc[j][e];
+          tq[e] = fmaf(acc[j][e], d * brs[e], tq[e]);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ta[e] += acc[j][e]; tq[e] = fmaf(acc[j][e], acc[j][e], tq[e]); }
+      }
+      st4(p.y + off, make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]));
     }
-    if (p.stats) {                                            // (wave-uniform) fp32 over the tile's seven pixels, double across tiles
+    if (p.stats) {                                            // (wave-uniform)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float a = 0.f, q = 0.f;
-#pragma unroll
-        for (int j = 0; j < NBLK; ++j) { a += acc[j][e]; q = fmaf(acc[j][e], acc[j][e], q); }
-        sd1[e] += (double)a;
-        sd2[e] += (double)q;
+        sd1[e] += (double)ta[e];
+        sd2[e] += (double)tq[e];
       }
     }
     if (t + 1 < t1) sstore(pre, g0 + 3);                      // slots of rows g0 + 3, g0 + 4: not among this tile's g0 - 1 .. g0 + 2
@@ -222,13 +251,15 @@ extern "C" int rp_conv3x3_c64_f32_blocks(int N) {
  * [64,64,3,3] weight).  input_gradient != 0: x is dY and the result is dX of the same convolution -- the filter w'[ci][r][s][co] =
  * w[co][2 - r][2 - s][ci] is read out of the forward weight w.  stats: NULL, or [rp_conv3x3_c64_f32_blocks(N)][2][64] doubles that receive the
  * per-workgroup sums of y and y^2 per channel (BatchNorm statistics of the output, finished by rp_bn_stats_from_partials with a zero pivot).
- * res: NULL, or a tensor of y's shape that is ADDED to the result in the epilogue (y = conv + res; the statistics then describe that sum). */
-extern "C" int rp_conv3x3_c64_f32(const float* x, const float* w, float* y, double* stats, const float* res, int N, int H, int W, int input_gradient,
-                                  void* stream) {
+ * res: NULL, or a tensor of y's shape that is ADDED to the result in the epilogue (y = conv + res; the statistics then describe that sum).
+ * bn: NULL, or the BatchNorm-mask epilogue (include/relpose_hip.h: RpBnMask; needs stats). */
+extern "C" int rp_conv3x3_c64_f32(const float* x, const float* w, float* y, double* stats, const float* res, const RpBnMask* bn, int N, int H, int W,
+                                  int input_gradient, void* stream) {
   if (!x || !w || !y || N <= 0) return RP_EBADSHAPE;
   if (H != IH || W != IW) return RP_EUNSUPPORTED;
   if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)stats | (uintptr_t)res) & 15) return RP_EALIGN;
-  CvF p{x, w, y, N * TPI, res, stats, input_gradient ? 1 : 0};
+  if (bn && (!bn->x || !bn->mean || !bn->rstd || !bn->gamma || !bn->beta || !stats || ((uintptr_t)bn->x & 15))) return RP_EBADSHAPE;
+  CvF p{x, w, y, N * TPI, res, bn ? *bn : RpBnMask{nullptr, nullptr, nullptr, nullptr, nullptr}, stats, input_gradient ? 1 : 0};
   hipLaunchKernelGGL(conv3x3_c64_f32_kernel, dim3(rp_conv3x3_c64_f32_blocks(N)), dim3(256), 0, (hipStream_t)stream, p);
   RP_CHECK_LAUNCH();
   return RP_OK;

@@ -12,6 +12,7 @@ All tensors are fp32, contiguous, on the GPU; anything else raises (there is no 
 front-end's bn_act / maxpool3x3s2 wrappers hand CPU tensors to the stock torch modules, for the fixture generator).
 """
 import ctypes
+import itertools
 import math
 import os
 import threading
@@ -1780,6 +1781,16 @@ class LayerNormFn(_Fn):
 # ------------------------------------------------------------------------------------------------
 # CNN front-end: channels-last BatchNorm2d + residual add + ReLU in two passes each way (csrc/batchnorm.hip)
 # ------------------------------------------------------------------------------------------------
+# BatchNorm backward, first pass fused into the producer of its incoming gradient (exact-fp32 configuration): BnActFn.forward hands out a
+# token with (x, mean, rstd, gamma, beta) (`_BN_LAST`, attached to its output by bn_act); a hand-written convolution that consumes that output
+# keeps it, masks its input gradient with the ReLU and posts the column-sum partials under the token (`_BN_PENDING`); BnActFn.backward finds
+# them and runs only its second and third pass.  RP_CONV_F32_BN_BWD=0: off (A/B aid).
+CONV_F32_BN_BWD = os.environ.get("RP_CONV_F32_BN_BWD", "1") != "0"
+_BN_TOKENS = itertools.count(1)
+_BN_LAST = None
+_BN_PENDING = {}
+
+
 class BnActFn(_Fn):
     """y = relu?(batch_norm(x) (+ residual)) for a channels-last NCHW x; same statistics / running-buffer semantics as
     torch.nn.BatchNorm2d (biased batch variance for the normalisation, unbiased for running_var, momentum update in
@@ -1817,11 +1828,19 @@ class BnActFn(_Fn):
             mean, rstd = running_mean, torch.rsqrt(running_var + eps)
         _lib.check(lib.rp_bn_apply_fwd(_p(xr), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(rr), _p(y), R, C, 1 if relu else 0,
                                        bf, _st()), "rp_bn_apply_fwd")
+        global _BN_LAST
+        _BN_LAST = None
         if _train(ctx):
             # without a residual the ReLU mask is re-evaluated from x in the backward: y is not kept alive for it
             keep_y = y if (relu and residual is not None) else None
             ctx.save_for_backward(xr, keep_y, mean, rstd, gamma, beta)
             ctx.cfg = (R, C, bool(relu), bool(training), residual is not None)
+            ctx.token = None
+            if training and relu and residual is None and not bf and CONV_F32_BN_BWD:
+                # a consumer of this output that computes its own input gradient (the hand-written fp32 convolutions) may mask that gradient
+                # with this ReLU and form this BatchNorm's backward column sums in its epilogue: see bn_act / conv2d / _BN_PENDING
+                ctx.token = next(_BN_TOKENS)
+                _BN_LAST = (ctx.token, xr, mean, rstd, gamma, beta)
         return y.permute(0, 3, 1, 2)
 
     @staticmethod
@@ -1838,6 +1857,14 @@ class BnActFn(_Fn):
         dx = torch.empty_like(xr)
         dres = torch.empty_like(xr) if has_res and ctx.needs_input_grad[5] else None
         dgamma, dbeta, c12 = _empty(C, like=xr), _empty(C, like=xr), _empty(2 * C, like=xr)
+        hit = _BN_PENDING.pop(ctx.token, None) if getattr(ctx, "token", None) is not None else None
+        if hit is not None and hit[0] == dyr.data_ptr() and training and relu and not has_res and not bf:
+            # dy IS the masked gradient g, written by the convolution kernel that produced it together with the column sums of g and g * xhat
+            part = hit[1]
+            _lib.check(lib.rp_bn_bwd_from_partials(_p(dyr), _p(xr), _p(mean), _p(rstd), _p(gamma), _p(part), part.shape[0], _p(dx), _p(dgamma),
+                                                   _p(dbeta), _p(c12), R, C, _st()), "rp_bn_bwd_from_partials")
+            return (dx.permute(0, 3, 1, 2), dgamma, dbeta, None, None, None, None, None, None, None, None)
+        # (a gradient that was masked by a producer but arrives as another tensor takes the full path: masking twice is the identity)
         part = torch.empty(lib.rp_bn_partial_blocks(R) * 2 * C, device=xr.device, dtype=torch.float64)
         _lib.check(lib.rp_bn_bwd(_p(dyr), _p(y), _p(xr), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dx), _p(dres), _p(dgamma), _p(dbeta),
                                  _p(part), _p(c12), R, C, 1 if relu else 0, 1 if training else 0, bf, _st()), "rp_bn_bwd")
@@ -1995,11 +2022,31 @@ CONV3X3_F32 = os.environ.get("RP_CONV3X3_F32", "1") != "0"
 CONV3X3_F32_MIN_N = int(os.environ.get("RP_CONV3X3_F32_MIN_N", "56"))
 
 
-def conv3x3_c64_f32(x_nhwc, w_ohwi, input_gradient=False, want_stats=False, res=None):
+def _bn_mask(bn, y, want_stats):
+    """RpBnMask of the convolution kernels' BatchNorm-backward epilogue (None = off): bn = (x_bn, mean, rstd, gamma, beta)"""
+    if bn is None:
+        return None
+    xb, mean, rstd, gamma, beta = bn
+    C = y.shape[-1]
+    if not want_stats:
+        raise RuntimeError("the BatchNorm-mask epilogue needs want_stats (its column sums are the point)")
+    if not (xb.is_cuda and xb.is_contiguous() and xb.dtype == torch.float32 and xb.shape == y.shape):
+        raise RuntimeError("the BatchNorm-mask epilogue needs the BatchNorm input as a contiguous fp32 tensor of the result's shape")
+    for t in (mean, rstd, gamma, beta):
+        if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32 and tuple(t.shape) == (C,)):
+            raise RuntimeError("the BatchNorm-mask epilogue needs contiguous fp32 [C] statistics and parameters")
+    m = _lib.RpBnMask()
+    m.x, m.mean, m.rstd, m.gamma, m.beta = xb.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr()
+    return ctypes.byref(m)
+
+
+def conv3x3_c64_f32(x_nhwc, w_ohwi, input_gradient=False, want_stats=False, res=None, bn=None):
     """rp_conv3x3_c64_f32: y = conv3x3(x, w), stride 1, pad 1, exact fp32, for x [N,56,56,64] (NHWC memory) and w [64,3,3,64] (the memory
     of a channels-last [64,64,3,3] weight) -> y [N,56,56,64].  input_gradient: x is dY, the result dX of that convolution (the rotated,
     channel-swapped filter is read out of the forward weight by the kernel).  want_stats: also returns the per-workgroup sums of y and
-    y^2 per channel [blocks,2,64] float64 from the kernel's epilogue (BnActFn's `stats`).  res: a tensor of y's shape added in the epilogue."""
+    y^2 per channel [blocks,2,64] float64 from the kernel's epilogue (BnActFn's `stats`).  res: a tensor of y's shape added in the epilogue.
+    bn = (x_bn [N,56,56,64], mean, rstd, gamma, beta) (with want_stats): the result is the gradient of relu(batch_norm(x_bn)); it is masked by
+    that ReLU and the partials are the sums of g and g * xhat (rp_bn_bwd_from_partials finishes the BatchNorm's backward)."""
     lib = _lib.load()
     if not (x_nhwc.is_cuda and x_nhwc.is_contiguous() and x_nhwc.dtype == torch.float32 and tuple(x_nhwc.shape[1:]) == (56, 56, 64)):
         raise RuntimeError("conv3x3_c64_f32: contiguous fp32 [N,56,56,64] GPU tensor expected")
@@ -2011,8 +2058,8 @@ def conv3x3_c64_f32(x_nhwc, w_ohwi, input_gradient=False, want_stats=False, res=
     y = torch.empty_like(x_nhwc)
     stats = torch.empty(lib.rp_conv3x3_c64_f32_blocks(N), 2, 64, device=x_nhwc.device, dtype=torch.float64) if want_stats else None
     with timed("conv3x3_c64_f32", 2.0 * N * 56 * 56 * 64 * 64 * 9, 4.0 * N * 56 * 56 * (128 if res is None else 192)):
-        _lib.check(lib.rp_conv3x3_c64_f32(_p(x_nhwc), _p(w_ohwi), _p(y), _p(stats), _p(res), N, 56, 56, 1 if input_gradient else 0, _st()),
-                   "rp_conv3x3_c64_f32")
+        _lib.check(lib.rp_conv3x3_c64_f32(_p(x_nhwc), _p(w_ohwi), _p(y), _p(stats), _p(res), _bn_mask(bn, y, want_stats), N, 56, 56,
+                                          1 if input_gradient else 0, _st()), "rp_conv3x3_c64_f32")
     return (y, stats) if want_stats else y
 
 
@@ -2023,12 +2070,15 @@ def _nhwc(t):
 
 class Conv3x3C64F32Fn(_Fn):
     @staticmethod
-    def forward(ctx, x, w, want_stats=False, share_input=False):
+    def forward(ctx, x, w, want_stats=False, share_input=False, bn_src=None):
         """want_stats: returns (y, stats) with the output's BatchNorm partial sums from the kernel's epilogue (None when MIOpen ran).
+        bn_src = (token, x_bn, mean, rstd, gamma, beta) of the BatchNorm + ReLU that produced x (BnActFn): the input gradient is masked by
+        that ReLU in the kernel and the BatchNorm's backward column sums are posted under the token.
         share_input: additionally returns x itself as an output -- the caller uses THAT tensor for the block's identity path, so the
         gradient of the identity path arrives here and is added in the input-gradient kernel's epilogue instead of by a pass of autograd's."""
         ctx.save_for_backward(x, w)
         own = CONV3X3_F32 and x.shape[0] >= CONV3X3_F32_MIN_N
+        ctx.bn_src = bn_src if own else None
         stats = None
         if want_stats and own and CONV_F32_STATS:
             y, stats = conv3x3_c64_f32(_nhwc(x), _nhwc(w), want_stats=True)
@@ -2049,7 +2099,15 @@ class Conv3x3C64F32Fn(_Fn):
         if ctx.needs_input_grad[0]:
             if CONV3X3_F32 and x.shape[0] >= CONV3X3_F32_MIN_N:
                 # dX = conv3x3(dY, w') with w'[ci][r][s][co] = w[co][2 - r][2 - s][ci], read out of w by the kernel (+ the identity path's gradient)
-                dx = conv3x3_c64_f32(_nhwc(dy), _nhwc(w), input_gradient=True, res=None if dshared is None else _nhwc(dshared)).permute(0, 3, 1, 2)
+                bn = ctx.bn_src
+                r = conv3x3_c64_f32(_nhwc(dy), _nhwc(w), input_gradient=True, res=None if dshared is None else _nhwc(dshared),
+                                    want_stats=bn is not None, bn=None if bn is None else bn[1:])
+                if bn is not None:
+                    if len(_BN_PENDING) > 64:
+                        _BN_PENDING.clear()
+                    _BN_PENDING[bn[0]] = (r[0].data_ptr(), r[1])
+                    r = r[0]
+                dx = r.permute(0, 3, 1, 2)
             else:
                 dx = torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0]
                 if dshared is not None:
@@ -2059,7 +2117,7 @@ class Conv3x3C64F32Fn(_Fn):
                 dw = conv3x3_c64_wgrad_f32(_nhwc(x), dy.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
             else:
                 dw = torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
-        return dx, dw, None, None
+        return dx, dw, None, None, None
 
 
 # The 128-input-channel 3x3 convolutions on 28 x 28 maps (resnet.layer2's 128 -> 128 convolutions forward and input gradient, the forward of
@@ -2071,7 +2129,7 @@ CONV_F32_STATS = os.environ.get("RP_CONV_F32_STATS", "1") != "0"
 CONV3X3_C128_F32_MIN_N = int(os.environ.get("RP_CONV3X3_C128_F32_MIN_N", "56"))
 
 
-def conv3x3_c128_f32(x_nhwc, w_ohwi, bias=None, input_gradient=False, want_stats=False, res=None):
+def conv3x3_c128_f32(x_nhwc, w_ohwi, bias=None, input_gradient=False, want_stats=False, res=None, bn=None):
     """rp_conv3x3_c128_f32: y = bias + conv3x3(x, w), stride 1, pad 1, exact fp32, for x [N,28,28,128] (NHWC memory) and w [CO,3,3,128]
     (the memory of a channels-last [CO,128,3,3] weight), CO = 128 or 192 -> y [N,28,28,CO].  input_gradient (CO = 128, no bias): x is dY,
     the result dX of the convolution whose forward weight is w.  want_stats: also returns the per-chunk sums of y and y^2 per channel
@@ -2094,7 +2152,7 @@ def conv3x3_c128_f32(x_nhwc, w_ohwi, bias=None, input_gradient=False, want_stats
     stats = (torch.empty(lib.rp_conv3x3_c128_f32_blocks(N, CO) // (CO // 64), 2, CO, device=x_nhwc.device, dtype=torch.float64)
              if want_stats else None)
     with timed("conv3x3_c128_f32", 2.0 * N * 28 * 28 * 128 * CO * 9, 4.0 * N * 28 * 28 * (128 + CO)):
-        _lib.check(lib.rp_conv3x3_c128_f32(_p(x_nhwc), _p(w_ohwi), _p(bias), _p(y), _p(stats), _p(res), N, 28, 28, CO,
+        _lib.check(lib.rp_conv3x3_c128_f32(_p(x_nhwc), _p(w_ohwi), _p(bias), _p(y), _p(stats), _p(res), _bn_mask(bn, y, want_stats), N, 28, 28, CO,
                                            1 if input_gradient else 0, _st()), "rp_conv3x3_c128_f32")
     return (y, stats) if want_stats else y
 
@@ -2103,10 +2161,11 @@ class Conv3x3C128F32Fn(_Fn):
     """forward (and, for the square filter, input gradient) on rp_conv3x3_c128_f32; weight / bias gradients on MIOpen"""
 
     @staticmethod
-    def forward(ctx, x, w, bias, want_stats=False, share_input=False):
-        """want_stats / share_input: see Conv3x3C64F32Fn"""
+    def forward(ctx, x, w, bias, want_stats=False, share_input=False, bn_src=None):
+        """want_stats / share_input / bn_src: see Conv3x3C64F32Fn"""
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
+        ctx.bn_src = bn_src if w.shape[0] == 128 else None
         stats = None
         if want_stats and CONV_F32_STATS:
             y, stats = conv3x3_c128_f32(_nhwc(x), _nhwc(w), bias, want_stats=True)
@@ -2127,7 +2186,15 @@ class Conv3x3C128F32Fn(_Fn):
         CO = w.shape[0]
         own_dx = ctx.needs_input_grad[0] and CO == 128
         if own_dx:
-            dx = conv3x3_c128_f32(_nhwc(dy), _nhwc(w), input_gradient=True, res=None if dshared is None else _nhwc(dshared)).permute(0, 3, 1, 2)
+            bn = ctx.bn_src
+            r = conv3x3_c128_f32(_nhwc(dy), _nhwc(w), input_gradient=True, res=None if dshared is None else _nhwc(dshared),
+                                 want_stats=bn is not None, bn=None if bn is None else bn[1:])
+            if bn is not None:
+                if len(_BN_PENDING) > 64:
+                    _BN_PENDING.clear()
+                _BN_PENDING[bn[0]] = (r[0].data_ptr(), r[1])
+                r = r[0]
+            dx = r.permute(0, 3, 1, 2)
         mask = [bool(ctx.needs_input_grad[0]) and not own_dx, bool(ctx.needs_input_grad[1]), ctx.has_bias and bool(ctx.needs_input_grad[2])]
         if any(mask):
             g = torch.ops.aten.convolution_backward(dy, x, w, [CO] if ctx.has_bias else None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, mask)
@@ -2136,7 +2203,7 @@ class Conv3x3C128F32Fn(_Fn):
             db = g[2] if mask[2] else None
             if mask[0] and dshared is not None:
                 dx = dx + dshared
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
 def conv3x3_c128_f32_ok(m, x):
@@ -2173,16 +2240,17 @@ def conv2d(m, x, want_stats=False):
             return Conv3x3C64Fn.apply(xb, m._rp_bf16[0], True)
         if CNN_PRECISION == 0 and x.is_cuda and torch.is_grad_enabled():
             # exact-fp32 configuration: the own convolutions write the statistics partials in their epilogue
+            bn_src = getattr(x, "_rp_bn", None) if CONV_F32_BN_BWD else None
             if conv3x3_f32_ok(m, x):
-                return Conv3x3C64F32Fn.apply(x, m.weight, True, False)
+                return Conv3x3C64F32Fn.apply(x, m.weight, True, False, bn_src)
             if conv3x3_c128_f32_ok(m, x):
-                return Conv3x3C128F32Fn.apply(x, m.weight, m.bias, True, False)
+                return Conv3x3C128F32Fn.apply(x, m.weight, m.bias, True, False, bn_src if m.weight.shape[0] == 128 else None)
         return conv2d(m, x), None
     if CNN_PRECISION == 0 or not x.is_cuda:
         if conv3x3_wgrad_f32_ok(m, x) or conv3x3_f32_ok(m, x):
-            return Conv3x3C64F32Fn.apply(x, m.weight, False, False)
+            return Conv3x3C64F32Fn.apply(x, m.weight, False, False, None)
         if conv3x3_c128_f32_ok(m, x):
-            return Conv3x3C128F32Fn.apply(x, m.weight, m.bias, False, False)
+            return Conv3x3C128F32Fn.apply(x, m.weight, m.bias, False, False, None)
         return m(x)
     bf = torch.bfloat16
     ready = getattr(m, "_rp_bf16", None)
@@ -2211,9 +2279,9 @@ def conv2d_shared(m, x):
     epilogue (no separate add pass); otherwise x' is x."""
     if (CONV_F32_SHARE_INPUT and CNN_PRECISION == 0 and x.is_cuda and torch.is_grad_enabled() and x.requires_grad):
         if conv3x3_f32_ok(m, x):
-            return Conv3x3C64F32Fn.apply(x, m.weight, True, True)
+            return Conv3x3C64F32Fn.apply(x, m.weight, True, True, None)
         if conv3x3_c128_f32_ok(m, x) and m.weight.shape[0] == 128 and m.bias is None:
-            return Conv3x3C128F32Fn.apply(x, m.weight, None, True, True)
+            return Conv3x3C128F32Fn.apply(x, m.weight, None, True, True, None)
     y, st = conv2d(m, x, want_stats=True)
     return y, st, x
 
@@ -2255,8 +2323,11 @@ def bn_act(bn, x, residual=None, relu=True, stats=None):
         return torch.relu(y) if relu else y
     if bn.training and bn.track_running_stats:
         _bump_batches_tracked(bn)
-    return BnActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, bn.training, bn.momentum, bn.eps,
-                         relu, stats if bn.training else None)
+    y = BnActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, bn.training, bn.momentum, bn.eps,
+                      relu, stats if bn.training else None)
+    if _BN_LAST is not None:
+        y._rp_bn = _BN_LAST          # (picked up by conv2d when the consumer is a hand-written fp32 convolution)
+    return y
 
 
 class GeodesicLossFn(_Fn):

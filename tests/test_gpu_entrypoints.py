@@ -444,7 +444,7 @@ def test_evaluation_scripts_reproduce_the_references_runs(tmp_path, monkeypatch)
 FP32_SWITCHES = ["SPLITK_BATCHING", "ROWS_LINEAR", "ROWS_DX", "FUSE_LN_BWD", "DW192_F32", "COLSUM_BATCHING", "ATTN_BWD_STORE_DS",
                  "EMM_BWD_STORE_DS", "QKV_BIAS_FROM_PRODUCERS", "EMM_STATS_ONE_PASS", "FUSE_MLP", "FUSE_MLP_TRAIN", "FUSE_MLP_BWD", "MLP_BWD_LN",
                  "USE_SIDE_STREAM", "STEM_CONV", "STEM_STATS", "FUSE_STEM_POOL", "CONV3X3_WGRAD_F32_MIN_N", "STEM_WGRAD", "ATTN_STORE_P",
-                 "EMM_STORE_S", "CONV3X3_F32_MIN_N", "CONV3X3_C128_F32_MIN_N", "CONV_F32_STATS", "CONV_F32_SHARE_INPUT"]
+                 "EMM_STORE_S", "CONV3X3_F32_MIN_N", "CONV3X3_C128_F32_MIN_N", "CONV_F32_STATS", "CONV_F32_SHARE_INPUT", "CONV_F32_BN_BWD"]
 BF16_SWITCHES = ["ACT_BF16", "BF16_PATH", "DX_LNBWD_BF16", "DW192", "MLP_W2_CHUNK_MAJOR", "MLP_BWD_LN", "CONV3X3_OWN", "CONV3X3_OWN_WGRAD", "STEM_CONV",
                  "STEM_WGRAD", "STEM_STATS", "CONV_BWD_AS_FWD_MIN_K"]
 

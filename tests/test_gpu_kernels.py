@@ -306,7 +306,7 @@ def test_conv3x3_c64_weight_gradient_exact_fp32(ops, N):
         e = rel(dw.permute(0, 3, 1, 2), ref.double())
         bound = 2e-5
     x1, w1 = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
-    y1 = ops.Conv3x3C64F32Fn.apply(x1, w1, False, False)
+    y1 = ops.Conv3x3C64F32Fn.apply(x1, w1, False, False, None)
     y1.backward(dy)
     x2, w2 = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
     y2 = F.conv2d(x2, w2, None, 1, 1)
@@ -359,7 +359,7 @@ def test_conv3x3_c64_forward_and_input_gradient_exact_fp32(ops, N):
     rres = rnd(N, 56, 56, 64, seed=16)
     assert torch.equal(ops.conv3x3_c64_f32(dyr, wr, input_gradient=True, res=rres), dx + rres)
     xs_, ws_ = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
-    ys_, _, xalias = ops.Conv3x3C64F32Fn.apply(xs_, ws_, True, True)
+    ys_, _, xalias = ops.Conv3x3C64F32Fn.apply(xs_, ws_, True, True, None)
     ((ys_ * dy).sum() + (xalias * rres.permute(0, 3, 1, 2)).sum()).backward()
     xp_, wp_ = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
     ((F.conv2d(xp_, wp_, None, 1, 1) * dy).sum() + (xp_ * rres.permute(0, 3, 1, 2)).sum()).backward()
@@ -408,7 +408,7 @@ def test_conv3x3_c128_forward_and_input_gradient_exact_fp32(ops, N, CO):
             e_dx = max(e_dx, float((dx[i:i + 16].permute(0, 3, 1, 2).double() - xs.grad).abs().max() / xs.grad.abs().max()))
     x1, w1 = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
     b1 = None if b is None else b.clone().requires_grad_(True)
-    ops.Conv3x3C128F32Fn.apply(x1, w1, b1, False, False).backward(dy)
+    ops.Conv3x3C128F32Fn.apply(x1, w1, b1, False, False, None).backward(dy)
     x2, w2 = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
     b2 = None if b is None else b.clone().requires_grad_(True)
     F.conv2d(x2, w2, b2, 1, 1).backward(dy)
@@ -423,7 +423,7 @@ def test_conv3x3_c128_forward_and_input_gradient_exact_fp32(ops, N, CO):
         rres = rnd(N, 28, 28, 128, seed=26)
         assert torch.equal(ops.conv3x3_c128_f32(dyr, wr, input_gradient=True, res=rres), dx + rres)
         xs_, ws_ = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
-        ys_, _, xalias = ops.Conv3x3C128F32Fn.apply(xs_, ws_, None, True, True)
+        ys_, _, xalias = ops.Conv3x3C128F32Fn.apply(xs_, ws_, None, True, True, None)
         ((ys_ * dy).sum() + (xalias * rres.permute(0, 3, 1, 2)).sum()).backward()
         xp_, wp_ = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
         ((F.conv2d(xp_, wp_, None, 1, 1) * dy).sum() + (xp_ * rres.permute(0, 3, 1, 2)).sum()).backward()
@@ -439,6 +439,59 @@ def test_conv3x3_c128_forward_and_input_gradient_exact_fp32(ops, N, CO):
     if CO == 192:
         with pytest.raises(RuntimeError):
             ops.conv3x3_c128_f32(xr, wr, input_gradient=True)
+
+
+@pytest.mark.parametrize("C,HW,N", [(64, 56, 3), (64, 56, 37), (64, 56, 128), (128, 28, 3), (128, 28, 37), (128, 28, 128)])
+def test_batchnorm_backward_first_pass_in_the_convolution_epilogue(ops, C, HW, N, monkeypatch):
+    """a = relu(bn1(x1)); y = conv2(a) (torchvision BasicBlock, src/model.py:131-132) in the exact-fp32 configuration: the hand-written
+    input-gradient kernel of conv2 masks its result with bn1's ReLU and forms bn1's backward column sums (sum g, sum g * xhat) in its
+    epilogue (RpBnMask), rp_bn_bwd_from_partials runs only the second and third pass.  (1) kernel level: g against dX * [fma(x - mean,
+    rstd * gamma, beta) > 0] and the partials against fp64 sums of g and g * xhat (2e-7 of the sums of magnitudes); (2) autograd level:
+    ops.bn_act + ops.conv2d with the fusion on against the same chain with it off (rp_bn_bwd's three passes): every gradient within 2e-6
+    (same arithmetic, another summation order of the column sums)."""
+    import torch.nn as nn
+    CL = torch.channels_last
+    monkeypatch.setattr(ops, "CONV3X3_F32_MIN_N", 0)
+    monkeypatch.setattr(ops, "CONV3X3_WGRAD_F32_MIN_N", 0)
+    monkeypatch.setattr(ops, "CONV3X3_C128_F32_MIN_N", 0)
+    x1 = rnd(N, C, HW, HW, seed=31).contiguous(memory_format=CL)
+    dy = rnd(N, C, HW, HW, seed=32).contiguous(memory_format=CL)
+    w = rnd(C, C, 3, 3, seed=33, scale=(C * 9) ** -0.5).contiguous(memory_format=CL)
+    gamma, beta = 1 + 0.2 * rnd(C, seed=34), 0.2 * rnd(C, seed=35)
+    xr, dyr, wr = x1.permute(0, 2, 3, 1), dy.permute(0, 2, 3, 1), w.permute(0, 2, 3, 1)
+    x2d = xr.reshape(-1, C)
+    mean = x2d.mean(0)
+    rstd = (x2d.var(0, unbiased=False) + 1e-5).rsqrt()
+    conv = ops.conv3x3_c64_f32 if C == 64 else ops.conv3x3_c128_f32
+    dx_plain = conv(dyr, wr, input_gradient=True)
+    g, part = conv(dyr, wr, input_gradient=True, want_stats=True, bn=(xr, mean, rstd, gamma, beta))
+    yv = torch.addcmul(beta, xr - mean, rstd * gamma)                 # (two roundings where the kernel has one fma: the sign can differ next to 0)
+    sure = yv.abs() > 1e-5
+    assert torch.equal(torch.where(sure, g, 0 * g), torch.where(sure & (yv > 0), dx_plain, 0 * g))
+    gd = g.double().reshape(-1, C)
+    xh = ((x2d - mean) * rstd).double()
+    e1 = float(((part[:, 0].sum(0) - gd.sum(0)).abs() / gd.abs().sum(0)).max())
+    e2 = float(((part[:, 1].sum(0) - (gd * xh).sum(0)).abs() / (gd * xh).abs().sum(0)).max())
+    assert part.dtype == torch.float64 and part.shape[1:] == (2, C) and e1 < 2e-7 and e2 < 2e-7, (e1, e2)
+    # autograd level
+    grads = {}
+    for fused in (True, False):
+        monkeypatch.setattr(ops, "CONV_F32_BN_BWD", fused)
+        bn = nn.BatchNorm2d(C).cuda().train()
+        cv = nn.Conv2d(C, C, 3, 1, 1, bias=False).cuda()
+        with torch.no_grad():
+            bn.weight.copy_(gamma); bn.bias.copy_(beta); cv.weight.copy_(w)
+        cv.weight.data = cv.weight.data.contiguous(memory_format=CL)
+        xi = x1.clone().requires_grad_(True)
+        a = ops.bn_act(bn, xi)
+        assert (getattr(a, "_rp_bn", None) is not None) == fused
+        y, _ = ops.conv2d(cv, a, want_stats=True)
+        y.backward(dy)
+        grads[fused] = (xi.grad, bn.weight.grad, bn.bias.grad, cv.weight.grad)
+        assert not ops._BN_PENDING
+    errs = [rel(u, v) for u, v in zip(grads[True], grads[False])]
+    report("bn_bwd_in_conv_epilogue[C=%d,N=%d]" % (C, N), partial_sum=e1, partial_sum_xhat=e2, dx=errs[0], dgamma=errs[1], dbeta=errs[2], dw=errs[3])
+    assert max(errs) < 2e-6, errs
 
 
 @pytest.mark.parametrize("ci,co,k,pad,h", [(128, 192, 5, 0, 28), (192, 192, 5, 0, 28), (64, 96, 3, 1, 20)])

@@ -237,7 +237,7 @@ int rp_conv3x3_c64_wgrad_f32(const float* x, const float* dy, float* dw, void* w
  * v_mfma_f32_16x16x4_f32), the input rows in a padded LDS ring read by one conflict-free ds_read_b32 per MFMA; one persistent
  * workgroup per CU (rp_conv3x3_c64_f32_blocks).  input_gradient != 0: x is dY and y is dX of the same convolution -- the filter
  * w'[ci][r][s][co] = w[co][2 - r][2 - s][ci] is read out of the forward weight w (no rotated copy). */
-/* BatchNorm-backward epilogue of the two convolution kernels below (input_gradient launches): the convolution's result is the gradient of
+/* BatchNorm-backward epilogue of rp_conv3x3_c64_f32 (input_gradient launches): the convolution's result is the gradient of
  * a = relu(batch_norm(x)) (torchvision BasicBlock: out = relu(bn1(conv1(.))) feeds conv2); with `bn` given the kernel masks it,
  * g = result * (fma(x - mean, rstd * gamma, beta) > 0) -- bit for bit rp_bn_apply_fwd's expression --, stores g instead, and `stats` receives
  * the per-workgroup sums of g and g * (x - mean) * rstd: the column sums rp_bn_bwd's first pass would read dy and x again for.
@@ -259,12 +259,14 @@ int rp_conv3x3_c64_f32(const float* x, const float* w, float* y, double* stats, 
  * registers (a wave owns 16 output channels: 288 VGPRs of 16x16x4 A operands), CO / 64 channel groups of workgroups per tile of four image
  * rows, padded 6-slot LDS row ring.  stats (both kernels): NULL, or [blocks / channel groups][2][CO] doubles that receive per-workgroup sums of y
  * and y^2 per output channel -- the BatchNorm batch statistics of the output, finished by rp_bn_stats_from_partials with a zero pivot, so
- * the statistics pass over y is not needed (reference: nn.BatchNorm2d behind every one of these convolutions).  res (both kernels): NULL, or a
- * tensor of y's shape that is added to the result in the epilogue -- used for the input gradient of a BasicBlock's first convolution, where
- * autograd would add the gradient arriving over the identity path (torchvision BasicBlock: out += identity) in a pass of its own.  input_gradient != 0 (CO == 128, no bias): x is dY and y is dX of the convolution whose FORWARD weight is w. */
+ * the statistics pass over y is not needed (reference: nn.BatchNorm2d behind every one of these convolutions).  res (rp_conv3x3_c64_f32): NULL,
+ * or a tensor of y's shape that is added to the result in the epilogue -- used for the input gradient of a BasicBlock's first convolution,
+ * where autograd would add the gradient arriving over the identity path (torchvision BasicBlock: out += identity) in a pass of its own.  (The
+ * 128-channel kernel has no registers to request a second epilogue operand a tile early, and exposed loads of it cost what the saved passes
+ * over its four-times-smaller maps would bring: measured break-even, profiles/r6_ab.txt -- it keeps the statistics epilogue only.)  input_gradient != 0 (CO == 128, no bias): x is dY and y is dX of the convolution whose FORWARD weight is w. */
 int rp_conv3x3_c128_f32_blocks(int N, int CO);
-int rp_conv3x3_c128_f32(const float* x, const float* w, const float* bias, float* y, double* stats, const float* res, const RpBnMask* bn, int N,
-                        int H, int W, int CO, int input_gradient, void* stream);
+int rp_conv3x3_c128_f32(const float* x, const float* w, const float* bias, float* y, double* stats, int N, int H, int W, int CO,
+                        int input_gradient, void* stream);
 
 /* The stem's BatchNorm -> ReLU -> MaxPool2d(3, 2, 1) chain (src/model.py:127-130 on torchvision's resnet.bn1 / relu / maxpool) without
  * the [N,H,W,C] intermediates.  Forward (after rp_bn_stats, or with the running statistics in eval): y [N,OH,OW,C], idx = window

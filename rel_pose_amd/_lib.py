@@ -154,7 +154,7 @@ _SIGS = {
     "rp_conv3x3_c64_f32_blocks": (c_int, [I]),
     "rp_conv3x3_c64_f32": (c_int, [P, P, P, P, P, POINTER(RpBnMask), I, I, I, I, P]),
     "rp_conv3x3_c128_f32_blocks": (c_int, [I, I]),
-    "rp_conv3x3_c128_f32": (c_int, [P, P, P, P, P, P, POINTER(RpBnMask), I, I, I, I, I, P]),
+    "rp_conv3x3_c128_f32": (c_int, [P, P, P, P, P, I, I, I, I, I, P]),
     "rp_bn_stats_from_partials": (c_int, [P, I, L, I, P, P, P, P, P, F, F, P]),
     "rp_bn_relu_pool_fwd": (c_int, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "rp_bn_relu_pool_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P]),

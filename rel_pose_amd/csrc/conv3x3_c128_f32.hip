@@ -40,8 +40,6 @@ struct CvG {
   const float* w;       // forward: [CO][3][3][128]; input gradient: the forward weight [128 (= this kernel's K)][3][3][CO = 128]
   const float* bias;    // [CO] or null
   float* y;             // [N,28,28,CO]
-  const float* res;     // null, or [N,28,28,CO]: added to the result (input gradient + the gradient over the identity path of a BasicBlock)
-  RpBnMask bn;          // bn.x != null: the result is masked by the ReLU of batch_norm(bn.x) and `stats` receives sums of g and g * xhat
   double* stats;        // null, or [tile chunks][2][CO]: per-chunk sums of y and y^2 per output channel (BatchNorm statistics of the output for
                         // rp_bn_stats_from_partials; a workgroup writes the 64 channels of its group)
   int ntiles;           // N * 7
@@ -63,8 +61,6 @@ template <int N, class F> RP_DEV void sforg(F&& f) {
 
 __global__ __launch_bounds__(256, 1) void conv3x3_c128_f32_kernel(CvG p) {
   __shared__ __attribute__((aligned(16))) float Xr[NSLOT + 1][ROWF];      // 109 984 B
-  __shared__ double Sd[8][256];      // per-thread epilogue sums (0-3: first, 4-7: second quantity) across tiles, in double -- in LDS: the
-                                     // tile loop has no 16 VGPRs to spare (288 filter registers)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, kq = lane >> 4;
   // workgroup b = 8 q + x runs on XCD x: channel group q % ncg of tile chunk (q / ncg) * 8 + x -- the groups of a chunk share an L2
   const int ncg = p.CO >> 6, q = blockIdx.x >> 3;
@@ -75,8 +71,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c128_f32_kernel(CvG p) {
     if (p.stats && tid < 128) p.stats[((long long)chunk * 2 + (tid >> 6)) * p.CO + 64 * cg + (tid & 63)] = 0.0;
     return;
   }
-#pragma unroll
-  for (int e = 0; e < 8; ++e) Sd[e][tid] = 0.0;                           // this lane's sums over its pixels, channels 16 wave + 4 kq + e
+  double sd1[4] = {0.0, 0.0, 0.0, 0.0}, sd2[4] = {0.0, 0.0, 0.0, 0.0};      // this lane's sums of y, y^2 over its pixels, channels 16 wave + 4 kq + e
   const unsigned xs0 = lds_byte_addr(&Xr[0][0]);
   const int lastrow = p.ntiles * RT - 1;
   // staging: NR consecutive rows from flattened (image, row) index g = NR * 896 float4, 3.5 NR per thread: float4 f -> row f / 896, pixel
@@ -159,10 +154,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c128_f32_kernel(CvG p) {
   }
   __syncthreads();
 
-  // per-lane pixel of each 16-pixel block: flattened index 16 j + l15 of the four rows -> (row 0 .. 3, column); recomputed where needed
-  // (two compares per block) instead of held in 14 registers across the tile
-  auto px_row = [&](int j) { const int pxi = 16 * j + l15; return (pxi >= IW) + (pxi >= 2 * IW) + (pxi >= 3 * IW); };
-  auto px_col = [&](int j) { return 16 * j + l15 - IW * px_row(j); };
+  // per-lane pixel of each 16-pixel block: flattened index 16 j + l15 of the four rows -> (row 0 .. 3, column)
+  int orow[NBLK], ocol[NBLK];
+#pragma unroll
+  for (int j = 0; j < NBLK; ++j) {
+    const int pxi = 16 * j + l15;
+    orow[j] = pxi / IW;
+    ocol[j] = pxi - IW * orow[j];
+  }
 
   for (int t = t0; t < t1; ++t) {
     const int y = RT * (t % TPI), g0 = RT * t;
@@ -174,11 +173,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c128_f32_kernel(CvG p) {
     for (int j = 0; j < NBLK; ++j)
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
-        const int yin = y + px_row(j) + r - 1;
-        int slot = m0 + px_row(j) + r;
+        const int yin = y + orow[j] + r - 1;
+        int slot = m0 + orow[j] + r;
         slot = slot >= NSLOT ? slot - NSLOT : slot;
         slot = (yin < 0 || yin >= IH) ? NSLOT : slot;
-        xa[j][r] = xs0 + (unsigned)(slot * ROWF + px_col(j) * PS + kq) * 4u;
+        xa[j][r] = xs0 + (unsigned)(slot * ROWF + ocol[j] * PS + kq) * 4u;
       }
     f32x4 acc[NBLK];
 #pragma unroll
@@ -207,53 +206,20 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c128_f32_kernel(CvG p) {
         }
       });
     });
-    // D[m = co 4 kq + e][n = pixel l15]: four consecutive output channels of one pixel per lane.  The epilogue's two sums per channel: y and
-    // y^2 (forward: BatchNorm statistics of the output), or -- bn -- g and g * xhat of the masked gradient g (the BatchNorm's backward sums);
-    // fp32 over the tile's seven pixels, double across tiles.  (No registers left to request res / bn.x a tile early: seven loads, one wait.)
-    if (p.res) {
-      float4 rv[NBLK];
-#pragma unroll
-      for (int j = 0; j < NBLK; ++j) rv[j] = ld4(p.res + (((long long)g0 + px_row(j)) * IW + px_col(j)) * p.CO + 64 * cg + 16 * wave + 4 * kq);
-#pragma unroll
-      for (int j = 0; j < NBLK; ++j) { acc[j][0] += rv[j].x; acc[j][1] += rv[j].y; acc[j][2] += rv[j].z; acc[j][3] += rv[j].w; }
-    }
-    float ta[4] = {0.f, 0.f, 0.f, 0.f}, tq[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.bn.x) {
-      const int ch = 64 * cg + 16 * wave + 4 * kq;
-      const float4 mu4 = ld4(p.bn.mean + ch), rs4 = ld4(p.bn.rstd + ch), ga4 = ld4(p.bn.gamma + ch), be4 = ld4(p.bn.beta + ch);
-      const float bmu[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, brs[4] = {rs4.x, rs4.y, rs4.z, rs4.w}, bbe[4] = {be4.x, be4.y, be4.z, be4.w};
-      const float brg[4] = {rs4.x * ga4.x, rs4.y * ga4.y, rs4.z * ga4.z, rs4.w * ga4.w};
-      float4 bx[NBLK];
-#pragma unroll
-      for (int j = 0; j < NBLK; ++j) bx[j] = ld4(p.bn.x + (((long long)g0 + px_row(j)) * IW + px_col(j)) * p.CO + ch);
-#pragma unroll
-      for (int j = 0; j < NBLK; ++j) {
-        const float xs[4] = {bx[j].x, bx[j].y, bx[j].z, bx[j].w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float d = xs[e] - bmu[e];
-          const float yv = __builtin_fmaf(d, brg[e], bbe[e]);          // = bn_affine (csrc/batchnorm.hip), bit for bit
-          acc[j][e] = yv > 0.f ? acc[j][e] : 0.f;
-          ta[e] += acc[j][e];
-          tq[e] = fmaf(acc[j][e], d * brs[e], tq[e]);
-        }
-      }
-    } else if (p.stats) {
-#pragma unroll
-      for (int j = 0; j < NBLK; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { ta[e] += acc[j][e]; tq[e] = fmaf(acc[j][e], acc[j][e], tq[e]); }
-    }
+    // D[m = co 4 kq + e][n = pixel l15]: four consecutive output channels of one pixel per lane
 #pragma unroll
     for (int j = 0; j < NBLK; ++j) {
-      float* o = p.y + (((long long)g0 + px_row(j)) * IW + px_col(j)) * p.CO + 64 * cg + 16 * wave + 4 * kq;
+      float* o = p.y + (((long long)g0 + orow[j]) * IW + ocol[j]) * p.CO + 64 * cg + 16 * wave + 4 * kq;
       st4(o, make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]));
     }
-    if (p.stats) {                                            // (wave-uniform)
+    if (p.stats) {                                            // (wave-uniform) fp32 over the tile's seven pixels, double across tiles
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        Sd[e][tid] += (double)ta[e];
-        Sd[4 + e][tid] += (double)tq[e];
+        float a = 0.f, q = 0.f;
+#pragma unroll
+        for (int j = 0; j < NBLK; ++j) { a += acc[j][e]; q = fmaf(acc[j][e], acc[j][e], q); }
+        sd1[e] += (double)a;
+        sd2[e] += (double)q;
       }
     }
     if (t + 1 < t1) {
@@ -268,8 +234,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c128_f32_kernel(CvG p) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int ch = 16 * wave + 4 * kq + e;
-      red[ch * 16 + l15] = Sd[e][tid];
-      red[1024 + ch * 16 + l15] = Sd[4 + e][tid];
+      red[ch * 16 + l15] = sd1[e];
+      red[1024 + ch * 16 + l15] = sd2[e];
     }
     __syncthreads();
     if (tid < 128) {
@@ -297,18 +263,13 @@ extern "C" int rp_conv3x3_c128_f32_blocks(int N, int CO) {
 /* y [N,28,28,CO] = bias + conv3x3(x [N,28,28,128], w [CO][3][3][128]), stride 1, pad 1, exact fp32 (NHWC memory; w = the memory of a
  * channels-last [CO,128,3,3] weight; CO = 128 or 192; bias [CO] or null).  input_gradient != 0 (CO == 128): x is dY and the result is dX of
  * the 128 -> 128 convolution whose FORWARD weight is w -- the filter w'[ci][r][s][co] = w[co][2 - r][2 - s][ci] is read out of it.  stats: NULL,
- * or [rp_conv3x3_c128_f32_blocks(N, CO) / (CO / 64)][2][CO] doubles = per-chunk sums of y and y^2 per channel (rp_bn_stats_from_partials).
- * res: NULL, or a tensor of y's shape that is ADDED to the result in the epilogue.  bn: NULL, or the BatchNorm-mask epilogue (RpBnMask;
- * needs stats; mean / rstd / gamma / beta 16-byte aligned). */
-extern "C" int rp_conv3x3_c128_f32(const float* x, const float* w, const float* bias, float* y, double* stats, const float* res, const RpBnMask* bn,
-                                   int N, int H, int W, int CO, int input_gradient, void* stream) {
+ * or [rp_conv3x3_c128_f32_blocks(N, CO) / (CO / 64)][2][CO] doubles = per-chunk sums of y and y^2 per channel (rp_bn_stats_from_partials). */
+extern "C" int rp_conv3x3_c128_f32(const float* x, const float* w, const float* bias, float* y, double* stats, int N, int H, int W, int CO,
+                                   int input_gradient, void* stream) {
   if (!x || !w || !y || N <= 0) return RP_EBADSHAPE;
   if (H != IH || W != IW || (CO != 128 && CO != 192) || (input_gradient && (CO != 128 || bias))) return RP_EUNSUPPORTED;
-  if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)bias | (uintptr_t)stats | (uintptr_t)res) & 15) return RP_EALIGN;
-  if (bn && (!bn->x || !bn->mean || !bn->rstd || !bn->gamma || !bn->beta || !stats ||
-             (((uintptr_t)bn->x | (uintptr_t)bn->mean | (uintptr_t)bn->rstd | (uintptr_t)bn->gamma | (uintptr_t)bn->beta) & 15)))
-    return RP_EBADSHAPE;
-  CvG p{x, w, bias, y, res, bn ? *bn : RpBnMask{nullptr, nullptr, nullptr, nullptr, nullptr}, stats, N * TPI, CO, input_gradient ? 1 : 0};
+  if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)bias | (uintptr_t)stats) & 15) return RP_EALIGN;
+  CvG p{x, w, bias, y, stats, N * TPI, CO, input_gradient ? 1 : 0};
   hipLaunchKernelGGL(conv3x3_c128_f32_kernel, dim3(rp_conv3x3_c128_f32_blocks(N, CO)), dim3(256), 0, (hipStream_t)stream, p);
   RP_CHECK_LAUNCH();
   return RP_OK;

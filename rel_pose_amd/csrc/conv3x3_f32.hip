@@ -62,6 +62,9 @@ template <int N, class F> RP_DEV void sforc(F&& f) {
   }
 }
 
+// RES / BN: the epilogue options as TEMPLATE parameters -- as run-time branches of one kernel they cost the plain launches 15 us each (294 -> 406
+// registers and a different schedule around the tile loop: profiles/r6_ab.txt), more than the passes they replace bring
+template <bool RES, bool BN>
 __global__ __launch_bounds__(256, 1) void conv3x3_c64_f32_kernel(CvF p) {
   __shared__ __attribute__((aligned(16))) float Xr[NSLOT + 1][ROWF];      // 107 968 B
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, kq = lane >> 4;
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_f32_kernel(CvF p) {
 
   // BatchNorm-mask epilogue: this lane's four channels' mean, rstd * gamma (the forward's product), beta, rstd
   float bmu[4] = {0.f, 0.f, 0.f, 0.f}, brg[4] = {0.f, 0.f, 0.f, 0.f}, bbe[4] = {0.f, 0.f, 0.f, 0.f}, brs[4] = {0.f, 0.f, 0.f, 0.f};
-  if (p.bn.x) {
+  if constexpr (BN) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int ch = 16 * wave + 4 * kq + e;
@@ -153,11 +156,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_f32_kernel(CvF p) {
 #pragma unroll
     for (int j = 0; j < NBLK; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     float4 rv[NBLK], bx[NBLK];                               // the residual / the BatchNorm input at this tile's outputs, requested a tile's worth of MFMAs early
-    if (p.res) {
+    if constexpr (RES) {
 #pragma unroll
       for (int j = 0; j < NBLK; ++j) rv[j] = ld4(p.res + (((long long)g0 + orow[j]) * IW + ocol[j]) * C + 16 * wave + 4 * kq);
     }
-    if (p.bn.x) {
+    if constexpr (BN) {
 #pragma unroll
       for (int j = 0; j < NBLK; ++j) bx[j] = ld4(p.bn.x + (((long long)g0 + orow[j]) * IW + ocol[j]) * C + 16 * wave + 4 * kq);
     }
@@ -192,8 +195,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_f32_kernel(CvF p) {
 #pragma unroll
     for (int j = 0; j < NBLK; ++j) {
       const long long off = (((long long)g0 + orow[j]) * IW + ocol[j]) * C + 16 * wave + 4 * kq;
-      if (p.res) { acc[j][0] += rv[j].x; acc[j][1] += rv[j].y; acc[j][2] += rv[j].z; acc[j][3] += rv[j].w; }
-      if (p.bn.x) {
+      if constexpr (RES) { acc[j][0] += rv[j].x; acc[j][1] += rv[j].y; acc[j][2] += rv[j].z; acc[j][3] += rv[j].w; }
+      if constexpr (BN) {
         const float4 xv = bx[j];
         const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
@@ -260,7 +263,11 @@ extern "C" int rp_conv3x3_c64_f32(const float* x, const float* w, float* y, doub
   if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)stats | (uintptr_t)res) & 15) return RP_EALIGN;
   if (bn && (!bn->x || !bn->mean || !bn->rstd || !bn->gamma || !bn->beta || !stats || ((uintptr_t)bn->x & 15))) return RP_EBADSHAPE;
   CvF p{x, w, y, N * TPI, res, bn ? *bn : RpBnMask{nullptr, nullptr, nullptr, nullptr, nullptr}, stats, input_gradient ? 1 : 0};
-  hipLaunchKernelGGL(conv3x3_c64_f32_kernel, dim3(rp_conv3x3_c64_f32_blocks(N)), dim3(256), 0, (hipStream_t)stream, p);
+  const dim3 grid(rp_conv3x3_c64_f32_blocks(N));
+  if (bn && res) return RP_EUNSUPPORTED;
+  if (bn) hipLaunchKernelGGL((conv3x3_c64_f32_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  else if (res) hipLaunchKernelGGL((conv3x3_c64_f32_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((conv3x3_c64_f32_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
   RP_CHECK_LAUNCH();
   return RP_OK;
 }

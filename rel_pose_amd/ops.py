@@ -2129,7 +2129,7 @@ CONV_F32_STATS = os.environ.get("RP_CONV_F32_STATS", "1") != "0"
 CONV3X3_C128_F32_MIN_N = int(os.environ.get("RP_CONV3X3_C128_F32_MIN_N", "56"))
 
 
-def conv3x3_c128_f32(x_nhwc, w_ohwi, bias=None, input_gradient=False, want_stats=False, res=None, bn=None):
+def conv3x3_c128_f32(x_nhwc, w_ohwi, bias=None, input_gradient=False, want_stats=False):
     """rp_conv3x3_c128_f32: y = bias + conv3x3(x, w), stride 1, pad 1, exact fp32, for x [N,28,28,128] (NHWC memory) and w [CO,3,3,128]
     (the memory of a channels-last [CO,128,3,3] weight), CO = 128 or 192 -> y [N,28,28,CO].  input_gradient (CO = 128, no bias): x is dY,
     the result dX of the convolution whose forward weight is w.  want_stats: also returns the per-chunk sums of y and y^2 per channel
@@ -2146,14 +2146,12 @@ def conv3x3_c128_f32(x_nhwc, w_ohwi, bias=None, input_gradient=False, want_stats
     if bias is not None and not (bias.is_cuda and bias.is_contiguous() and bias.dtype == torch.float32 and tuple(bias.shape) == (CO,)):
         raise RuntimeError("conv3x3_c128_f32: contiguous fp32 [CO] GPU bias expected")
     N = x_nhwc.shape[0]
-    if res is not None and not (res.is_cuda and res.is_contiguous() and res.dtype == torch.float32 and tuple(res.shape) == (N, 28, 28, CO)):
-        raise RuntimeError("conv3x3_c128_f32: res must be a contiguous fp32 [N,28,28,CO] tensor")
     y = torch.empty(N, 28, 28, CO, device=x_nhwc.device, dtype=torch.float32)
     stats = (torch.empty(lib.rp_conv3x3_c128_f32_blocks(N, CO) // (CO // 64), 2, CO, device=x_nhwc.device, dtype=torch.float64)
              if want_stats else None)
     with timed("conv3x3_c128_f32", 2.0 * N * 28 * 28 * 128 * CO * 9, 4.0 * N * 28 * 28 * (128 + CO)):
-        _lib.check(lib.rp_conv3x3_c128_f32(_p(x_nhwc), _p(w_ohwi), _p(bias), _p(y), _p(stats), _p(res), _bn_mask(bn, y, want_stats), N, 28, 28, CO,
-                                           1 if input_gradient else 0, _st()), "rp_conv3x3_c128_f32")
+        _lib.check(lib.rp_conv3x3_c128_f32(_p(x_nhwc), _p(w_ohwi), _p(bias), _p(y), _p(stats), N, 28, 28, CO, 1 if input_gradient else 0,
+                                           _st()), "rp_conv3x3_c128_f32")
     return (y, stats) if want_stats else y
 
 
@@ -2161,49 +2159,33 @@ class Conv3x3C128F32Fn(_Fn):
     """forward (and, for the square filter, input gradient) on rp_conv3x3_c128_f32; weight / bias gradients on MIOpen"""
 
     @staticmethod
-    def forward(ctx, x, w, bias, want_stats=False, share_input=False, bn_src=None):
-        """want_stats / share_input / bn_src: see Conv3x3C64F32Fn"""
+    def forward(ctx, x, w, bias, want_stats=False):
+        """want_stats: see Conv3x3C64F32Fn"""
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
-        ctx.bn_src = bn_src if w.shape[0] == 128 else None
-        stats = None
         if want_stats and CONV_F32_STATS:
             y, stats = conv3x3_c128_f32(_nhwc(x), _nhwc(w), bias, want_stats=True)
             ctx.mark_non_differentiable(stats)
-        else:
-            y = conv3x3_c128_f32(_nhwc(x), _nhwc(w), bias)
-        y = y.permute(0, 3, 1, 2)                                  # (channels-last NCHW view of the NHWC result)
-        if share_input:
-            return y, stats, x.view_as(x)
-        return (y, stats) if want_stats else y
+            return y.permute(0, 3, 1, 2), stats
+        y = conv3x3_c128_f32(_nhwc(x), _nhwc(w), bias).permute(0, 3, 1, 2)           # (channels-last NCHW view of the NHWC result)
+        return (y, None) if want_stats else y
 
     @staticmethod
-    def backward(ctx, dy, *rest):
+    def backward(ctx, dy, *_):
         x, w = ctx.saved_tensors
         dx = dw = db = None
         dy = dy.contiguous(memory_format=torch.channels_last)
-        dshared = rest[1] if len(rest) > 1 else None
         CO = w.shape[0]
         own_dx = ctx.needs_input_grad[0] and CO == 128
         if own_dx:
-            bn = ctx.bn_src
-            r = conv3x3_c128_f32(_nhwc(dy), _nhwc(w), input_gradient=True, res=None if dshared is None else _nhwc(dshared),
-                                 want_stats=bn is not None, bn=None if bn is None else bn[1:])
-            if bn is not None:
-                if len(_BN_PENDING) > 64:
-                    _BN_PENDING.clear()
-                _BN_PENDING[bn[0]] = (r[0].data_ptr(), r[1])
-                r = r[0]
-            dx = r.permute(0, 3, 1, 2)
+            dx = conv3x3_c128_f32(_nhwc(dy), _nhwc(w), input_gradient=True).permute(0, 3, 1, 2)
         mask = [bool(ctx.needs_input_grad[0]) and not own_dx, bool(ctx.needs_input_grad[1]), ctx.has_bias and bool(ctx.needs_input_grad[2])]
         if any(mask):
             g = torch.ops.aten.convolution_backward(dy, x, w, [CO] if ctx.has_bias else None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, mask)
             dx = g[0] if mask[0] else dx
             dw = g[1] if mask[1] else None
             db = g[2] if mask[2] else None
-            if mask[0] and dshared is not None:
-                dx = dx + dshared
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None
 
 
 def conv3x3_c128_f32_ok(m, x):
@@ -2244,13 +2226,13 @@ def conv2d(m, x, want_stats=False):
             if conv3x3_f32_ok(m, x):
                 return Conv3x3C64F32Fn.apply(x, m.weight, True, False, bn_src)
             if conv3x3_c128_f32_ok(m, x):
-                return Conv3x3C128F32Fn.apply(x, m.weight, m.bias, True, False, bn_src if m.weight.shape[0] == 128 else None)
+                return Conv3x3C128F32Fn.apply(x, m.weight, m.bias, True)
         return conv2d(m, x), None
     if CNN_PRECISION == 0 or not x.is_cuda:
         if conv3x3_wgrad_f32_ok(m, x) or conv3x3_f32_ok(m, x):
             return Conv3x3C64F32Fn.apply(x, m.weight, False, False, None)
         if conv3x3_c128_f32_ok(m, x):
-            return Conv3x3C128F32Fn.apply(x, m.weight, m.bias, False, False, None)
+            return Conv3x3C128F32Fn.apply(x, m.weight, m.bias, False)
         return m(x)
     bf = torch.bfloat16
     ready = getattr(m, "_rp_bf16", None)
@@ -2274,14 +2256,12 @@ CONV_F32_SHARE_INPUT = os.environ.get("RP_CONV_F32_SHARE_INPUT", "1") != "0"
 
 def conv2d_shared(m, x):
     """(y, stats, x') for the FIRST convolution of a residual block whose identity path is x itself: y = m(x), stats as conv2d(...,
-    want_stats=True), and x' = the tensor to use for the identity path.  With the own exact-fp32 convolutions x' is an output of the
+    want_stats=True), and x' = the tensor to use for the identity path.  With the own exact-fp32 64-channel convolution x' is an output of the
     convolution's autograd node, so the gradient of the identity path is handed to that node and added in its input-gradient kernel's
     epilogue (no separate add pass); otherwise x' is x."""
     if (CONV_F32_SHARE_INPUT and CNN_PRECISION == 0 and x.is_cuda and torch.is_grad_enabled() and x.requires_grad):
         if conv3x3_f32_ok(m, x):
             return Conv3x3C64F32Fn.apply(x, m.weight, True, True, None)
-        if conv3x3_c128_f32_ok(m, x) and m.weight.shape[0] == 128 and m.bias is None:
-            return Conv3x3C128F32Fn.apply(x, m.weight, None, True, True, None)
     y, st = conv2d(m, x, want_stats=True)
     return y, st, x
 

@@ -267,7 +267,7 @@ TAG_SYMBOLS = {
     "attn_fwd_bf16": "attn_fwd_bf16_kernel<2, false, 1>", "attn_stats_bf16": "attn_fwd_bf16_kernel<3, true, 1>", "attn_bwd_bf16": "attn_bwd_dkdv_bf16_kernel + attn_bwd_dq_bf16_kernel",
     "dx_lnbwd_bf16": "dx_lnbwd_bf16_kernel",
     "emm_apply_bf16": "emm_apply_bf16_kernel", "emm_grad_bf16": "emm_grad_bf16_kernel",
-    "conv3x3_c64_f32": "conv3x3_c64_f32_kernel", "conv3x3_c128_f32": "conv3x3_c128_f32_kernel", "conv_stem_fwd": "conv_stem_fwd_kernel", "conv3x3_c64_wgrad_f32": "conv3x3_c64_wgrad_f32_kernel", "conv_stem_wgrad_f32": "conv_stem_wgrad_f32_kernel",
+    "conv3x3_c64_f32": "conv3x3_c64_f32_kernel<false, false>", "conv3x3_c128_f32": "conv3x3_c128_f32_kernel", "conv_stem_fwd": "conv_stem_fwd_kernel", "conv3x3_c64_wgrad_f32": "conv3x3_c64_wgrad_f32_kernel", "conv_stem_wgrad_f32": "conv_stem_wgrad_f32_kernel",
     "conv3x3_c64_bf16": "conv3x3_c64_kernel", "conv3x3_c64_wgrad_bf16": "conv3x3_c64_wgrad_kernel", "conv_stem_fwd_bf16": "conv_stem_bf16_kernel",
     "conv_stem_wgrad_bf16": "conv_stem_wgrad_kernel",
 }

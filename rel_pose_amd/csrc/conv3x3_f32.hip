@@ -102,14 +102,40 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_f32_kernel(CvF p) {
   gload(pre2, a0 + 2);
   // the filter of this wave's 16 output channels: A operand of k-step (tap, kk) = W[16 wave + l15][tap][4 kk + kq]
   float wreg[9][16];
-  {
-    // A[m = output channel 16 wave + l15][k = input channel 4 kk + kq] of tap (r, s)
-    const int so = p.dgrad ? 1 : 9 * C, si = p.dgrad ? 9 * C : 1;
-    const float* wp = p.w + (long long)(16 * wave + l15) * so + (long long)kq * si;
+  if (p.dgrad) {
+    // W'[ci][r][s][co] = W[co][2 - r][2 - s][ci] out of the forward weight: A[m][k] of tap = w[k][8 - tap][m] -- the 16 lanes of a kq group read
+    // 64 contiguous bytes
+    const float* wp = p.w + (16 * wave + l15) + (long long)kq * (9 * C);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-      for (int kk = 0; kk < 16; ++kk) wreg[tap][kk] = wp[(p.dgrad ? 8 - tap : tap) * C + (long long)(4 * kk) * si];
+      for (int kk = 0; kk < 16; ++kk) wreg[tap][kk] = wp[(8 - tap) * C + (long long)(4 * kk) * (9 * C)];
+  } else {
+    // forward: lane (m, kq) needs W[m][tap][4 kk + kq], 4-byte pieces 16 bytes apart = sixteen 64-byte requests per wave instruction (the
+    // forward launches ran 12-15 us behind the input gradients).  Instead the four kq lanes of a channel read the row as 16-byte pieces (lane
+    // kq: floats 16 j + 4 kq .. + 3) and transpose the 4 x 4 blocks among themselves (conv3x3_c128_f32.hip): v_permlane32_swap exchanges the
+    // off-diagonal 2 x 2 blocks (lanes l, l + 32), v_permlane16_swap transposes inside them (lanes l, l + 16).
+    const float* wp = p.w + (long long)(16 * wave + l15) * (9 * C) + 4 * kq;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 v = ld4(wp + tap * C + 16 * j);
+        unsigned r0 = __builtin_bit_cast(unsigned, v.x), r1 = __builtin_bit_cast(unsigned, v.y), r2 = __builtin_bit_cast(unsigned, v.z),
+                 r3 = __builtin_bit_cast(unsigned, v.w);
+        auto a = __builtin_amdgcn_permlane32_swap(r0, r2, false, false);
+        r0 = a[0]; r2 = a[1];
+        auto b = __builtin_amdgcn_permlane32_swap(r1, r3, false, false);
+        r1 = b[0]; r3 = b[1];
+        auto c = __builtin_amdgcn_permlane16_swap(r0, r1, false, false);
+        r0 = c[0]; r1 = c[1];
+        auto d = __builtin_amdgcn_permlane16_swap(r2, r3, false, false);
+        r2 = d[0]; r3 = d[1];
+        wreg[tap][4 * j + 0] = __builtin_bit_cast(float, r0);
+        wreg[tap][4 * j + 1] = __builtin_bit_cast(float, r1);
+        wreg[tap][4 * j + 2] = __builtin_bit_cast(float, r2);
+        wreg[tap][4 * j + 3] = __builtin_bit_cast(float, r3);
+      }
   }
   // zero padding of the ring slots (staging only ever writes positions 1 .. 56) and the zero row
   for (int i = tid; i < NSLOT * 2 * PS; i += 256) Xr[i / (2 * PS)][((i / PS) & 1) * (IW + 1) * PS + (i % PS)] = 0.f;

@@ -35,6 +35,31 @@ template <> RP_DEV float4 ldv<bf16s>(const bf16s* p) {
 template <typename T> RP_DEV void stv(T* p, float4 v);
 template <> RP_DEV void stv<float>(float* p, float4 v) { st4(p, v); }
 template <> RP_DEV void stv<bf16s>(bf16s* p, float4 v) { *reinterpret_cast<uint2*>(p) = make_uint2(pk_bf16(v.x, v.y), pk_bf16(v.z, v.w)); }
+// G float4 groups (4 G channels) per thread and access: 1 for fp32 (16 bytes); 2 for bf16 storage when C % 8 == 0 -- with 8-byte accesses the bf16
+// passes were INSTRUCTION-bound (the same bytes took 1.5x the fp32 kernels' time: profiles/r6_ab.txt), with 16-byte accesses they are HBM-bound
+template <typename T, int G> RP_DEV void ldg(const T* p, float4 (&v)[G]) {
+  if constexpr (G == 1) {
+    v[0] = ldv<T>(p);
+  } else {
+    static_assert(sizeof(T) == 2 && G == 2, "two groups per access: bf16 storage only");
+    const uint4 w = *reinterpret_cast<const uint4*>(p);
+    v[0] = make_float4(__builtin_bit_cast(float, w.x << 16), __builtin_bit_cast(float, w.x & 0xffff0000u),
+                       __builtin_bit_cast(float, w.y << 16), __builtin_bit_cast(float, w.y & 0xffff0000u));
+    v[1] = make_float4(__builtin_bit_cast(float, w.z << 16), __builtin_bit_cast(float, w.z & 0xffff0000u),
+                       __builtin_bit_cast(float, w.w << 16), __builtin_bit_cast(float, w.w & 0xffff0000u));
+  }
+}
+template <typename T, int G> RP_DEV void stg(T* p, const float4 (&v)[G]) {
+  if constexpr (G == 1) {
+    stv<T>(p, v[0]);
+  } else {
+    *reinterpret_cast<uint4*>(p) = make_uint4(pk_bf16(v[0].x, v[0].y), pk_bf16(v[0].z, v[0].w), pk_bf16(v[1].x, v[1].y), pk_bf16(v[1].z, v[1].w));
+  }
+}
+static bool bn_wide(int bf16, int C) {
+  static const bool off = getenv("RP_BN_NARROW") != nullptr;       // A/B aid: 8-byte bf16 accesses as before
+  return bf16 && (C % 8) == 0 && !off;
+}
 template <typename T> RP_DEV float ld1(const T* p);
 template <> RP_DEV float ld1<float>(const float* p) { return *p; }
 template <> RP_DEV float ld1<bf16s>(const bf16s* p) { return __builtin_bit_cast(float, (unsigned)(*p) << 16); }
@@ -190,6 +215,95 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ x,
   }
 }
 
+// bn_reduce_kernel<MODE, false, T> with G float4 groups (4 G channels) per thread: one 16-byte access per row and thread for bf16 storage (G = 2).
+// Same sums; the per-thread row sets differ from the G = 1 form (256 / (C / 4G) row lanes), so the results agree to rounding, not bitwise.
+template <int MODE, typename T, int G>
+__global__ __launch_bounds__(256) void bn_reduce_g_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ gout,
+                                                          double* __restrict__ partial, long long R, int C, int rpb, int relu) {
+  __shared__ double red[2][256][4 * G];
+  constexpr int W = 4 * G;
+  const int cgn = C / W, nrl = 256 / cgn;
+  const int tid = threadIdx.x, cg = tid % cgn, rl = tid / cgn;
+  const long long r0 = (long long)blockIdx.x * rpb, r1 = min(R, r0 + rpb);
+  double a0[W], b0[W];
+#pragma unroll
+  for (int e = 0; e < W; ++e) { a0[e] = 0.0; b0[e] = 0.0; }
+  if (rl < nrl) {
+    float4 mu[G], rs[G], ga[G], be[G], pv[G], sa[G], sb[G];
+    const bool remask = MODE == 1 && relu && y == nullptr;       // ReLU mask rebuilt from x (no residual was added)
+    if (MODE == 0) ldg<T, G>(x + W * cg, pv);                    // pivot = row 0 of the tensor (see bn_reduce_kernel)
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      mu[g] = rs[g] = ga[g] = be[g] = sa[g] = sb[g] = z;
+      if (MODE == 0) continue;
+      pv[g] = z;
+      mu[g] = ld4(mean + W * cg + 4 * g);
+      rs[g] = ld4(rstd + W * cg + 4 * g);
+      if (remask) { ga[g] = ld4(gamma + W * cg + 4 * g); be[g] = ld4(beta + W * cg + 4 * g); }
+    }
+    int cnt = 0;
+    auto row = [&](long long r) {
+      const long long off = r * C + W * cg;
+      float4 xv[G], gv[G], yv[G];
+      ldg<T, G>(x + off, xv);
+      if (MODE == 1) {
+        ldg<T, G>(dy + off, gv);
+        if (relu && !remask) ldg<T, G>(y + off, yv);
+      }
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        if (MODE == 0) {
+          const float dx_ = xv[g].x - pv[g].x, dy_ = xv[g].y - pv[g].y, dz_ = xv[g].z - pv[g].z, dw_ = xv[g].w - pv[g].w;
+          sa[g].x += dx_; sa[g].y += dy_; sa[g].z += dz_; sa[g].w += dw_;
+          sb[g].x += dx_ * dx_; sb[g].y += dy_ * dy_; sb[g].z += dz_ * dz_; sb[g].w += dw_ * dw_;
+        } else {
+          if (remask) yv[g] = bn_affine(xv[g], mu[g], rs[g], ga[g], be[g]);
+          if (relu) {
+            gv[g].x = yv[g].x > 0.f ? gv[g].x : 0.f; gv[g].y = yv[g].y > 0.f ? gv[g].y : 0.f;
+            gv[g].z = yv[g].z > 0.f ? gv[g].z : 0.f; gv[g].w = yv[g].w > 0.f ? gv[g].w : 0.f;
+          }
+          sa[g].x += gv[g].x; sa[g].y += gv[g].y; sa[g].z += gv[g].z; sa[g].w += gv[g].w;
+          sb[g].x += gv[g].x * (xv[g].x - mu[g].x) * rs[g].x; sb[g].y += gv[g].y * (xv[g].y - mu[g].y) * rs[g].y;
+          sb[g].z += gv[g].z * (xv[g].z - mu[g].z) * rs[g].z; sb[g].w += gv[g].w * (xv[g].w - mu[g].w) * rs[g].w;
+        }
+      }
+      if (MODE == 1 && gout) stg<T, G>(gout + off, gv);
+    };
+    auto flush = [&]() {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        a0[4 * g] += sa[g].x; a0[4 * g + 1] += sa[g].y; a0[4 * g + 2] += sa[g].z; a0[4 * g + 3] += sa[g].w;
+        b0[4 * g] += sb[g].x; b0[4 * g + 1] += sb[g].y; b0[4 * g + 2] += sb[g].z; b0[4 * g + 3] += sb[g].w;
+        sa[g] = make_float4(0.f, 0.f, 0.f, 0.f); sb[g] = sa[g];
+      }
+    };
+    constexpr int U = 4;                     // rows in flight per thread
+    long long r = r0 + rl;
+    for (; r + (U - 1) * (long long)nrl < r1; r += (long long)U * nrl) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) row(r + (long long)u * nrl);
+      cnt += U;
+      if (cnt >= 64) { flush(); cnt = 0; }       // fp32 partials over <= 64 rows, double above that
+    }
+    for (; r < r1; r += nrl) row(r);
+    flush();
+  }
+#pragma unroll
+  for (int e = 0; e < W; ++e) { red[0][tid][e] = a0[e]; red[1][tid][e] = b0[e]; }
+  __syncthreads();
+  if (tid < cgn) {          // row lane 0 of each column group sums the others (fixed order)
+    for (int l = 1; l < nrl; ++l)
+#pragma unroll
+      for (int e = 0; e < W; ++e) { a0[e] += red[0][tid + l * cgn][e]; b0[e] += red[1][tid + l * cgn][e]; }
+    double* p = partial + (long long)blockIdx.x * 2 * C;
+#pragma unroll
+    for (int e = 0; e < W; ++e) { p[W * cg + e] = a0[e]; p[C + W * cg + e] = b0[e]; }
+  }
+}
+
 // stage 2: a block takes 16 channels x 64 lanes (1024 threads); lane l sums block partials l, l + 64, ... (<= 16 of them: all loads
 // independent and in flight together -- the round-2 form walked 64 partials per lane behind each other and took 11 us, 26 times per
 // step), then the 64 lane sums of a channel are combined through LDS in a fixed order (8 x 8), all in double.
@@ -254,22 +368,24 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const double* __restr
 }
 
 // y = relu?((x - mean) * rstd * gamma + beta (+ residual))
-template <typename T>
+template <typename T, int G>
 __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const T* __restrict__ x, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const T* __restrict__ res,
-                                                           T* __restrict__ y, long long n4, int c4n, int relu) {
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-    const int c = 4 * (int)(i % c4n);
-    const float4 xv = ldv<T>(x + 4 * i), mu = ld4(mean + c), rs = ld4(rstd + c), ga = ld4(gamma + c), be = ld4(beta + c);
-    float4 v;
-    v = bn_affine(xv, mu, rs, ga, be);
-    if (res) {
-      const float4 r = ldv<T>(res + 4 * i);
-      v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                                                           T* __restrict__ y, long long ng, int cgn, int relu) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < ng; i += (long long)gridDim.x * 256) {
+    const int c = 4 * G * (int)(i % cgn);
+    float4 xv[G], r[G], v[G];
+    ldg<T, G>(x + 4 * G * i, xv);
+    if (res) ldg<T, G>(res + 4 * G * i, r);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const float4 mu = ld4(mean + c + 4 * g), rs = ld4(rstd + c + 4 * g), ga = ld4(gamma + c + 4 * g), be = ld4(beta + c + 4 * g);
+      v[g] = bn_affine(xv[g], mu, rs, ga, be);
+      if (res) { v[g].x += r[g].x; v[g].y += r[g].y; v[g].z += r[g].z; v[g].w += r[g].w; }
+      if (relu) { v[g].x = fmaxf(v[g].x, 0.f); v[g].y = fmaxf(v[g].y, 0.f); v[g].z = fmaxf(v[g].z, 0.f); v[g].w = fmaxf(v[g].w, 0.f); }
     }
-    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-    stv<T>(y + 4 * i, v);
+    stg<T, G>(y + 4 * G * i, v);
   }
 }
 
@@ -311,6 +427,47 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const T* __restrict__
   }
 }
 
+// bn_apply_bwd_kernel<false, T> with G groups per thread (same arithmetic per element)
+template <typename T, int G>
+__global__ __launch_bounds__(256) void bn_apply_bwd_g_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ gin,
+                                                             const T* __restrict__ x, const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ c12,
+                                                             T* __restrict__ dx, long long ng, int cgn, int relu) {
+  const int C = 4 * G * cgn;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < ng; i += (long long)gridDim.x * 256) {
+    const int c0 = 4 * G * (int)(i % cgn);
+    float4 xv[G], gv[G], yv[G], v[G];
+    ldg<T, G>(x + 4 * G * i, xv);
+    if (gin) {
+      ldg<T, G>(gin + 4 * G * i, gv);
+    } else {
+      ldg<T, G>(dy + 4 * G * i, gv);
+      if (relu && y) ldg<T, G>(y + 4 * G * i, yv);
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int c = c0 + 4 * g;
+      const float4 rs = ld4(rstd + c), ga = ld4(gamma + c), mu = ld4(mean + c);
+      if (!gin && relu) {
+        if (!y) yv[g] = bn_affine(xv[g], mu, rs, ga, ld4(beta + c));
+        gv[g].x = yv[g].x > 0.f ? gv[g].x : 0.f; gv[g].y = yv[g].y > 0.f ? gv[g].y : 0.f;
+        gv[g].z = yv[g].z > 0.f ? gv[g].z : 0.f; gv[g].w = yv[g].w > 0.f ? gv[g].w : 0.f;
+      }
+      if (c12) {
+        const float4 c1 = ld4(c12 + c), c2 = ld4(c12 + C + c);
+        v[g].x = (ga.x * rs.x) * (gv[g].x - c1.x - (xv[g].x - mu.x) * rs.x * c2.x);
+        v[g].y = (ga.y * rs.y) * (gv[g].y - c1.y - (xv[g].y - mu.y) * rs.y * c2.y);
+        v[g].z = (ga.z * rs.z) * (gv[g].z - c1.z - (xv[g].z - mu.z) * rs.z * c2.z);
+        v[g].w = (ga.w * rs.w) * (gv[g].w - c1.w - (xv[g].w - mu.w) * rs.w * c2.w);
+      } else {
+        v[g].x = ga.x * rs.x * gv[g].x; v[g].y = ga.y * rs.y * gv[g].y; v[g].z = ga.z * rs.z * gv[g].z; v[g].w = ga.w * rs.w * gv[g].w;
+      }
+    }
+    stg<T, G>(dx + 4 * G * i, v);
+  }
+}
+
 int bn_check(long long R, int C) {
   if (R <= 0 || C <= 0 || (C & 3) || C > BN_MAXC) return RP_EBADSHAPE;
   return RP_OK;
@@ -331,8 +488,14 @@ template <typename T>
 static int bn_stats_t(const T* x, long long R, int C, double* partial, float* mean, float* rstd, float* running_mean,
                       float* running_var, float momentum, float eps, hipStream_t st) {
   const int rpb = bn_rows_per_block(R), nblk = (int)((R + rpb - 1) / rpb);
-  hipLaunchKernelGGL((bn_reduce_kernel<0, false, T>), dim3(nblk), dim3(256), 0, st, x, (const T*)nullptr, (const T*)nullptr, nullptr, nullptr,
-                     nullptr, nullptr, (T*)nullptr, partial, R, C, rpb, 0, PoolSrc{});
+  bool wide = false;
+  if constexpr (sizeof(T) == 2) wide = bn_wide(1, C);
+  if constexpr (sizeof(T) == 2) {
+    if (wide) hipLaunchKernelGGL((bn_reduce_g_kernel<0, T, 2>), dim3(nblk), dim3(256), 0, st, x, (const T*)nullptr, (const T*)nullptr, nullptr, nullptr,
+                                 nullptr, nullptr, (T*)nullptr, partial, R, C, rpb, 0);
+  }
+  if (!wide) hipLaunchKernelGGL((bn_reduce_kernel<0, false, T>), dim3(nblk), dim3(256), 0, st, x, (const T*)nullptr, (const T*)nullptr, nullptr, nullptr,
+                                nullptr, nullptr, (T*)nullptr, partial, R, C, rpb, 0, PoolSrc{});
   RP_CHECK_LAUNCH();
   hipLaunchKernelGGL((bn_finalize_kernel<0, T>), dim3((C + 15) / 16), dim3(1024), 0, st, (const double*)partial, nblk, C, R, mean,
                      rstd, running_mean, running_var, momentum, eps, nullptr, x);
@@ -364,9 +527,11 @@ extern "C" int rp_bn_apply_fwd(const void* x, const float* mean, const float* rs
                                const void* residual, void* y, long long R, int C, int relu, int bf16, void* stream) {
   if (int e = bn_check(R, C)) return e;
   const long long n4 = R * C / 4;
-  if (bf16) hipLaunchKernelGGL(bn_apply_fwd_kernel<bf16s>, dim3(apply_grid(n4)), dim3(256), 0, (hipStream_t)stream, (const bf16s*)x, mean, rstd,
-                               gamma, beta, (const bf16s*)residual, (bf16s*)y, n4, C / 4, relu);
-  else hipLaunchKernelGGL(bn_apply_fwd_kernel<float>, dim3(apply_grid(n4)), dim3(256), 0, (hipStream_t)stream, (const float*)x, mean, rstd, gamma,
+  if (bn_wide(bf16, C)) hipLaunchKernelGGL((bn_apply_fwd_kernel<bf16s, 2>), dim3(apply_grid(n4 / 2)), dim3(256), 0, (hipStream_t)stream, (const bf16s*)x,
+                                           mean, rstd, gamma, beta, (const bf16s*)residual, (bf16s*)y, n4 / 2, C / 8, relu);
+  else if (bf16) hipLaunchKernelGGL((bn_apply_fwd_kernel<bf16s, 1>), dim3(apply_grid(n4)), dim3(256), 0, (hipStream_t)stream, (const bf16s*)x, mean,
+                                    rstd, gamma, beta, (const bf16s*)residual, (bf16s*)y, n4, C / 4, relu);
+  else hipLaunchKernelGGL((bn_apply_fwd_kernel<float, 1>), dim3(apply_grid(n4)), dim3(256), 0, (hipStream_t)stream, (const float*)x, mean, rstd, gamma,
                           beta, (const float*)residual, (float*)y, n4, C / 4, relu);
   RP_CHECK_LAUNCH();
   return RP_OK;
@@ -377,13 +542,27 @@ static int bn_bwd_t(const T* dy, const T* y, const T* x, const float* mean, cons
                     T* dx, T* dres, float* dgamma, float* dbeta, double* partial, float* c12, long long R, int C, int relu, int training,
                     hipStream_t st) {
   const int rpb = bn_rows_per_block(R), nblk = (int)((R + rpb - 1) / rpb);
-  hipLaunchKernelGGL((bn_reduce_kernel<1, false, T>), dim3(nblk), dim3(256), 0, st, x, dy, y, mean, rstd, gamma, beta, dres, partial, R, C, rpb,
-                     relu, PoolSrc{});
+  bool wide = false;
+  if constexpr (sizeof(T) == 2) wide = bn_wide(1, C);
+  if constexpr (sizeof(T) == 2) {
+    if (wide) hipLaunchKernelGGL((bn_reduce_g_kernel<1, T, 2>), dim3(nblk), dim3(256), 0, st, x, dy, y, mean, rstd, gamma, beta, dres, partial, R, C,
+                                 rpb, relu);
+  }
+  if (!wide) hipLaunchKernelGGL((bn_reduce_kernel<1, false, T>), dim3(nblk), dim3(256), 0, st, x, dy, y, mean, rstd, gamma, beta, dres, partial, R, C, rpb,
+                                relu, PoolSrc{});
   RP_CHECK_LAUNCH();
   hipLaunchKernelGGL((bn_finalize_kernel<1, float>), dim3((C + 15) / 16), dim3(1024), 0, st, (const double*)partial, nblk, C, R, dbeta,
                      dgamma, nullptr, nullptr, 0.f, 0.f, c12, nullptr);
   RP_CHECK_LAUNCH();
   const long long n4 = R * C / 4;
+  if constexpr (sizeof(T) == 2) {
+    if (bn_wide(1, C)) {
+      hipLaunchKernelGGL((bn_apply_bwd_g_kernel<T, 2>), dim3(apply_grid(n4 / 2)), dim3(256), 0, st, dy, y, (const T*)dres, x, mean, rstd, gamma, beta,
+                         training ? (const float*)c12 : nullptr, dx, n4 / 2, C / 8, relu);
+      RP_CHECK_LAUNCH();
+      return RP_OK;
+    }
+  }
   hipLaunchKernelGGL((bn_apply_bwd_kernel<false, T>), dim3(apply_grid(n4)), dim3(256), 0, st, dy, y, (const T*)dres, x, mean, rstd, gamma,
                      beta, training ? (const float*)c12 : nullptr, dx, n4, C / 4, relu, PoolSrc{});
   RP_CHECK_LAUNCH();
@@ -529,22 +708,28 @@ namespace {
 
 // pooled[n,oh,ow,c] = max over the window of relu(bn(x)); idx = window position of the FIRST maximum (strict >), i.e. exactly
 // maxpool_fwd_kernel applied to bn_apply_fwd_kernel's output, which is never written
-template <typename T>
+template <typename T, int G>
 __global__ __launch_bounds__(256) void bn_pool_fwd_kernel(const T* __restrict__ x, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, T* __restrict__ y,
                                                           unsigned char* __restrict__ idx, int N, int H, int W, int C, int OH, int OW) {
-  const int c4n = C >> 2;
-  const long long total = (long long)N * OH * OW * c4n;
+  constexpr int CW = 4 * G;                                       // channels per thread (G = 2: one 16-byte access of bf16 storage)
+  const int cgn = C / CW;
+  const long long total = (long long)N * OH * OW * cgn;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int c4 = (int)(i % c4n);
-    long long p = i / c4n;
+    const int c = CW * (int)(i % cgn);
+    long long p = i / cgn;
     const int ow = (int)(p % OW);
     p /= OW;
     const int oh = (int)(p % OH), n = (int)(p / OH);
-    const float4 mu = ld4(mean + 4 * c4), rs = ld4(rstd + 4 * c4), ga = ld4(gamma + 4 * c4), be = ld4(beta + 4 * c4);
-    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-    int kx = 0, ky = 0, kz = 0, kw_ = 0;
+    float4 mu[G], rs[G], ga[G], be[G], m[G];
+    int kk[G][4];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      mu[g] = ld4(mean + c + 4 * g); rs[g] = ld4(rstd + c + 4 * g); ga[g] = ld4(gamma + c + 4 * g); be[g] = ld4(beta + c + 4 * g);
+      m[g] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      kk[g][0] = kk[g][1] = kk[g][2] = kk[g][3] = 0;
+    }
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
       const int ih = 2 * oh - 1 + kh;
@@ -553,17 +738,25 @@ __global__ __launch_bounds__(256) void bn_pool_fwd_kernel(const T* __restrict__ 
       for (int kw = 0; kw < 3; ++kw) {
         const int iw = 2 * ow - 1 + kw;
         if (iw < 0 || iw >= W) continue;
-        float4 v = bn_affine(ldv<T>(x + (((long long)n * H + ih) * W + iw) * C + 4 * c4), mu, rs, ga, be);
-        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        float4 xv[G];
+        ldg<T, G>(x + (((long long)n * H + ih) * W + iw) * C + c, xv);
         const int k = kh * 3 + kw;
-        if (v.x > m.x) { m.x = v.x; kx = k; }
-        if (v.y > m.y) { m.y = v.y; ky = k; }
-        if (v.z > m.z) { m.z = v.z; kz = k; }
-        if (v.w > m.w) { m.w = v.w; kw_ = k; }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          float4 v = bn_affine(xv[g], mu[g], rs[g], ga[g], be[g]);
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+          if (v.x > m[g].x) { m[g].x = v.x; kk[g][0] = k; }
+          if (v.y > m[g].y) { m[g].y = v.y; kk[g][1] = k; }
+          if (v.z > m[g].z) { m[g].z = v.z; kk[g][2] = k; }
+          if (v.w > m[g].w) { m[g].w = v.w; kk[g][3] = k; }
+        }
       }
     }
-    stv<T>(y + 4 * i, m);
-    *reinterpret_cast<uchar4*>(idx + 4 * i) = make_uchar4((unsigned char)kx, (unsigned char)ky, (unsigned char)kz, (unsigned char)kw_);
+    stg<T, G>(y + CW * i, m);
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+      *reinterpret_cast<uchar4*>(idx + CW * i + 4 * g) = make_uchar4((unsigned char)kk[g][0], (unsigned char)kk[g][1], (unsigned char)kk[g][2],
+                                                                     (unsigned char)kk[g][3]);
   }
 }
 
@@ -640,9 +833,11 @@ extern "C" int rp_bn_relu_pool_fwd(const void* x, const float* mean, const float
   if (int e = bn_check((long long)N * H * W, C)) return e;
   const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
   const long long total = (long long)N * OH * OW * (C / 4);
-  if (bf16) hipLaunchKernelGGL(bn_pool_fwd_kernel<bf16s>, dim3(apply_grid(total)), dim3(256), 0, (hipStream_t)stream, (const bf16s*)x, mean, rstd, gamma,
-                               beta, (bf16s*)y, idx, N, H, W, C, OH, OW);
-  else hipLaunchKernelGGL(bn_pool_fwd_kernel<float>, dim3(apply_grid(total)), dim3(256), 0, (hipStream_t)stream, (const float*)x, mean, rstd, gamma,
+  if (bn_wide(bf16, C)) hipLaunchKernelGGL((bn_pool_fwd_kernel<bf16s, 2>), dim3(apply_grid(total / 2)), dim3(256), 0, (hipStream_t)stream, (const bf16s*)x,
+                                           mean, rstd, gamma, beta, (bf16s*)y, idx, N, H, W, C, OH, OW);
+  else if (bf16) hipLaunchKernelGGL((bn_pool_fwd_kernel<bf16s, 1>), dim3(apply_grid(total)), dim3(256), 0, (hipStream_t)stream, (const bf16s*)x, mean, rstd,
+                                    gamma, beta, (bf16s*)y, idx, N, H, W, C, OH, OW);
+  else hipLaunchKernelGGL((bn_pool_fwd_kernel<float, 1>), dim3(apply_grid(total)), dim3(256), 0, (hipStream_t)stream, (const float*)x, mean, rstd, gamma,
                           beta, (float*)y, idx, N, H, W, C, OH, OW);
   RP_CHECK_LAUNCH();
   return RP_OK;
@@ -653,37 +848,48 @@ extern "C" int rp_bn_relu_pool_fwd(const void* x, const float* mean, const float
 // bytes and gradient are read ONCE per patch instead of once per pixel that touches it: bn_apply_bwd_kernel<true> issued 80 bytes of L2
 // reads per 16 bytes of dx (246 us at 128 images, 3.9 TB/s of HBM traffic but L2-bound), this form 20.  Same sums in the same order
 // (windows (a, b), (a, b + 1), (a + 1, b), (a + 1, b + 1)): bit-identical to the pixel-major kernel.
-template <typename T>
+template <typename T, int G>
 __global__ __launch_bounds__(256) void bn_pool_apply_bwd_kernel(const T* __restrict__ dp, const unsigned char* __restrict__ idx,
                                                                 const T* __restrict__ x, const float* __restrict__ mean,
                                                                 const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, const float* __restrict__ c12,
                                                                 T* __restrict__ dx, int N, int H, int W, int C, int OH, int OW) {
-  const int c4n = C >> 2, PH = (H + 1) >> 1, PW = (W + 1) >> 1;
-  const long long total = (long long)N * PH * PW * c4n;
+  constexpr int CW = 4 * G;                                       // channels per thread (G = 2: one 16-byte access of bf16 storage)
+  const int cgn = C / CW, PH = (H + 1) >> 1, PW = (W + 1) >> 1;
+  const long long total = (long long)N * PH * PW * cgn;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int c = 4 * (int)(i % c4n);
-    long long q = i / c4n;
+    const int c = CW * (int)(i % cgn);
+    long long q = i / cgn;
     const int b = (int)(q % PW);
     q /= PW;
     const int a = (int)(q % PH), n = (int)(q / PH);
-    const float4 rs = ld4(rstd + c), ga = ld4(gamma + c), mu = ld4(mean + c), be = ld4(beta + c);
-    float4 c1 = make_float4(0.f, 0.f, 0.f, 0.f), c2 = c1;
-    if (c12) { c1 = ld4(c12 + c); c2 = ld4(c12 + C + c); }
+    float4 rs[G], ga[G], mu[G], be[G], c1[G], c2[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      rs[g] = ld4(rstd + c + 4 * g); ga[g] = ld4(gamma + c + 4 * g); mu[g] = ld4(mean + c + 4 * g); be[g] = ld4(beta + c + 4 * g);
+      c1[g] = c2[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c12) { c1[g] = ld4(c12 + c + 4 * g); c2[g] = ld4(c12 + C + c + 4 * g); }
+    }
     // the four windows of the patch: position bytes and gradients (zero where the window does not exist)
-    uchar4 k4[2][2];
-    float4 d4[2][2];
+    uchar4 k4[2][2][G];
+    float4 d4[2][2][G];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int v = 0; v < 2; ++v) {
         const int oh = a + u, ow = b + v;
-        k4[u][v] = make_uchar4(255, 255, 255, 255);
-        d4[u][v] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int g = 0; g < G; ++g) { k4[u][v][g] = make_uchar4(255, 255, 255, 255); d4[u][v][g] = make_float4(0.f, 0.f, 0.f, 0.f); }
         if (oh < OH && ow < OW) {
           const unsigned o = (((unsigned)n * OH + oh) * OW + ow) * C + c;
-          k4[u][v] = *reinterpret_cast<const uchar4*>(idx + o);
-          d4[u][v] = ldv<T>(dp + o);
+          if constexpr (G == 1) {
+            k4[u][v][0] = *reinterpret_cast<const uchar4*>(idx + o);
+          } else {
+            const uint2 kk = *reinterpret_cast<const uint2*>(idx + o);
+            k4[u][v][0] = __builtin_bit_cast(uchar4, kk.x);
+            k4[u][v][1] = __builtin_bit_cast(uchar4, kk.y);
+          }
+          ldg<T, G>(dp + o, d4[u][v]);
         }
       }
 #pragma unroll
@@ -692,34 +898,37 @@ __global__ __launch_bounds__(256) void bn_pool_apply_bwd_kernel(const T* __restr
       for (int pc = 0; pc < 2; ++pc) {
         const int ih = 2 * a + pr, iw = 2 * b + pc;
         if (ih >= H || iw >= W) continue;
-        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-        // windows in maxpool_bwd_kernel's order; window (a + u, b + v) holds pixel (ih, iw) at position (ih - 2 (a + u) + 1, iw - 2 (b + v) + 1)
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-          for (int v = 0; v < 2; ++v) {
-            const int kh = pr - 2 * u + 1, kw = pc - 2 * v + 1;
-            if (kh < 0 || kh > 2 || kw < 0 || kw > 2) continue;       // (compile-time: pr, pc, u, v are unrolled)
-            const int k = kh * 3 + kw;
-            if (k4[u][v].x == k) g.x += d4[u][v].x;
-            if (k4[u][v].y == k) g.y += d4[u][v].y;
-            if (k4[u][v].z == k) g.z += d4[u][v].z;
-            if (k4[u][v].w == k) g.w += d4[u][v].w;
-          }
         const long long off = (((long long)n * H + ih) * W + iw) * C + c;
-        const float4 xv = ldv<T>(x + off);
-        const float4 yv = bn_affine(xv, mu, rs, ga, be);
-        g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f; g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
-        float4 o;
-        if (c12) {
-          o.x = (ga.x * rs.x) * (g.x - c1.x - (xv.x - mu.x) * rs.x * c2.x);
-          o.y = (ga.y * rs.y) * (g.y - c1.y - (xv.y - mu.y) * rs.y * c2.y);
-          o.z = (ga.z * rs.z) * (g.z - c1.z - (xv.z - mu.z) * rs.z * c2.z);
-          o.w = (ga.w * rs.w) * (g.w - c1.w - (xv.w - mu.w) * rs.w * c2.w);
-        } else {
-          o.x = ga.x * rs.x * g.x; o.y = ga.y * rs.y * g.y; o.z = ga.z * rs.z * g.z; o.w = ga.w * rs.w * g.w;
+        float4 xv[G], o[G];
+        ldg<T, G>(x + off, xv);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          float4 gr = make_float4(0.f, 0.f, 0.f, 0.f);
+          // windows in maxpool_bwd_kernel's order; window (a + u, b + v) holds pixel (ih, iw) at position (ih - 2 (a + u) + 1, iw - 2 (b + v) + 1)
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+              const int kh = pr - 2 * u + 1, kw = pc - 2 * v + 1;
+              if (kh < 0 || kh > 2 || kw < 0 || kw > 2) continue;       // (compile-time: pr, pc, u, v are unrolled)
+              const int k = kh * 3 + kw;
+              if (k4[u][v][g].x == k) gr.x += d4[u][v][g].x;
+              if (k4[u][v][g].y == k) gr.y += d4[u][v][g].y;
+              if (k4[u][v][g].z == k) gr.z += d4[u][v][g].z;
+              if (k4[u][v][g].w == k) gr.w += d4[u][v][g].w;
+            }
+          const float4 yv = bn_affine(xv[g], mu[g], rs[g], ga[g], be[g]);
+          gr.x = yv.x > 0.f ? gr.x : 0.f; gr.y = yv.y > 0.f ? gr.y : 0.f; gr.z = yv.z > 0.f ? gr.z : 0.f; gr.w = yv.w > 0.f ? gr.w : 0.f;
+          if (c12) {
+            o[g].x = (ga[g].x * rs[g].x) * (gr.x - c1[g].x - (xv[g].x - mu[g].x) * rs[g].x * c2[g].x);
+            o[g].y = (ga[g].y * rs[g].y) * (gr.y - c1[g].y - (xv[g].y - mu[g].y) * rs[g].y * c2[g].y);
+            o[g].z = (ga[g].z * rs[g].z) * (gr.z - c1[g].z - (xv[g].z - mu[g].z) * rs[g].z * c2[g].z);
+            o[g].w = (ga[g].w * rs[g].w) * (gr.w - c1[g].w - (xv[g].w - mu[g].w) * rs[g].w * c2[g].w);
+          } else {
+            o[g].x = ga[g].x * rs[g].x * gr.x; o[g].y = ga[g].y * rs[g].y * gr.y; o[g].z = ga[g].z * rs[g].z * gr.z; o[g].w = ga[g].w * rs[g].w * gr.w;
+          }
         }
-        stv<T>(dx + off, o);
+        stg<T, G>(dx + off, o);
       }
   }
 }
@@ -755,8 +964,14 @@ static int bn_relu_pool_bwd_t(const T* dp, const unsigned char* idx, const T* x,
                        x, mean, rstd, gamma, beta, training ? (const float*)c12 : nullptr, dx, n4, C / 4, 1, ps);
   } else {
     const long long np = (long long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
-    hipLaunchKernelGGL(bn_pool_apply_bwd_kernel<T>, dim3(apply_grid(np)), dim3(256), 0, st, dp, idx, x, mean, rstd, gamma, beta,
-                       training ? (const float*)c12 : nullptr, dx, N, H, W, C, ps.OH, ps.OW);
+    bool wide = false;
+    if constexpr (sizeof(T) == 2) wide = bn_wide(1, C);
+    if constexpr (sizeof(T) == 2) {
+      if (wide) hipLaunchKernelGGL((bn_pool_apply_bwd_kernel<T, 2>), dim3(apply_grid(np / 2)), dim3(256), 0, st, dp, idx, x, mean, rstd, gamma, beta,
+                                   training ? (const float*)c12 : nullptr, dx, N, H, W, C, ps.OH, ps.OW);
+    }
+    if (!wide) hipLaunchKernelGGL((bn_pool_apply_bwd_kernel<T, 1>), dim3(apply_grid(np)), dim3(256), 0, st, dp, idx, x, mean, rstd, gamma, beta,
+                                  training ? (const float*)c12 : nullptr, dx, N, H, W, C, ps.OH, ps.OW);
   }
   RP_CHECK_LAUNCH();
   return RP_OK;
